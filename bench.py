@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- FlashFry `discover` on MI355X: guide x target comparisons per second on the hg38-scale workload.
+
+One "step" = one complete pass of the hot path over the resident database shard with the whole guide batch:
+candidate lists -> compare kernel -> hit ordering -> ordered cut-off -> CFD/Hsu2013 scoring -> per-guide aggregates
+(device-resident results; only the per-guide summaries travel to the host).  The database and its two bucketed scan
+images are already in HBM when the timed region starts (ffh_db_load_soa is outside it; its device time is reported
+as db_prepare_ms).  Inputs are synthetic and seeded (flashfry_amd/synth.py) -- there is no genome on the box.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: every rank owns its own database shard of the same size (weak scaling: a genome N times larger, bins sharded
+statically); the only exchange is the per-guide totals all-gather (ordered cut-off across shards) and
+the per-guide aggregate all-reduce over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--targets", type=float, default=3.0e8, help="unique targets per GPU shard (hg38 NGG ~ 3e8)")
+    ap.add_argument("--guides", type=int, default=100000)
+    ap.add_argument("--max-mismatch", type=int, default=4)
+    ap.add_argument("--max-offtargets", type=int, default=2000)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="hg38-scale")
+    return ap.parse_args()
+
+
+def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max_ot, budget_s):
+    """the oracle (C restatement of the reference algorithm, single thread) timed on a bounded sample: the first
+    `nbins` of the 16384 database bins, all guides"""
+    import torch
+    from tests import oracle_lib
+    from flashfry_amd import synth
+    oracle = oracle_lib.load()
+
+    def run(nbins):
+        limit = nbins << 32  # 7-base bin = bits [45:32] of a Cas9 23-mer
+        seq = targets_dev & ((1 << 46) - 1)
+        idx = int(torch.searchsorted(seq, torch.tensor([limit], device=seq.device, dtype=seq.dtype))[0])
+        t = targets_dev[:idx].cpu().numpy().view(np.uint64)
+        p = positions_dev[:int(pos_off_dev[idx])].cpu().numpy().view(np.uint64)
+        odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+        t0 = time.perf_counter()
+        res = odb.discover(guides_np, max_mm, max_ot)
+        dt = time.perf_counter() - t0
+        return idx, dt, res
+
+    nb = 8
+    idx, dt, res = run(nb)
+    # one calibration round towards the time budget
+    per_bin = max(dt, 1e-3) / nb
+    nb2 = int(min(4096, max(nb, budget_s / per_bin)))
+    if nb2 > nb * 2:
+        nb = nb2
+        idx, dt, res = run(nb)
+    G = len(guides_np)
+    return {"value": G * idx / dt, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port",
+            "sample": "oracle/ff_oracle.c (C restatement of the reference loop structure, not the JVM), 1 thread, all %d guides vs the "
+                      "first %d of 16384 bins (%d targets), %.1f s incl. the 16384-bin x guide prefix filter" % (G, nb, idx, dt),
+            "seconds": dt, "executed_comparisons": int(res.all_comparisons), "sample_targets": idx}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from flashfry_amd import capi, synth
+    from flashfry_amd import dist as ffdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    T_req, G = int(args.targets), args.guides
+    # ---- synthetic inputs, generated on the device (same generator as the tests) ----
+    guides_dev = synth.make_guides(G, device=dev)
+    db = synth.make_database(T_req, seed=synth.DB_SEED + rank, plant_guides=guides_dev, device=dev)
+    T, P = db["T"], db["P"]
+    guides_np = guides_dev.cpu().numpy().view(np.uint64)
+    ctx = capi.Context(3, device=local)
+    torch.cuda.synchronize()
+    ctx.load_soa_device(db["targets"].data_ptr(), T, db["positions"].data_ptr(), P)
+    info = ctx.info()
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            cpu = cpu_baseline(db["targets"], db["pos_offsets"], db["positions"], guides_np, args.max_mismatch, args.max_offtargets, args.cpu_seconds)
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the measurement
+            cpu = {"value": None, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    del db
+    torch.cuda.empty_cache()
+
+    def step():
+        ctx.scan(guides_np, args.max_mismatch)
+        prior = None
+        if world > 1:
+            prior = ffdist.prior_totals(ctx.shard_totals(args.max_offtargets), args.max_offtargets, device=dev)
+        res = ctx.finalize(args.max_offtargets, prior_totals=prior, summaries_only=True)
+        if world > 1:
+            ffdist.allreduce_summaries(res.summaries, dev)
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    tms = []
+    for _ in range(args.steps):
+        res = step()
+        tms.append(ctx.timings().as_dict())
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        tsum = torch.tensor([T], device=dev, dtype=torch.int64)
+        dist.all_reduce(tsum)
+        T_total = int(tsum[0])
+    else:
+        T_total = T
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        cmp_ms = float(np.mean([t["compare_ms"] for t in tms]))
+        raw_hits = int(np.mean([t["n_raw_hits"] for t in tms]))
+        kept_pos = int(res.summaries["ot_count"].sum())
+        # algorithmic bytes of ONE compare launch: every resident target once (8 B), every guide once (8 B), one 8-byte record per hit
+        b_alg = 8 * T + 8 * G + 8 * raw_hits
+        b_survey = 8 * T + 8 * G + 16 * raw_hits + 8 * kept_pos  # SURVEY.md §8d formula for the whole discover
+        achieved = b_alg / (cmp_ms * 1e-3) / 1e9
+        pairs = float(np.mean([t["pairs_prefix"] + t["pairs_suffix"] for t in tms]))
+        out = {
+            "metric": "guide x target comparisons/s (discover, <=%d mismatches, CFD+Hsu2013 aggregate)" % args.max_mismatch,
+            "value": G * T_total * args.steps / dt,
+            "unit": "comparisons/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d random NGG guides vs %d unique targets per GPU (%d positions), <=%d mismatches, maximumOffTargets %d, spCas9-NGG"
+                                   % (args.workload, G, T, P, args.max_mismatch, args.max_offtargets),
+                       "guides": G, "targets_per_gpu": T, "targets_total": T_total, "positions_per_gpu": P,
+                       "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "ffh::k_compare", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
+                         "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3)},
+            "cpu_baseline": cpu,
+            "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
+            "discover_wall_s": dt / args.steps,
+            "db_prepare_ms": info.prepare_ms,
+            "plan": {"prefix_bases": tms[-1]["prefix_bases"], "prefix_radius": tms[-1]["prefix_radius"], "suffix_bases": info.suffix_bases,
+                     "suffix_radius": tms[-1]["suffix_radius"], "items": tms[-1]["items_prefix"] + tms[-1]["items_suffix"],
+                     "tiles": tms[-1]["tiles_prefix"] + tms[-1]["tiles_suffix"]},
+            "hits": {"raw": raw_hits, "kept_positions": kept_pos, "overflowed_guides": int(res.summaries["overflow"].sum())},
+            "algorithmic_bytes_survey": b_survey,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI in include/flashfry_hip.h (flashfry_amd/lib/libflashfry_hip.so).
+
+This is plumbing only: every call goes straight into the HIP library.  There is NO CPU fallback -- loading fails
+loudly if the library has not been built, and `Context()` fails loudly when no GPU is usable."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+i64p = C.POINTER(C.c_int64)
+
+FINALIZE_SUMMARIES_ONLY = 1
+
+# every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
+    "ffh_db_load_soa", "ffh_db_open", "ffh_db_info_get", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
+    "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
+    "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
+    "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
+]
+
+
+class GuideSummary(C.Structure):
+    _fields_ = [("n_hits", C.c_uint32), ("ot_count", C.c_uint32), ("overflow", C.c_uint32), ("hist", C.c_uint32 * 5),
+                ("closest", C.c_uint32), ("closest_count", C.c_uint32), ("in_genome", C.c_uint32), ("n_scored", C.c_uint32),
+                ("cfd_max", C.c_double), ("cfd_sum", C.c_double), ("hsu_sum", C.c_double)]
+
+
+SUMMARY_DTYPE = np.dtype([("n_hits", "<u4"), ("ot_count", "<u4"), ("overflow", "<u4"), ("hist", "<u4", (5,)),
+                          ("closest", "<u4"), ("closest_count", "<u4"), ("in_genome", "<u4"), ("n_scored", "<u4"),
+                          ("cfd_max", "<f8"), ("cfd_sum", "<f8"), ("hsu_sum", "<f8")])
+assert SUMMARY_DTYPE.itemsize == C.sizeof(GuideSummary) == 72
+
+
+class DbInfo(C.Structure):
+    _fields_ = [("n_targets", C.c_uint64), ("n_positions", C.c_uint64), ("n_bins", C.c_uint32), ("bin_begin", C.c_uint32),
+                ("bin_end", C.c_uint32), ("enzyme_index", C.c_int), ("prefix_bases", C.c_int), ("suffix_bases", C.c_int),
+                ("prepare_ms", C.c_double)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("prepare_ms", C.c_double), ("compare_ms", C.c_double),
+                ("sort_ms", C.c_double), ("finalize_ms", C.c_double), ("total_scan_ms", C.c_double),
+                ("n_raw_hits", C.c_uint64), ("pairs_prefix", C.c_uint64), ("pairs_suffix", C.c_uint64),
+                ("items_prefix", C.c_uint64), ("items_suffix", C.c_uint64), ("tiles_prefix", C.c_uint64),
+                ("tiles_suffix", C.c_uint64), ("compare_launches", C.c_uint32), ("prefix_bases", C.c_int),
+                ("prefix_radius", C.c_int), ("suffix_radius", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class FlashFryHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("flashfry_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library(build=True):
+    """dlopen the HIP library (building it first if the sources are newer).  Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build_hip_library() if build else _build.LIB
+    if not os.path.exists(path):
+        raise ImportError("libflashfry_hip.so is missing (%s): build it with `python -m flashfry_amd._build`; "
+                          "there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.ffh_version.restype = C.c_int
+    L.ffh_device_count.restype = C.c_int
+    L.ffh_create.restype = C.c_void_p
+    L.ffh_create.argtypes = [C.c_int, C.c_int]
+    L.ffh_destroy.argtypes = [C.c_void_p]
+    L.ffh_last_error.restype = C.c_char_p
+    L.ffh_last_error.argtypes = [C.c_void_p]
+    L.ffh_db_load_blocks.argtypes = [C.c_void_p, i64p, u64p, C.c_uint32]
+    L.ffh_db_load_soa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
+    L.ffh_db_open.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+    L.ffh_db_info_get.argtypes = [C.c_void_p, C.POINTER(DbInfo)]
+    L.ffh_db_contig.restype = C.c_char_p
+    L.ffh_db_contig.argtypes = [C.c_void_p, C.c_uint32]
+    L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ffh_scan.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int]
+    L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
+    L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.ffh_discover.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.ffh_result_n_guides.restype = C.c_uint32
+    L.ffh_result_n_guides.argtypes = [C.c_void_p]
+    L.ffh_result_n_hits.restype = C.c_uint64
+    L.ffh_result_n_hits.argtypes = [C.c_void_p]
+    L.ffh_result_n_positions.restype = C.c_uint64
+    L.ffh_result_n_positions.argtypes = [C.c_void_p]
+    L.ffh_result_scores_valid.argtypes = [C.c_void_p]
+    for name, rt in (("ffh_result_summaries", C.c_void_p), ("ffh_result_guide_offsets", u64p), ("ffh_result_hit_targets", u64p),
+                     ("ffh_result_hit_mismatches", C.POINTER(C.c_uint8)), ("ffh_result_hit_cfd", C.POINTER(C.c_double)),
+                     ("ffh_result_pos_offsets", u64p), ("ffh_result_positions", u64p)):
+        getattr(L, name).restype = rt
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.ffh_result_free.argtypes = [C.c_void_p]
+    L.ffh_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    _lib = L
+    return L
+
+
+def _copy(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class Result:
+    """Host copy of an ffh_result: guides in input order, hits in database order, already cut off."""
+
+    def __init__(self, L, h, lists=True):
+        try:
+            n = L.ffh_result_n_guides(h)
+            H = L.ffh_result_n_hits(h)
+            P = L.ffh_result_n_positions(h)
+            self.n_guides, self.n_hits, self.n_positions = n, H, P
+            self.scores_valid = bool(L.ffh_result_scores_valid(h))
+            sp = L.ffh_result_summaries(h)
+            if n:
+                buf = (C.c_char * (n * 72)).from_address(sp)
+                self.summaries = np.frombuffer(buf, dtype=SUMMARY_DTYPE, count=n).copy()
+            else:
+                self.summaries = np.zeros(0, dtype=SUMMARY_DTYPE)
+            self.guide_offsets = _copy(L.ffh_result_guide_offsets(h), n + 1, np.uint64)
+            if lists:
+                self.hit_targets = _copy(L.ffh_result_hit_targets(h), H, np.uint64)
+                self.hit_mismatches = _copy(L.ffh_result_hit_mismatches(h), H, np.uint8)
+                self.hit_cfd = _copy(L.ffh_result_hit_cfd(h), H, np.float64)
+                self.pos_offsets = _copy(L.ffh_result_pos_offsets(h), H + 1, np.uint64)
+                self.positions = _copy(L.ffh_result_positions(h), P, np.uint64)
+        finally:
+            L.ffh_result_free(h)
+
+    def hits(self, g):
+        a, b = int(self.guide_offsets[g]), int(self.guide_offsets[g + 1])
+        return self.hit_targets[a:b]
+
+    # the values the reference prints (Doench2016CFDScore.scala:76-87, CrisprMitEduOffTarget.scala:103-105)
+    def cfd_specificity(self):
+        return 1.0 / (1.0 + self.summaries["cfd_sum"])
+
+    def hsu2013(self):
+        return (100.0 / (100.0 + self.summaries["hsu_sum"])) * 100.0
+
+
+class Context:
+    """One GPU, one HIP stream, one resident database shard."""
+
+    def __init__(self, enzyme_index=3, device=0):
+        self.L = load_library()
+        self.h = self.L.ffh_create(device, enzyme_index)
+        if not self.h:
+            raise FlashFryHipError(-7, self.L.ffh_last_error(None).decode())
+        self.enzyme_index = enzyme_index
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ffh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FlashFryHipError(rc, self.L.ffh_last_error(self.h).decode())
+
+    # ---- database ------------------------------------------------------------------------------------
+    def load_blocks(self, longs, bin_offsets):
+        longs = np.ascontiguousarray(longs, dtype=np.int64)
+        offs = np.ascontiguousarray(bin_offsets, dtype=np.uint64)
+        self._check(self.L.ffh_db_load_blocks(self.h, longs.ctypes.data_as(i64p), offs.ctypes.data_as(u64p), len(offs) - 1))
+
+    def load_soa(self, targets, positions):
+        t = np.ascontiguousarray(targets).view(np.uint64)
+        p = np.ascontiguousarray(positions).view(np.uint64)
+        self._check(self.L.ffh_db_load_soa(self.h, t.ctypes.data, len(t), p.ctypes.data, len(p), 0))
+
+    def load_soa_device(self, targets_ptr, n_targets, positions_ptr, n_positions):
+        """device pointers (e.g. torch tensors' data_ptr()) on this context's GPU; the data is copied"""
+        self._check(self.L.ffh_db_load_soa(self.h, targets_ptr, n_targets, positions_ptr, n_positions, 1))
+
+    def open(self, path, bin_begin=0, bin_end=0):
+        self._check(self.L.ffh_db_open(self.h, path.encode(), bin_begin, bin_end))
+
+    def info(self):
+        i = DbInfo()
+        self._check(self.L.ffh_db_info_get(self.h, C.byref(i)))
+        return i
+
+    def contigs(self):
+        out, i = [], 1
+        while True:
+            c = self.L.ffh_db_contig(self.h, i)
+            if c is None:
+                return out
+            out.append(c.decode())
+            i += 1
+
+    def set_plan(self, prefix_bases=-1, prefix_radius=-1):
+        self._check(self.L.ffh_set_plan(self.h, prefix_bases, prefix_radius))
+
+    # ---- discover ------------------------------------------------------------------------------------
+    def scan(self, guides, max_mismatch=4):
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        self._n_guides = len(g)
+        self._check(self.L.ffh_scan(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch))
+
+    def shard_totals(self, clamp):
+        t = np.zeros(max(self._n_guides, 1), dtype=np.uint32)
+        self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))
+        return t[:self._n_guides]
+
+    def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False):
+        out = C.c_void_p()
+        pt = None
+        if prior_totals is not None:
+            pt = np.ascontiguousarray(prior_totals, dtype=np.uint32)
+            assert len(pt) == self._n_guides
+        self._check(self.L.ffh_finalize(self.h, pt.ctypes.data_as(u32p) if pt is not None else None, max_offtargets,
+                                        FINALIZE_SUMMARIES_ONLY if summaries_only else 0, C.byref(out)))
+        return Result(self.L, out.value, lists=not summaries_only)
+
+    def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False):
+        self.scan(guides, max_mismatch)
+        return self.finalize(max_offtargets, None, summaries_only)
+
+    def timings(self):
+        t = Timings()
+        self._check(self.L.ffh_get_timings(self.h, C.byref(t)))
+        return t

@@ -1,0 +1,667 @@
+// ffh_api.hip -- context, memory and launch orchestration behind the C ABI of include/flashfry_hip.h.
+// gfx950 only.  One context = one GPU + one HIP stream; everything below is issued on that stream.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/flashfry_hip.h"
+#include "ffh_dbfile.hpp"
+#include "ffh_kernels.hpp"
+#include "cfd_table.inc"
+
+using namespace ffh;
+
+static std::string g_create_error;
+
+#define FFH_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+            return FFH_E_HIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {  // contents are NOT preserved
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Image {  // one bucketed scan image of the database
+    int width = -1;
+    DevBuf<uint32_t> bstart;  // 4^width + 1
+    DevBuf<uint64_t> keys;    // planar keys grouped by bucket
+    DevBuf<uint32_t> tidx;    // database index of each key
+};
+
+struct Plan { int a, r1, s, r2; };  // prefix width/radius, suffix width/radius (r2 < 0: no suffix pass)
+
+struct Evt {
+    hipEvent_t e = nullptr;
+};
+
+}  // namespace
+
+struct ffh_result {
+    uint32_t n_guides = 0;
+    uint64_t n_hits = 0, n_positions = 0;
+    int scores_valid = 0;
+    std::vector<ffh_guide_summary> summaries;
+    std::vector<uint64_t> guide_offsets, hit_targets, pos_offsets, positions;
+    std::vector<uint8_t> hit_mm;
+    std::vector<double> hit_cfd;
+};
+
+struct ffh_ctx {
+    int device = 0, enzyme = 0;
+    hipStream_t st = nullptr;
+    Geometry geo{};
+    std::string err;
+
+    // database
+    uint64_t T = 0, P = 0;
+    DevBuf<uint64_t> targets, positions, pos_off;
+    Image img[2];  // 0 prefix, 1 suffix
+    std::vector<std::string> contigs;
+    uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
+    double db_prepare_ms = 0;
+    int plan_a = -1, plan_r1 = -1;
+
+    // scan state
+    DevBuf<uint64_t> guides;
+    uint32_t n_guides = 0;
+    int max_mm = 0;
+    bool scanned = false;
+    DevBuf<uint64_t> hits, hits_alt;
+    uint64_t *hits_sorted = nullptr;
+    uint64_t n_raw = 0;
+    DevBuf<uint32_t> seg_begin, seg_end;
+    unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] scratch
+
+    // per-pass scratch
+    DevBuf<uint64_t> gkey[2];
+    DevBuf<uint32_t> gbucket[2], patterns[2], istart[2], tstart[2];
+    DevBuf<uint32_t> icount, ifill, tcount, item_gid, scan_tmp32;
+    DevBuf<uint64_t> item_key, scan_tmp64;
+    DevBuf<uint4> tiles;
+    DevBuf<uint32_t> sort_table, sort_offs;
+    std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
+
+    // finalize scratch
+    DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals;
+    DevBuf<uint64_t> ret_off, out_target, out_posoff, out_pos;
+    DevBuf<uint8_t> out_mm;
+    DevBuf<double> out_cfd, out_hsu;
+    DevBuf<GuideSummary> summ;
+    ScoreTables *d_tab = nullptr;
+
+    hipEvent_t ev[8] = {};
+    ffh_timings tm{};
+};
+
+static unsigned blocks_for(uint64_t n, unsigned threads) { return (unsigned)std::max<uint64_t>(1, (n + threads - 1) / threads); }
+
+// ---- ball sizes and patterns -----------------------------------------------------------------------------
+static double ball_size(int n, int r) {  // sum_k C(n,k) 3^k
+    if (r < 0) return 0;
+    double tot = 0, c = 1, p3 = 1;
+    for (int k = 0; k <= std::min(n, r); ++k) {
+        tot += c * p3;
+        c = c * (n - k) / (k + 1);
+        p3 *= 3;
+    }
+    return tot;
+}
+
+static void enum_patterns(int n, int r, int start, uint32_t cur, std::vector<uint32_t> &out) {
+    out.push_back(cur);
+    if (r == 0) return;
+    for (int p = start; p < n; ++p)
+        for (uint32_t d = 1; d <= 3; ++d)  // (dh, dl) in {01, 10, 11}: the three other bases
+            enum_patterns(n, r - 1, p + 1, cur ^ (((d >> 1) << (n + p)) | ((d & 1u) << p)), out);
+}
+
+static const std::vector<uint32_t> &patterns_for(ffh_ctx *ctx, int n, int r) {
+    r = std::min(r, n);
+    auto key = std::make_pair(n, r);
+    auto it = ctx->pattern_cache.find(key);
+    if (it != ctx->pattern_cache.end()) return it->second;
+    std::vector<uint32_t> v;
+    v.reserve((size_t)ball_size(n, r));
+    enum_patterns(n, r, 0, 0, v);
+    return ctx->pattern_cache.emplace(key, std::move(v)).first->second;
+}
+
+static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
+    const int lc = ctx->geo.lc, a = ctx->img[0].width, s = ctx->img[1].width;
+    const double T = (double)std::max<uint64_t>(ctx->T, 1);
+    const double per_p = std::max(T / std::pow(4.0, a), 1.0), per_s = std::max(T / std::pow(4.0, s), 1.0);
+    Plan best{a, std::min(max_mm, a), s, -1};
+    double best_cost = ball_size(a, best.r1) * (per_p + 8.0);
+    if (ctx->plan_r1 >= 0) {  // forced
+        Plan p{a, std::min(ctx->plan_r1, a), s, max_mm - 1 - ctx->plan_r1};
+        if (p.r1 >= max_mm || p.r1 >= a) { p.r1 = std::min(max_mm, a); p.r2 = -1; }
+        if (p.r2 > s) p.r2 = s;
+        return p;
+    }
+    if (max_mm >= 1 && a + s == lc)
+        for (int r1 = 0; r1 <= std::min(max_mm - 1, a); ++r1) {
+            const int r2 = max_mm - 1 - r1;
+            if (r2 > s) continue;
+            const double cost = ball_size(a, r1) * (per_p + 8.0) + ball_size(s, r2) * (per_s + 8.0);
+            if (cost < best_cost) { best_cost = cost; best = Plan{a, r1, s, r2}; }
+        }
+    return best;
+}
+
+// ---- database residency ----------------------------------------------------------------------------------
+static int build_image(ffh_ctx *ctx, int which, int width) {
+    Image &im = ctx->img[which];
+    const uint32_t nb = 1u << (2 * width);
+    im.width = width;
+    FFH_HIP(im.bstart.reserve((size_t)nb + 1));
+    FFH_HIP(im.keys.reserve(ctx->T));
+    FFH_HIP(im.tidx.reserve(ctx->T));
+    FFH_HIP(ctx->icount.reserve((size_t)nb + 1));
+    FFH_HIP(ctx->ifill.reserve((size_t)nb + 1));
+    FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
+    FFH_HIP(hipMemsetAsync(ctx->icount.p, 0, ((size_t)nb + 1) * 4, ctx->st));
+    FFH_HIP(hipMemsetAsync(ctx->ifill.p, 0, ((size_t)nb + 1) * 4, ctx->st));
+    const unsigned bl = blocks_for(ctx->T, 256);
+    if (ctx->T) {
+        if (which == 0) hipLaunchKernelGGL(k_image_hist<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, ctx->icount.p);
+        else hipLaunchKernelGGL(k_image_hist<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, ctx->icount.p);
+    }
+    exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.bstart.p, ctx->scan_tmp32.p, ctx->st);
+    if (ctx->T) {
+        if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, im.keys.p, im.tidx.p);
+        else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, im.keys.p, im.tidx.p);
+    }
+    FFH_HIP(hipGetLastError());
+    return FFH_OK;
+}
+
+// targets/positions are already on the device in ctx->targets / ctx->positions
+static int prepare_database(ffh_ctx *ctx) {
+    if (ctx->T >= (1ull << 32) - 64) { ctx->err = "more than 2^32 targets in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
+    FFH_HIP(hipEventRecord(ctx->ev[0], ctx->st));
+    // counts -> position offsets; validate counts like BlockManager.scala:232-236
+    FFH_HIP(ctx->out_cnt.reserve(ctx->T + 1));
+    FFH_HIP(ctx->pos_off.reserve(ctx->T + 1));
+    FFH_HIP(ctx->scan_tmp64.reserve(scan_scratch_elems_safe(ctx->T)));
+    uint32_t *bad = (uint32_t *)ctx->d_counters + 8;
+    FFH_HIP(hipMemsetAsync(bad, 0, 4, ctx->st));
+    if (ctx->T) hipLaunchKernelGGL(k_check_counts, dim3(blocks_for(ctx->T, 256)), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->out_cnt.p, bad);
+    exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, ctx->T, ctx->pos_off.p, ctx->scan_tmp64.p, ctx->st);
+    uint32_t hbad = 0;
+    uint64_t total = 0;
+    FFH_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->st));
+    FFH_HIP(hipMemcpyAsync(&total, ctx->pos_off.p + ctx->T, 8, hipMemcpyDeviceToHost, ctx->st));
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    if (hbad) { ctx->err = "Encoded position count should be greater than zero (and fit a signed short)"; return FFH_E_FORMAT; }
+    if (total != ctx->P) { ctx->err = "positions array length does not equal the sum of the target counts"; return FFH_E_FORMAT; }
+    // bucket widths: ~48 targets per prefix bucket, both keys <= 12 bases
+    const int lc = ctx->geo.lc;
+    int a = (int)std::floor(std::log((double)std::max<uint64_t>(ctx->T, 1) / 48.0) / std::log(4.0));
+    if (ctx->plan_a >= 0) a = ctx->plan_a;
+    a = std::max(lc - 12, std::min(12, a));
+    int rc = build_image(ctx, 0, a);
+    if (rc) return rc;
+    rc = build_image(ctx, 1, lc - a);
+    if (rc) return rc;
+    FFH_HIP(hipEventRecord(ctx->ev[1], ctx->st));
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    float ms = 0;
+    FFH_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->db_prepare_ms = ms;
+    ctx->scanned = false;
+    return FFH_OK;
+}
+
+// ---- candidate lists + tiles of one image (no host synchronisation: counts stay on the device) ---------------
+struct SideBufs {  // per-image scratch that must survive until the compare launch
+    DevBuf<uint32_t> istart, tstart;
+};
+
+static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, const uint32_t *item_base, const uint32_t *tile_base) {
+    Image &im = ctx->img[which];
+    const int width = im.width;
+    const uint32_t nb = 1u << (2 * width);
+    const std::vector<uint32_t> &pat = patterns_for(ctx, width, radius);
+    const uint32_t np = (uint32_t)pat.size();
+    hipStream_t st = ctx->st;
+    DevBuf<uint32_t> &patterns = ctx->patterns[which], &istart = ctx->istart[which], &tstart = ctx->tstart[which];
+    DevBuf<uint64_t> &gkey = ctx->gkey[which];
+    DevBuf<uint32_t> &gbucket = ctx->gbucket[which];
+    FFH_HIP(patterns.reserve(np));
+    FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+    FFH_HIP(gkey.reserve(ng));
+    FFH_HIP(gbucket.reserve(ng));
+    FFH_HIP(ctx->icount.reserve((size_t)nb + 1));
+    FFH_HIP(istart.reserve((size_t)nb + 1));
+    FFH_HIP(ctx->ifill.reserve((size_t)nb + 1));
+    FFH_HIP(ctx->tcount.reserve((size_t)nb + 1));
+    FFH_HIP(tstart.reserve((size_t)nb + 1));
+    FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
+    FFH_HIP(hipMemsetAsync(ctx->icount.p, 0, ((size_t)nb + 1) * 4, st));
+    FFH_HIP(hipMemsetAsync(ctx->ifill.p, 0, ((size_t)nb + 1) * 4, st));
+    const uint64_t *gptr = ctx->guides.p + g0;
+    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, gkey.p, gbucket.p);
+    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, gkey.p, gbucket.p);
+    const uint64_t n_enum = (uint64_t)ng * np;
+    hipLaunchKernelGGL(k_item_count, dim3(blocks_for(n_enum, 256)), dim3(256), 0, st, gbucket.p, ng, patterns.p, np, im.bstart.p, ctx->icount.p);
+    exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, istart.p, ctx->scan_tmp32.p, st);
+    hipLaunchKernelGGL(k_item_fill, dim3(blocks_for(n_enum, 256)), dim3(256), 0, st, gbucket.p, gkey.p, ng, patterns.p, np, im.bstart.p, istart.p, ctx->ifill.p,
+                       item_base, ctx->item_key.p, ctx->item_gid.p);
+    hipLaunchKernelGGL(k_tile_count, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, nb, ctx->tcount.p, ctx->d_counters + 1 + which);
+    exclusive_scan<uint32_t, uint32_t>(ctx->tcount.p, nb, tstart.p, ctx->scan_tmp32.p, st);
+    hipLaunchKernelGGL(k_tile_fill, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, tstart.p, nb, item_base, tile_base, (uint32_t)which, ctx->tiles.p);
+    FFH_HIP(hipGetLastError());
+    return FFH_OK;
+}
+
+// =============================================================================================================
+// C ABI
+// =============================================================================================================
+extern "C" {
+
+int ffh_version(void) { return FFH_VERSION; }
+
+int ffh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ffh_last_error(const ffh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+ffh_ctx *ffh_create(int device_id, int enzyme_index) {
+    static const struct { int c0, lc, scan, cas9_23; } G[7] = {
+        {0, 0, 0, 0},
+        {0, 20, 24, 0},  // 1 Cpf1: comparisonBitEncoding 0x00FFFFFFFFFF, StandardScanParameters.scala:205
+        {3, 20, 23, 1},  // 2 spCas9 0x3FFFFFFFFFC0 :99
+        {3, 20, 23, 1},  // 3 NGG :143
+        {3, 20, 23, 1},  // 4 NAG :187
+        {3, 19, 22, 0},  // 5 19-mer 0x0FFFFFFFFFC0 :121
+        {3, 19, 22, 0},  // 6 NGG 19-mer :165
+    };
+    if (enzyme_index < 1 || enzyme_index > 6) { g_create_error = "Unable to find the correct parameter pack for enzyme: " + std::to_string(enzyme_index); return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device available (flashfry_hip has no CPU fallback)"; return nullptr; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return nullptr; }
+    ffh_ctx *ctx = new (std::nothrow) ffh_ctx();
+    if (!ctx) { g_create_error = "out of memory"; return nullptr; }
+    ctx->device = device_id;
+    ctx->enzyme = enzyme_index;
+    ctx->geo = Geometry{G[enzyme_index].c0, G[enzyme_index].lc, G[enzyme_index].scan, G[enzyme_index].cas9_23};
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
+    if (e == hipSuccess) {
+        ScoreTables h;
+        std::memcpy(h.cfd_mm, FFH_CFD_MM, sizeof h.cfd_mm);
+        std::memcpy(h.cfd_pam, FFH_CFD_PAM, sizeof h.cfd_pam);
+        static const double coeff[20] = {0.0, 0.0, 0.014, 0.0, 0.0, 0.395, 0.317, 0.0, 0.389, 0.079,   // CrisprMitEduOffTarget.scala:43-47
+                                         0.445, 0.508, 0.613, 0.851, 0.732, 0.828, 0.615, 0.804, 0.685, 0.583};
+        std::memcpy(h.hsu_coeff, coeff, sizeof coeff);
+        e = hipMemcpy(ctx->d_tab, &h, sizeof h, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
+        ffh_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void ffh_destroy(ffh_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+    ctx->targets.release(); ctx->positions.release(); ctx->pos_off.release();
+    for (auto &im : ctx->img) { im.bstart.release(); im.keys.release(); im.tidx.release(); }
+    ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->seg_begin.release(); ctx->seg_end.release();
+    for (int w = 0; w < 2; ++w) { ctx->gkey[w].release(); ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->istart[w].release(); ctx->tstart[w].release(); }
+    ctx->icount.release(); ctx->ifill.release();
+    ctx->tcount.release(); ctx->item_gid.release(); ctx->scan_tmp32.release(); ctx->item_key.release(); ctx->scan_tmp64.release();
+    ctx->tiles.release(); ctx->sort_table.release(); ctx->sort_offs.release();
+    ctx->n_ret.release(); ctx->ot_count.release(); ctx->full.release(); ctx->prior.release(); ctx->out_cnt.release(); ctx->out_tidx.release(); ctx->totals.release();
+    ctx->ret_off.release(); ctx->out_target.release(); ctx->out_posoff.release(); ctx->out_pos.release(); ctx->out_mm.release();
+    ctx->out_cfd.release(); ctx->out_hsu.release(); ctx->summ.release();
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->st) (void)hipStreamDestroy(ctx->st);
+    delete ctx;
+}
+
+int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius) {
+    if (!ctx) return FFH_E_ARG;
+    if (prefix_bases > 12) { ctx->err = "prefix_bases must be <= 12"; return FFH_E_ARG; }
+    const bool rebuild = ctx->T && prefix_bases >= 0 && prefix_bases != ctx->img[0].width;
+    ctx->plan_a = prefix_bases;
+    ctx->plan_r1 = prefix_radius;
+    if (rebuild) {
+        (void)hipSetDevice(ctx->device);
+        return prepare_database(ctx);
+    }
+    return FFH_OK;
+}
+
+int ffh_db_load_soa(ffh_ctx *ctx, const uint64_t *targets, uint64_t n_targets, const uint64_t *positions, uint64_t n_positions, int on_device) {
+    if (!ctx || (n_targets && !targets) || (n_positions && !positions)) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    if (on_device) FFH_HIP(hipDeviceSynchronize());  // the producer (e.g. torch) used another stream
+    ctx->T = n_targets;
+    ctx->P = n_positions;
+    FFH_HIP(ctx->targets.reserve(n_targets + 1));
+    FFH_HIP(ctx->positions.reserve(n_positions + 1));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (n_targets) FFH_HIP(hipMemcpyAsync(ctx->targets.p, targets, n_targets * 8, kind, ctx->st));
+    if (n_positions) FFH_HIP(hipMemcpyAsync(ctx->positions.p, positions, n_positions * 8, kind, ctx->st));
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return prepare_database(ctx);
+}
+
+int ffh_db_load_blocks(ffh_ctx *ctx, const int64_t *longs, const uint64_t *bin_offsets, uint32_t n_bins) {
+    if (!ctx || !longs || !bin_offsets) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    std::vector<uint64_t> t, p;
+    const std::string e = decode_blocks(longs, bin_offsets, n_bins, t, p);
+    if (!e.empty()) { ctx->err = e; return FFH_E_FORMAT; }
+    ctx->n_bins = n_bins; ctx->bin_begin = 0; ctx->bin_end = n_bins;
+    return ffh_db_load_soa(ctx, t.data(), t.size(), p.data(), p.size(), 0);
+}
+
+int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t bin_end) {
+    if (!ctx || !db_path) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    DbHeader h;
+    std::string e = read_db_header(std::string(db_path) + ".header", h);
+    if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
+    if (h.enzyme_index != ctx->enzyme) {
+        // the context was created for another enzyme than the one recorded in the header (BinaryHeader.scala:127)
+        ctx->err = "database enzyme index " + std::to_string(h.enzyme_index) + " differs from the context's " + std::to_string(ctx->enzyme);
+        return FFH_E_ARG;
+    }
+    if (bin_end == 0 || bin_end > h.n_bins) bin_end = h.n_bins;
+    std::vector<int64_t> longs;
+    std::vector<uint64_t> offs;
+    e = read_db_bins(db_path, h, bin_begin, bin_end, longs, offs);
+    if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
+    ctx->contigs = h.contigs;
+    int rc = ffh_db_load_blocks(ctx, longs.data(), offs.data(), bin_end - bin_begin);
+    ctx->n_bins = h.n_bins; ctx->bin_begin = bin_begin; ctx->bin_end = bin_end;
+    return rc;
+}
+
+int ffh_db_info_get(const ffh_ctx *ctx, ffh_db_info *out) {
+    if (!ctx || !out) return FFH_E_ARG;
+    out->n_targets = ctx->T; out->n_positions = ctx->P; out->n_bins = ctx->n_bins; out->bin_begin = ctx->bin_begin; out->bin_end = ctx->bin_end;
+    out->enzyme_index = ctx->enzyme; out->prefix_bases = ctx->img[0].width; out->suffix_bases = ctx->img[1].width; out->prepare_ms = ctx->db_prepare_ms;
+    return FFH_OK;
+}
+
+const char *ffh_db_contig(const ffh_ctx *ctx, uint32_t id) {
+    if (!ctx || id < 1 || id > ctx->contigs.size()) return nullptr;
+    return ctx->contigs[id - 1].c_str();
+}
+
+int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm) {
+    if (!ctx || (n_guides && !guides) || max_mm < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    if (ctx->img[0].width < 0) { ctx->err = "no database loaded"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    ctx->scanned = false;
+    ctx->n_guides = n_guides;
+    ctx->max_mm = max_mm;
+    ctx->tm = ffh_timings{};
+    FFH_HIP(ctx->guides.reserve((size_t)n_guides + 1));
+    if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
+    FFH_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
+
+    const Plan plan = choose_plan(ctx, std::min(max_mm, ctx->geo.lc));
+    ctx->tm.prefix_bases = plan.a; ctx->tm.prefix_radius = plan.r1; ctx->tm.suffix_radius = plan.r2;
+    const double per_guide = ball_size(plan.a, plan.r1) + ball_size(plan.s, plan.r2);
+    const uint64_t item_budget = 1ull << 28;
+    const uint32_t batch = (uint32_t)std::max<double>(1.0, std::min<double>((double)std::max<uint32_t>(n_guides, 1), std::floor((double)item_budget / per_guide)));
+    // upper bounds, so that nothing has to be read back before the compare launch
+    const uint64_t nbp = 1ull << (2 * plan.a), nbs = 1ull << (2 * plan.s);
+    const uint64_t tile_cap = std::min<uint64_t>(nbp, ctx->T) + std::min<uint64_t>(nbs, ctx->T) + 2 * (ctx->T / kTileTargets) + 4;
+    const uint32_t *zero = (const uint32_t *)(ctx->d_counters + 3);
+    FFH_HIP(hipEventRecord(ctx->ev[0], st));
+    float ms_cmp = 0, ms_prep = 0;
+    unsigned long long cursor_before = 0;
+    for (uint32_t g0 = 0; g0 < n_guides;) {
+        const uint32_t ng = std::min(batch, n_guides - g0);
+        unsigned long long snap[3] = {0, 0, 0};
+        FFH_HIP(hipMemcpyAsync(snap, ctx->d_counters, sizeof snap, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        const uint64_t item_cap = (uint64_t)std::ceil(per_guide) * ng + 4;
+        if (item_cap >= (1ull << 32)) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
+        FFH_HIP(ctx->item_key.reserve(item_cap));
+        FFH_HIP(ctx->item_gid.reserve(item_cap));
+        FFH_HIP(ctx->tiles.reserve(tile_cap));
+        FFH_HIP(hipEventRecord(ctx->ev[2], st));
+        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, zero, zero);
+        if (rc) return rc;
+        const uint32_t *n_items0 = ctx->istart[0].p + nbp, *n_tiles0 = ctx->tstart[0].p + nbp, *n_tiles1 = zero;
+        if (plan.r2 >= 0) {
+            rc = prepare_side(ctx, 1, plan.r2, g0, ng, n_items0, n_tiles0);
+            if (rc) return rc;
+            n_tiles1 = ctx->tstart[1].p + nbs;
+        }
+        FFH_HIP(hipEventRecord(ctx->ev[3], st));
+        const uint32_t prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
+        hipLaunchKernelGGL(k_compare, dim3(256 * 8), dim3(kCmpThreads), 0, st, ctx->tiles.p, n_tiles0, n_tiles1, ctx->img[0].keys.p, ctx->img[0].tidx.p,
+                           ctx->img[1].keys.p, ctx->img[1].tidx.p, ctx->item_key.p, ctx->item_gid.p, max_mm, prefix_mask, plan.r1, ctx->hits.p, ctx->d_counters,
+                           (uint64_t)ctx->hits.cap);
+        FFH_HIP(hipGetLastError());
+        FFH_HIP(hipEventRecord(ctx->ev[4], st));
+        unsigned long long cursor = 0;
+        uint32_t stats[4] = {0, 0, 0, 0};
+        FFH_HIP(hipMemcpyAsync(&cursor, ctx->d_counters, 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(&stats[0], n_items0, 4, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(&stats[1], n_tiles0, 4, hipMemcpyDeviceToHost, st));
+        if (plan.r2 >= 0) {
+            FFH_HIP(hipMemcpyAsync(&stats[2], ctx->istart[1].p + nbs, 4, hipMemcpyDeviceToHost, st));
+            FFH_HIP(hipMemcpyAsync(&stats[3], n_tiles1, 4, hipMemcpyDeviceToHost, st));
+        }
+        FFH_HIP(hipStreamSynchronize(st));
+        if (cursor > ctx->hits.cap) {  // staging overflowed: grow and redo this batch (earlier batches are kept)
+            std::vector<uint64_t> keep((size_t)cursor_before);
+            if (cursor_before) FFH_HIP(hipMemcpy(keep.data(), ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToHost));
+            FFH_HIP(ctx->hits.reserve((size_t)(cursor + cursor / 2)));
+            if (cursor_before) FFH_HIP(hipMemcpy(ctx->hits.p, keep.data(), (size_t)cursor_before * 8, hipMemcpyHostToDevice));
+            FFH_HIP(hipMemcpy(ctx->d_counters, snap, sizeof snap, hipMemcpyHostToDevice));
+            continue;
+        }
+        float a = 0, b = 0;
+        FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
+        FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
+        ms_prep += a; ms_cmp += b;
+        ctx->tm.items_prefix += stats[0]; ctx->tm.tiles_prefix += stats[1]; ctx->tm.items_suffix += stats[2]; ctx->tm.tiles_suffix += stats[3];
+        ctx->tm.compare_launches++;
+        // candidate lists carry batch-local guide ids: make this batch's hits global
+        if (g0 && cursor > cursor_before)
+            hipLaunchKernelGGL(k_add_u64, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,
+                               (uint64_t)(cursor - cursor_before), (uint64_t)g0 << 32);
+        cursor_before = cursor;
+        g0 += ng;
+    }
+    ctx->n_raw = cursor_before;
+    FFH_HIP(hipEventRecord(ctx->ev[5], st));
+    // ---- order the hits by (guide, database index) ----
+    ctx->hits_sorted = ctx->hits.p;
+    if (ctx->n_raw) {
+        const uint32_t nbk = sort_nblocks(ctx->n_raw);
+        FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
+        FFH_HIP(ctx->sort_table.reserve((size_t)256 * nbk + 1));
+        FFH_HIP(ctx->sort_offs.reserve((size_t)256 * nbk + 1));
+        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
+        SortScratch ss;
+        ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
+        int tbits = 1, gbits = 1;
+        while (tbits < 32 && (1ull << tbits) < std::max<uint64_t>(ctx->T, 2)) ++tbits;
+        while (gbits < 32 && (1ull << gbits) < std::max<uint64_t>(n_guides, 2)) ++gbits;
+        ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, tbits, 32, 32 + gbits, ss, st);
+    }
+    FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));
+    FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
+    FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, ((size_t)n_guides + 1) * 4, st));
+    FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, ((size_t)n_guides + 1) * 4, st));
+    if (ctx->n_raw) hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->seg_begin.p, ctx->seg_end.p);
+    FFH_HIP(hipEventRecord(ctx->ev[6], st));
+    unsigned long long counters[3] = {0, 0, 0};
+    FFH_HIP(hipMemcpyAsync(counters, ctx->d_counters, sizeof counters, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));
+    FFH_HIP(hipGetLastError());
+    float ms_sort = 0, ms_total = 0;
+    FFH_HIP(hipEventElapsedTime(&ms_sort, ctx->ev[5], ctx->ev[6]));
+    FFH_HIP(hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[6]));
+    ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp;
+    ctx->tm.sort_ms = ms_sort; ctx->tm.total_scan_ms = ms_total; ctx->tm.n_raw_hits = ctx->n_raw;
+    ctx->tm.pairs_prefix = counters[1]; ctx->tm.pairs_suffix = counters[2];
+    ctx->scanned = true;
+    return FFH_OK;
+}
+
+int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
+    if (!ctx || !totals) return FFH_E_ARG;
+    if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(ctx->totals.reserve((size_t)ctx->n_guides + 1));
+    if (ctx->n_guides) {
+        hipLaunchKernelGGL(k_shard_totals, dim3(blocks_for(ctx->n_guides, 128)), dim3(128), 0, ctx->st, ctx->hits_sorted, ctx->seg_begin.p, ctx->seg_end.p,
+                           ctx->targets.p, ctx->n_guides, clamp, ctx->totals.p);
+        FFH_HIP(hipMemcpyAsync(totals, ctx->totals.p, (size_t)ctx->n_guides * 4, hipMemcpyDeviceToHost, ctx->st));
+    }
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
+
+int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets, unsigned flags, ffh_result **out) {
+    if (!ctx || !out || max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    const uint32_t G = ctx->n_guides;
+    FFH_HIP(hipEventRecord(ctx->ev[0], st));
+    FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
+    FFH_HIP(ctx->ot_count.reserve((size_t)G + 1));
+    FFH_HIP(ctx->full.reserve((size_t)G + 1));
+    FFH_HIP(ctx->ret_off.reserve((size_t)G + 2));
+    FFH_HIP(ctx->summ.reserve((size_t)G + 1));
+    FFH_HIP(ctx->scan_tmp64.reserve(scan_scratch_elems_safe(std::max<uint64_t>(G, ctx->n_raw) + 1)));
+    const uint32_t *d_prior = nullptr;
+    if (prior_totals) {
+        FFH_HIP(ctx->prior.reserve((size_t)G + 1));
+        if (G) FFH_HIP(hipMemcpyAsync(ctx->prior.p, prior_totals, (size_t)G * 4, hipMemcpyHostToDevice, st));
+        d_prior = ctx->prior.p;
+    }
+    if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->hits_sorted, ctx->seg_begin.p, ctx->seg_end.p, ctx->targets.p, d_prior, G,
+                              (uint32_t)max_offtargets, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p);
+    exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
+    uint64_t Hr = 0;
+    FFH_HIP(hipMemcpyAsync(&Hr, ctx->ret_off.p + G, 8, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));
+    FFH_HIP(ctx->out_target.reserve(Hr + 1));
+    FFH_HIP(ctx->out_mm.reserve(Hr + 1));
+    FFH_HIP(ctx->out_cnt.reserve(std::max<uint64_t>(Hr, ctx->T) + 1));
+    FFH_HIP(ctx->out_tidx.reserve(Hr + 1));
+    FFH_HIP(ctx->out_cfd.reserve(Hr + 1));
+    FFH_HIP(ctx->out_hsu.reserve(Hr + 1));
+    FFH_HIP(ctx->out_posoff.reserve(Hr + 2));
+    if (ctx->n_raw)
+        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
+                           ctx->targets.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
+                           ctx->out_hsu.p);
+    exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, Hr, ctx->out_posoff.p, ctx->scan_tmp64.p, st);
+    uint64_t Pr = 0;
+    FFH_HIP(hipMemcpyAsync(&Pr, ctx->out_posoff.p + Hr, 8, hipMemcpyDeviceToHost, st));
+    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
+                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
+    FFH_HIP(hipStreamSynchronize(st));
+    const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY);
+    if (want_lists) {
+        FFH_HIP(ctx->out_pos.reserve(Pr + 1));
+        if (Hr) hipLaunchKernelGGL(k_gather_positions, dim3(blocks_for(Hr, 256)), dim3(256), 0, st, ctx->out_tidx.p, ctx->out_cnt.p, ctx->out_posoff.p, Hr, ctx->pos_off.p,
+                                   ctx->positions.p, ctx->out_pos.p);
+    }
+    FFH_HIP(hipEventRecord(ctx->ev[1], st));
+    FFH_HIP(hipGetLastError());
+    ffh_result *r = new (std::nothrow) ffh_result();
+    if (!r) { ctx->err = "out of memory"; return FFH_E_NOMEM; }
+    r->n_guides = G; r->n_hits = Hr; r->n_positions = want_lists ? Pr : 0; r->scores_valid = ctx->geo.cas9_23;
+    static_assert(sizeof(GuideSummary) == sizeof(ffh_guide_summary), "summary layouts must agree");
+    r->summaries.resize(G);
+    hipError_t e = hipSuccess;
+    if (G) e = hipMemcpyAsync(r->summaries.data(), ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+    r->guide_offsets.resize((size_t)G + 1);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets.data(), ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
+    if (want_lists) {
+        r->hit_targets.resize(Hr); r->hit_mm.resize(Hr); r->hit_cfd.resize(Hr); r->pos_offsets.resize(Hr + 1); r->positions.resize(Pr);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_targets.data(), ctx->out_target.p, Hr * 8, hipMemcpyDeviceToHost, st);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm.data(), ctx->out_mm.p, Hr, hipMemcpyDeviceToHost, st);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd.data(), ctx->out_cfd.p, Hr * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets.data(), ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions.data(), ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    ctx->tm.finalize_ms = ms;
+    *out = r;
+    return FFH_OK;
+}
+
+int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
+    int rc = ffh_scan(ctx, guides, n_guides, max_mismatch);
+    if (rc) return rc;
+    return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
+}
+
+int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out) {
+    if (!ctx || !out) return FFH_E_ARG;
+    *out = ctx->tm;
+    return FFH_OK;
+}
+
+uint32_t ffh_result_n_guides(const ffh_result *r) { return r->n_guides; }
+uint64_t ffh_result_n_hits(const ffh_result *r) { return r->n_hits; }
+uint64_t ffh_result_n_positions(const ffh_result *r) { return r->n_positions; }
+int ffh_result_scores_valid(const ffh_result *r) { return r->scores_valid; }
+const ffh_guide_summary *ffh_result_summaries(const ffh_result *r) { return r->summaries.data(); }
+const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { return r->guide_offsets.data(); }
+const uint64_t *ffh_result_hit_targets(const ffh_result *r) { return r->hit_targets.data(); }
+const uint8_t *ffh_result_hit_mismatches(const ffh_result *r) { return r->hit_mm.data(); }
+const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd.data(); }
+const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { return r->pos_offsets.data(); }
+const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions.data(); }
+void ffh_result_free(ffh_result *r) { delete r; }
+
+}  // extern "C"

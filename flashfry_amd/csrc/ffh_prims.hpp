@@ -1,0 +1,198 @@
+// ffh_prims.hpp -- device-wide primitives for gfx950 (wave64): exclusive scan and LSD radix sort of u64 keys.
+// Hand-written; no rocPRIM/hipCUB.  Everything is launched on the caller's stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffh {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exclusive scan:  out[i] = sum_{j<i} in[j],  out[n] = total   (out has n+1 entries; in-place allowed when
+// TOut == TIn and out == in is NOT used -- callers pass distinct buffers).  Three-kernel reduce/scan/scatter,
+// recursive over block sums.  Block = 256 threads x 16 items = 4096 items.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *lds /* >= 8 entries */, T &block_total) {
+    // wave inclusive scan via DPP-free shuffles, then across the 4 waves through LDS
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    T wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        T s = lds[w];
+        if ((uint32_t)w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    block_total = tot;
+    return wave_off + incl - v;
+}
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const TIn *__restrict__ in, uint64_t n, TOut *__restrict__ bsum) {
+    __shared__ TOut lds[8];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    TOut s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) s += (TOut)in[base + k];
+    TOut tot;
+    block_exclusive_scan<TOut>(s, lds, tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn *__restrict__ in, uint64_t n, const TOut *__restrict__ boff,
+                                                              TOut *__restrict__ out) {
+    __shared__ TOut lds[8];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    TOut v[kScanItems];
+    TOut s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? (TOut)in[base + k] : (TOut)0;
+        s += v[k];
+    }
+    TOut tot;
+    TOut off = block_exclusive_scan<TOut>(s, lds, tot) + boff[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+    }
+    // the grand total goes to out[n]
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanThreads - 1) out[n] = off;
+}
+
+// out must hold n+1 entries.  scratch: scan_scratch_elems_safe(n) TOut elements.
+template <typename TIn, typename TOut>
+inline void exclusive_scan(const TIn *in, uint64_t n, TOut *out, TOut *scratch, hipStream_t st) {
+    uint64_t nb = (n + kScanTile - 1) / kScanTile;
+    if (nb == 0) nb = 1;
+    TOut *bsum = scratch;           // nb entries (+1 for the recursive total)
+    TOut *next = scratch + nb + 1;  // scratch of the next level
+    hipLaunchKernelGGL((k_scan_reduce<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, bsum);
+    if (nb > 1) {
+        // scan block sums in place-ish: bsum -> boff (stored in `next` region's head), recursive
+        TOut *boff = next;
+        exclusive_scan<TOut, TOut>(bsum, nb, boff, next + nb + 1, st);
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, boff, out);
+    } else {
+        // single block: offset 0
+        (void)hipMemsetAsync(next, 0, sizeof(TOut), st);
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3(1), dim3(kScanThreads), 0, st, in, n, next, out);
+    }
+}
+
+// scratch needed when recursion allocates [bsum(nb+1)][boff(nb+1)][next level ...]
+inline uint64_t scan_scratch_elems_safe(uint64_t n) {
+    uint64_t tot = 16;
+    while (true) {
+        uint64_t nb = (n + kScanTile - 1) / kScanTile;
+        if (nb == 0) nb = 1;
+        tot += 2 * (nb + 1);
+        if (nb <= 1) break;
+        n = nb;
+    }
+    return tot;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSD radix sort of u64 keys, 8 bits per pass, only over the caller-given bit ranges.
+// One wave per block; a block owns a contiguous chunk of kSortChunk keys and ranks them row by row (64 keys per
+// row) so the scatter is stable.  Per pass: histogram -> scan of the digit-major (256 x nblocks) table -> scatter.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSortRows = 32;
+constexpr int kSortChunk = kSortRows * kWave;  // 2048 keys per block
+
+__global__ __launch_bounds__(64) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
+                                                   uint32_t *__restrict__ table /* [256][nblocks] */, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    const uint32_t lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) h[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+    for (int r = 0; r < kSortRows; ++r) {
+        uint64_t i = base + (uint64_t)r * 64 + lane;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) table[(uint64_t)i * nblocks + blockIdx.x] = h[i];
+}
+
+__global__ __launch_bounds__(64) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
+                                                      const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks) {
+    __shared__ uint32_t cur[256];
+    const uint32_t lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) cur[i] = offs[(uint64_t)i * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * 64 + lane;
+        const bool valid = i < n;
+        const uint64_t key = valid ? keys[i] : 0;
+        const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+        // lanes holding the same digit: intersect the 8 per-bit ballots
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const uint32_t rank = mbcnt(peers);
+        uint32_t pos = 0;
+        if (valid) pos = cur[d] + rank;
+        __syncthreads();
+        if (valid && rank == (uint32_t)__popcll(peers) - 1) cur[d] = pos + 1;  // last peer advances the cursor
+        __syncthreads();
+        if (valid) out[pos] = key;
+    }
+}
+
+struct SortScratch {
+    uint64_t *alt = nullptr;     // n keys
+    uint32_t *table = nullptr;   // 256*nblocks + 1
+    uint32_t *offs = nullptr;    // 256*nblocks + 1
+    uint32_t *scan_tmp = nullptr;
+};
+
+inline uint32_t sort_nblocks(uint64_t n) { return (uint32_t)((n + kSortChunk - 1) / kSortChunk); }
+
+// sorts keys[0..n) ascending considering only bits [lo_a, hi_a) and [lo_b, hi_b) (lo_b >= hi_a); returns the
+// pointer (keys or scratch.alt) that holds the sorted result.
+inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, int lo_b, int hi_b, SortScratch &s, hipStream_t st) {
+    if (n == 0) return keys;
+    const uint32_t nb = sort_nblocks(n);
+    uint64_t *src = keys, *dst = s.alt;
+    int ranges[2][2] = {{lo_a, hi_a}, {lo_b, hi_b}};
+    for (int rg = 0; rg < 2; ++rg)
+        for (int shift = ranges[rg][0]; shift < ranges[rg][1]; shift += 8) {
+            hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(64), 0, st, src, n, shift, s.table, nb);
+            exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(64), 0, st, src, dst, n, shift, s.offs, nb);
+            uint64_t *t = src; src = dst; dst = t;
+        }
+    return src;
+}
+
+}  // namespace ffh

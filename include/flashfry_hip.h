@@ -1,0 +1,180 @@
+/*
+ * flashfry_hip.h -- C ABI of the MI355X-native FlashFry `discover` scan + off-target score aggregation.
+ *
+ * This is the drop-in boundary.  It replaces, for ONE hot path, what the reference does behind
+ *
+ *   trait Traverser { def scan(binaryFile, header, traversal, aggregator, maxMismatch, configuration,
+ *                              bitCoder, posCoder): Unit }
+ *       src/main/scala/reference/traverser/Traverser.scala:38-61
+ *       (implementations SeekTraverser.scala:58-121, LinearTraverser.scala:59-130; chosen in
+ *        modules/OffTargetDiscovery.scala:119-135; hits are delivered through
+ *        ResultsAggregator.updateOT, crispr/ResultsAggregator.scala:61-69)
+ *
+ * and, for the scoring epilogue, the hit-list models behind
+ *
+ *   trait ScoreModel / SingleGuideScoreModel.scoreGuide      scoring/ScoreModel.scala:31-133
+ *       Doench2016CFDScore.scala:53-88,132-151   CrisprMitEduOffTarget.scala:60-148
+ *       ClosestHit.scala:43-76                    DangerousSequences.scala:61-65
+ *
+ * A JVM host binds these entry points with a thin JNI stub (INTEGRATION.md shows it); this repository's own
+ * C++ CLI and the ctypes binding used by the tests call exactly the same symbols.
+ *
+ * Conventions: plain C, no C++ or torch types; every function returns 0 on success or a negative FFH_E* code
+ * (never throws); ffh_last_error() gives the message.  The caller owns every input buffer; the library owns
+ * an ffh_result until ffh_result_free().  A context is bound to one GPU and one HIP stream and is NOT
+ * thread-safe (the reference path is single-threaded and not re-entrant either, Traverser.scala:68-74); use
+ * one context per host thread / per GPU.  All integers are host (little-endian) order.  Guide and target
+ * longs use the reference's layout verbatim (bitcoding/BitEncoding.scala:46-67: 2 bits per base, first base
+ * most significant, occurrence count in bits 63:48), so GuideIndex.guide values pass through unchanged.
+ */
+#ifndef FLASHFRY_HIP_H
+#define FLASHFRY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFH_VERSION 1
+
+enum {
+    FFH_OK = 0,
+    FFH_E_ARG = -1,       /* bad argument (the reference would fail a require/assert) */
+    FFH_E_HIP = -2,       /* a HIP runtime call failed (message carries hipGetErrorString) */
+    FFH_E_FORMAT = -3,    /* malformed database block / header (BlockManager.scala:85-87, BinaryHeader.scala:121-124) */
+    FFH_E_STATE = -4,     /* call order: no database loaded, no scan to finalize, ... */
+    FFH_E_IO = -5,        /* file could not be read */
+    FFH_E_NOMEM = -6,
+    FFH_E_NODEVICE = -7   /* no usable GPU: there is deliberately NO CPU fallback */
+};
+
+typedef struct ffh_ctx ffh_ctx;
+typedef struct ffh_result ffh_result;
+
+int ffh_version(void);
+int ffh_device_count(void);
+
+/* enzyme_index as stored in the database header: 1 Cpf1, 2 spCas9, 3 spCas9-NGG, 4 spCas9-NAG, 5 spCas9 19-mer,
+ * 6 spCas9-NGG 19-mer (ParameterPack.indexToParameterPack, standards/StandardScanParameters.scala:61-69).
+ * Returns NULL on failure; ffh_last_error(NULL) then tells why. */
+ffh_ctx *ffh_create(int device_id, int enzyme_index);
+void ffh_destroy(ffh_ctx *ctx);
+const char *ffh_last_error(const ffh_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Database residency.  Exactly one of the loaders is called once per context; the database then stays in HBM
+ * (targets, positions, and the two bucketed scan images built from them) for any number of discover calls.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Decoded bin payloads, i.e. the Array[Long] that fillBlock/byteArrayToLong hand to BlockManager.compareBlock
+ * (SeekTraverser.scala:113-120, Utils.scala:167-186), concatenated in bin order.  bin_offsets has n_bins+1
+ * entries (in longs).  Block types 1 (linear) and 2 (indexed, 256-entry sub-bin table) are accepted,
+ * anything else is FFH_E_FORMAT (BlockManager.scala:63-90). */
+int ffh_db_load_blocks(ffh_ctx *ctx, const int64_t *longs, const uint64_t *bin_offsets, uint32_t n_bins);
+
+/* Structure-of-arrays form: targets[] in database order (count in bits 63:48), positions[] concatenated with
+ * count(target i) entries each.  on_device != 0 means both pointers are device pointers on this context's GPU
+ * (they are copied; the caller keeps ownership). */
+int ffh_db_load_soa(ffh_ctx *ctx, const uint64_t *targets, uint64_t n_targets, const uint64_t *positions,
+                    uint64_t n_positions, int on_device);
+
+/* On-disk database written by `index` (text <path>.header, BinaryHeader.scala:69-160, + BGZF body,
+ * DatabaseWriter.scala:58-111).  Only bins [bin_begin, bin_end) are loaded: the static shard of this GPU.
+ * bin_end == 0 means "to the last bin". */
+int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t bin_end);
+
+typedef struct ffh_db_info {
+    uint64_t n_targets;      /* unique target sequences resident (this shard) */
+    uint64_t n_positions;    /* genomic positions resident (this shard) */
+    uint32_t n_bins;         /* bins in the database header (0 for ffh_db_load_soa) */
+    uint32_t bin_begin, bin_end;
+    int enzyme_index;
+    int prefix_bases;        /* bucket widths of the two resident scan images */
+    int suffix_bases;
+    double prepare_ms;       /* device time spent building the scan images */
+} ffh_db_info;
+int ffh_db_info_get(const ffh_ctx *ctx, ffh_db_info *out);
+/* contig names of the database header (1-based ids as in BitPosition.scala:38-49); NULL past the end */
+const char *ffh_db_contig(const ffh_ctx *ctx, uint32_t contig_id);
+
+/* Force the candidate-generation split (tests / tuning).  prefix_bases = width of the prefix bucket key,
+ * prefix_radius = mismatches tolerated inside the prefix; the suffix pass covers the rest.  -1 = automatic. */
+int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * discover = scan + finalize.  Multi-GPU callers run ffh_scan on every shard, exchange ffh_shard_totals, and
+ * pass the totals of the lower-ranked shards to ffh_finalize so the ordered cut-off of
+ * CRISPRSiteOT.addOT/full (crispr/CRISPRSiteOT.scala:39-46) is applied across shards in database order.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Finds every (guide, target) with mismatches(guide, target) <= max_mismatch (BitEncoding.scala:127-132) in
+ * this shard; hits stay on the device, sorted by (guide, database order). */
+int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch);
+
+/* per guide: sum of positions over ALL hits of this shard, saturated at `clamp` (pass max_offtargets) */
+int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t clamp);
+
+#define FFH_FINALIZE_SUMMARIES_ONLY 1u /* do not copy hit lists / positions to the host */
+int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
+                 unsigned flags, ffh_result **out);
+
+int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets,
+                 unsigned flags, ffh_result **out);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Results: guides in input order; per guide the retained hit list in database order, already cut off.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct ffh_guide_summary {
+    uint32_t n_hits;         /* retained off-target sequences (CRISPRSiteOT.offTargets.size) */
+    uint32_t ot_count;       /* sum of their positions = the table's otCount column */
+    uint32_t overflow;       /* CRISPRSiteOT.full after the scan -> OVERFLOW / OK */
+    uint32_t hist[5];        /* ClosestHit: count-weighted histogram over 0..4 mismatches */
+    uint32_t closest;        /* ClosestHit: smallest non-zero mismatch count, 0xFFFFFFFF = none ("UNK") */
+    uint32_t closest_count;
+    uint32_t in_genome;      /* DangerousSequences: occurrences at 0 mismatches */
+    uint32_t n_scored;       /* hits that entered the CFD / Hsu2013 sums (mismatches != 0) */
+    double cfd_max;          /* max over hits of pam*cfd, 0.0 if none (before the 0.023 print threshold) */
+    double cfd_sum;          /* sum of pam*cfd*count in database order; specificity = 1/(1+cfd_sum) */
+    double hsu_sum;          /* sum of Hsu2013 hit scores in database order; score = 100/(100+hsu_sum)*100 */
+} ffh_guide_summary;
+
+uint32_t ffh_result_n_guides(const ffh_result *r);
+uint64_t ffh_result_n_hits(const ffh_result *r);
+uint64_t ffh_result_n_positions(const ffh_result *r);
+int      ffh_result_scores_valid(const ffh_result *r);     /* CFD / Hsu2013 defined for this enzyme (Cas9 23-mer) */
+const ffh_guide_summary *ffh_result_summaries(const ffh_result *r);      /* [n_guides] */
+const uint64_t *ffh_result_guide_offsets(const ffh_result *r);           /* [n_guides+1] into the hit arrays */
+const uint64_t *ffh_result_hit_targets(const ffh_result *r);             /* [n_hits] target longs incl. count */
+const uint8_t  *ffh_result_hit_mismatches(const ffh_result *r);          /* [n_hits] */
+const double   *ffh_result_hit_cfd(const ffh_result *r);                 /* [n_hits] pam*cfd, NaN where not scored */
+const uint64_t *ffh_result_pos_offsets(const ffh_result *r);             /* [n_hits+1] into positions */
+const uint64_t *ffh_result_positions(const ffh_result *r);               /* [n_positions] BitPosition longs */
+void ffh_result_free(ffh_result *r);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Instrumentation of the last ffh_scan/ffh_finalize on this context (HIP events on the context's stream).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct ffh_timings {
+    double prepare_ms;        /* guide encode + candidate lists + tiles */
+    double compare_ms;        /* the compare kernel (the dominant kernel): ONE launch per guide batch covering both images */
+    double sort_ms;           /* hit ordering */
+    double finalize_ms;       /* cut-off, scoring, aggregation, gathers */
+    double total_scan_ms;     /* ffh_scan, first launch to last event */
+    uint64_t n_raw_hits;      /* hits before the cut-off */
+    uint64_t pairs_prefix;    /* full-length comparisons executed by the prefix pass */
+    uint64_t pairs_suffix;    /* ... by the suffix pass */
+    uint64_t items_prefix;    /* (bucket, guide) candidate entries */
+    uint64_t items_suffix;
+    uint64_t tiles_prefix;
+    uint64_t tiles_suffix;
+    uint32_t compare_launches; /* guide batches */
+    int prefix_bases, prefix_radius, suffix_radius;
+} ffh_timings;
+int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,211 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (ctypes).  Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from flashfry_amd import synth
+from tests.helpers import assert_same_hits, assert_same_scores, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from flashfry_amd import capi
+    capi.load_library()
+    assert capi.load_library().ffh_device_count() >= 1, "no GPU visible: the gpu tests must run on the MI355X box"
+    return capi
+
+
+def run_both(capi, oracle, odb, targets, positions, guides, enzyme, max_mm, max_ot, via="soa", plan=None):
+    with capi.Context(enzyme) as ctx:
+        if plan:
+            ctx.set_plan(*plan[:1])
+        if via == "soa":
+            ctx.load_soa(targets, positions)
+        else:
+            longs, offs = odb.all_blocks()
+            ctx.load_blocks(longs, offs)
+        if plan:
+            ctx.set_plan(*plan)
+        gpu = ctx.discover(guides, max_mm, max_ot)
+        tm = ctx.timings()
+    ora = odb.discover(guides, max_mm, max_ot)
+    return gpu, ora, tm
+
+
+@pytest.mark.parametrize("max_mm", [0, 1, 2, 3, 4, 5])
+def test_hits_match_oracle_cas9(capi, oracle, max_mm):
+    odb, t, p, g = make_case(oracle, 60000, 400, enzyme=3, seed=max_mm)
+    gpu, ora, tm = run_both(capi, oracle, odb, t, p, g, 3, max_mm, 2000)
+    assert_same_hits(gpu, ora)
+    assert_same_scores(oracle, 3, g, gpu, ora)
+    assert gpu.n_hits > 0
+
+
+def test_blocks_loader_equals_soa_loader(capi, oracle):
+    # max_linear=40 forces a mix of linear and indexed blocks (BlockManager.scala:63-90 dispatch)
+    odb, t, p, g = make_case(oracle, 300000, 300, enzyme=2, seed=11, max_linear=40)
+    kinds = {int(odb.bin(b)[0][0]) for b in range(0, odb.n_bins, 97)}
+    assert kinds == {1, 2}
+    a, ora, _ = run_both(capi, oracle, odb, t, p, g, 2, 4, 2000, via="blocks")
+    b, _, _ = run_both(capi, oracle, odb, t, p, g, 2, 4, 2000, via="soa")
+    assert_same_hits(a, ora)
+    assert_same_hits(b, ora)
+    assert_same_scores(oracle, 2, g, a, ora)
+
+
+@pytest.mark.parametrize("plan", [(8, 0), (8, 1), (8, 2), (8, 3), (8, 4), (10, 2), (11, 1), (12, 2), (9, 3)])
+def test_every_candidate_split_gives_the_same_hits(capi, oracle, plan):
+    """the prefix/suffix ball split is an exact filter: any (width, radius) must reproduce the oracle's hit set"""
+    odb, t, p, g = make_case(oracle, 80000, 300, enzyme=3, seed=5)
+    gpu, ora, tm = run_both(capi, oracle, odb, t, p, g, 3, 4, 2000, plan=plan)
+    assert tm.prefix_bases == plan[0]
+    assert_same_hits(gpu, ora)
+
+
+@pytest.mark.parametrize("max_ot", [0, 1, 5, 37, 2000])
+def test_ordered_cutoff(capi, oracle, max_ot):
+    """CRISPRSiteOT.addOT/full (CRISPRSiteOT.scala:39-46): keep while the running position total is < max"""
+    odb, t, p, g = make_case(oracle, 120000, 500, enzyme=3, seed=21)
+    gpu, ora, _ = run_both(capi, oracle, odb, t, p, g, 3, 5, max_ot)
+    assert_same_hits(gpu, ora)
+    if 0 < max_ot < 2000:
+        assert ora.full.any() and not ora.full.all()
+    assert_same_scores(oracle, 3, g, gpu, ora)
+
+
+@pytest.mark.parametrize("enzyme", [1, 4, 5, 6])
+def test_other_enzymes(capi, oracle, enzyme):
+    """Cpf1 (5' PAM, bases 4..23 compared), NAG, and the 19-mer packs (StandardScanParameters.scala:90-215)"""
+    rng = np.random.default_rng(enzyme)
+    L = {1: 24, 4: 23, 5: 22, 6: 22}[enzyme]
+    n = 40000
+    raw = rng.integers(0, 1 << (2 * L), size=n, dtype=np.uint64)
+    raw = np.unique(raw)
+    counts = rng.integers(1, 4, size=len(raw)).astype(np.uint64)
+    targets = raw | (counts << np.uint64(48))
+    if enzyme == 1:  # database order of a 5'-PAM enzyme: bin = bases 4..10, then the full string
+        binkey = (raw >> np.uint64(2 * (24 - 11))) & np.uint64(0x3FFF)
+        order = np.lexsort((raw, binkey))
+        targets = targets[order]
+        raw = raw[order]
+    positions = rng.integers(0, 1 << 27, size=int(counts.sum()), dtype=np.uint64) | (np.uint64(L) << np.uint64(52)) | (np.uint64(1) << np.uint64(32))
+    if enzyme == 1:
+        counts = (targets >> np.uint64(48))
+    odb = oracle.db_from_sorted(enzyme, targets, positions, contigs=["c1"])
+    # guides = mutated database members so that hits exist
+    pick = rng.integers(0, len(raw), size=200)
+    guides = raw[pick].copy()
+    for k in range(len(guides)):
+        for _ in range(rng.integers(0, 5)):
+            guides[k] ^= np.uint64(int(rng.integers(1, 4)) << (2 * int(rng.integers(0, L))))
+    guides |= np.uint64(1) << np.uint64(48)
+    gpu, ora, _ = run_both(capi, oracle, odb, targets, positions, guides, enzyme, 3, 2000)
+    assert_same_hits(gpu, ora)
+    assert gpu.n_hits >= 50
+    assert_same_scores(oracle, enzyme, guides, gpu, ora)
+
+
+def test_edge_cases(capi, oracle):
+    odb, t, p, g = make_case(oracle, 5000, 50, enzyme=3, seed=2)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        r = ctx.discover(np.zeros(0, dtype=np.uint64), 4, 2000)           # no guides
+        assert r.n_guides == 0 and r.n_hits == 0
+        far = np.array([oracle.encode("ACGT" * 5 + "AGG")], dtype=np.uint64)  # a guide without any hit
+        r = ctx.discover(far, 0, 2000)
+        assert r.n_guides == 1
+        o = odb.discover(far, 0, 2000)
+        assert_same_hits(r, o)
+        dup = np.concatenate([g[:10], g[:10]])                              # duplicated guides give separate rows (quirk 11)
+        r = ctx.discover(dup, 4, 2000)
+        assert_same_hits(r, odb.discover(dup, 4, 2000))
+        assert np.array_equal(r.hits(0), r.hits(10))
+    with capi.Context(3) as ctx:                                            # empty database
+        ctx.load_soa(np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+        r = ctx.discover(g, 4, 2000)
+        assert r.n_hits == 0 and not r.summaries["overflow"].any()
+    with capi.Context(3) as ctx:                                            # malformed input is refused
+        bad = t.copy()
+        bad[3] &= np.uint64((1 << 48) - 1)                                  # count 0
+        with pytest.raises(capi.FlashFryHipError):
+            ctx.load_soa(bad, p)
+        with pytest.raises(capi.FlashFryHipError):
+            ctx.load_blocks(np.array([7, 1, 2], dtype=np.int64), np.array([0, 3], dtype=np.uint64))  # unknown block type
+        with pytest.raises(capi.FlashFryHipError):
+            ctx.discover(g, 4, 2000)                                       # no database loaded
+
+
+def test_hit_buffer_growth_and_heavy_guides(capi, oracle):
+    """guides with very many hits: poly-A database, max_mm large, staging buffer must regrow; cut-off still exact"""
+    rng = np.random.default_rng(3)
+    base = oracle.encode("A" * 20 + "AGG") & ((1 << 46) - 1)
+    muts = set()
+    while len(muts) < 30000:
+        v = base
+        for _ in range(rng.integers(0, 5)):
+            v ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(3, 23)))
+        muts.add(v)
+    raw = np.array(sorted(muts), dtype=np.uint64)
+    targets = raw | (np.uint64(1) << np.uint64(48))
+    positions = np.arange(len(raw), dtype=np.uint64) | (np.uint64(23) << np.uint64(52)) | (np.uint64(1) << np.uint64(32))
+    odb = oracle.db_from_sorted(3, targets, positions, contigs=["c1"])
+    guides = np.array([oracle.encode("A" * 20 + "TGG"), oracle.encode("A" * 19 + "C" + "TGG"), oracle.encode("ACGT" * 5 + "TGG")], dtype=np.uint64)
+    for max_ot in (2000, 10 ** 6):
+        gpu, ora, _ = run_both(capi, oracle, odb, targets, positions, guides, 3, 6, max_ot)
+        assert_same_hits(gpu, ora)
+    assert gpu.n_hits >= 30000
+
+
+def test_two_shards_with_ordered_cutoff(capi, oracle):
+    """bins split over two contexts; totals of the first shard shift the cut-off of the second"""
+    odb, t, p, g = make_case(oracle, 150000, 400, enzyme=3, seed=31)
+    max_ot = 40
+    ora = odb.discover(g, 5, max_ot)
+    cut = len(t) // 2
+    poff = np.concatenate([[0], np.cumsum(t >> np.uint64(48))]).astype(np.int64)
+    parts = [(t[:cut], p[:poff[cut]]), (t[cut:], p[poff[cut]:])]
+    ctxs = [capi.Context(3), capi.Context(3)]
+    try:
+        for c, (tt, pp) in zip(ctxs, parts):
+            c.load_soa(tt, pp)
+            c.scan(g, 5)
+        totals = [c.shard_totals(max_ot) for c in ctxs]
+        prior = [np.zeros(len(g), np.uint32), totals[0]]
+        res = [c.finalize(max_ot, prior_totals=pr) for c, pr in zip(ctxs, prior)]
+    finally:
+        for c in ctxs:
+            c.close()
+    n_hits = res[0].summaries["n_hits"].astype(np.int64) + res[1].summaries["n_hits"]
+    assert np.array_equal(n_hits, np.diff(ora.guide_offsets.astype(np.int64)))
+    for gi in range(len(g)):
+        assert np.array_equal(np.concatenate([res[0].hits(gi), res[1].hits(gi)]), ora.hits(gi))
+    tot = res[0].summaries["ot_count"].astype(np.int64) + res[1].summaries["ot_count"]
+    assert np.array_equal(tot, ora.current_total)
+    assert np.array_equal((res[0].summaries["overflow"] | res[1].summaries["overflow"]).astype(bool), ora.full)
+
+
+def test_database_file_roundtrip(capi, oracle, tmp_path):
+    """a database written in the reference's on-disk format (.header + BGZF) loads into the HIP path, whole and by bin range"""
+    odb, t, p, g = make_case(oracle, 50000, 100, enzyme=3, seed=41, max_linear=3)
+    path = str(tmp_path / "synthetic_db")
+    odb.write(path)
+    ora = odb.discover(g, 4, 2000)
+    with capi.Context(3) as ctx:
+        ctx.open(path)
+        info = ctx.info()
+        assert info.n_targets == len(t) and info.n_positions == len(p) and info.n_bins == 16384
+        assert ctx.contigs() == synth.CONTIGS_24
+        gpu = ctx.discover(g, 4, 2000)
+    assert_same_hits(gpu, ora)
+    with capi.Context(3) as c0, capi.Context(3) as c1:
+        c0.open(path, 0, 8192)
+        c1.open(path, 8192, 0)
+        assert c0.info().n_targets + c1.info().n_targets == len(t)
+        c0.scan(g, 4); c1.scan(g, 4)
+        r0 = c0.finalize(2000)
+        r1 = c1.finalize(2000, prior_totals=c0.shard_totals(2000))
+    for gi in range(len(g)):
+        assert np.array_equal(np.concatenate([r0.hits(gi), r1.hits(gi)]), ora.hits(gi))
