@@ -45,8 +45,8 @@ def test_hits_match_oracle_cas9(capi, oracle, max_mm):
 
 
 def test_blocks_loader_equals_soa_loader(capi, oracle):
-    # max_linear=40 forces a mix of linear and indexed blocks (BlockManager.scala:63-90 dispatch)
-    odb, t, p, g = make_case(oracle, 300000, 300, enzyme=2, seed=11, max_linear=40)
+    # max_linear=18 (about the mean bin size) forces a mix of linear and indexed blocks (BlockManager.scala:63-90 dispatch)
+    odb, t, p, g = make_case(oracle, 300000, 300, enzyme=2, seed=11, max_linear=18)
     kinds = {int(odb.bin(b)[0][0]) for b in range(0, odb.n_bins, 97)}
     assert kinds == {1, 2}
     a, ora, _ = run_both(capi, oracle, odb, t, p, g, 2, 4, 2000, via="blocks")
@@ -65,14 +65,38 @@ def test_every_candidate_split_gives_the_same_hits(capi, oracle, plan):
     assert_same_hits(gpu, ora)
 
 
+def dense_case(oracle, n_random=60000, n_guides=300, n_dense=40, variants=80, seed=21):
+    """random database + a dense neighbourhood (<= 3 substitutions) around the first n_dense guides, so that those
+    guides collect many hits and the cut-off rule is exercised"""
+    g = synth.make_guides(n_guides, seed=synth.GUIDE_SEED + seed)
+    db = synth.make_database(n_random, seed=synth.DB_SEED + seed, plant_guides=g, with_positions=False)
+    rng = np.random.default_rng(seed)
+    mers = set(int(x) for x in ((db["targets"] >> 6) & synth.MASK40))
+    for gi in range(n_dense):
+        base = (int(g[gi]) >> 6) & synth.MASK40
+        for _ in range(variants):
+            v = base
+            for _ in range(int(rng.integers(1, 4))):
+                v ^= int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 20)))
+            mers.add(v)
+    mers = np.array(sorted(mers), dtype=np.uint64)
+    counts = rng.integers(1, 6, size=len(mers)).astype(np.uint64)
+    targets = (mers << np.uint64(6)) | np.uint64(0b101010) | (counts << np.uint64(48))
+    positions = rng.integers(0, 1 << 27, size=int(counts.sum()), dtype=np.uint64) | (np.uint64(23) << np.uint64(52)) | (np.uint64(3) << np.uint64(32))
+    odb = oracle.db_from_sorted(3, targets, positions, contigs=synth.CONTIGS_24)
+    return odb, targets, positions, synth.as_u64(g)
+
+
 @pytest.mark.parametrize("max_ot", [0, 1, 5, 37, 2000])
 def test_ordered_cutoff(capi, oracle, max_ot):
     """CRISPRSiteOT.addOT/full (CRISPRSiteOT.scala:39-46): keep while the running position total is < max"""
-    odb, t, p, g = make_case(oracle, 120000, 500, enzyme=3, seed=21)
-    gpu, ora, _ = run_both(capi, oracle, odb, t, p, g, 3, 5, max_ot)
+    odb, t, p, g = dense_case(oracle)
+    gpu, ora, _ = run_both(capi, oracle, odb, t, p, g, 3, 4, max_ot)
     assert_same_hits(gpu, ora)
     if 0 < max_ot < 2000:
         assert ora.full.any() and not ora.full.all()
+        # the last retained hit may overshoot the limit (addOT adds the whole position list, CRISPRSiteOT.scala:45)
+        assert (ora.current_total[ora.full] >= max_ot).all()
     assert_same_scores(oracle, 3, g, gpu, ora)
 
 
@@ -161,9 +185,10 @@ def test_hit_buffer_growth_and_heavy_guides(capi, oracle):
 
 def test_two_shards_with_ordered_cutoff(capi, oracle):
     """bins split over two contexts; totals of the first shard shift the cut-off of the second"""
-    odb, t, p, g = make_case(oracle, 150000, 400, enzyme=3, seed=31)
+    odb, t, p, g = dense_case(oracle, seed=31)
     max_ot = 40
     ora = odb.discover(g, 5, max_ot)
+    assert ora.full.any() and not ora.full.all()
     cut = len(t) // 2
     poff = np.concatenate([[0], np.cumsum(t >> np.uint64(48))]).astype(np.int64)
     parts = [(t[:cut], p[:poff[cut]]), (t[cut:], p[poff[cut]:])]
