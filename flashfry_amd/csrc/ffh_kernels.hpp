@@ -97,90 +97,157 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
     gbucket[g] = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
 }
 
-__global__ void k_item_count(const uint32_t *__restrict__ gbucket, uint32_t n_guides, const uint32_t *__restrict__ patterns, uint32_t n_pat,
-                             const uint32_t *__restrict__ bstart, uint32_t *__restrict__ icount) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n_guides * n_pat) return;
-    const uint32_t g = (uint32_t)(i / n_pat), j = (uint32_t)(i % n_pat);
-    const uint32_t b = gbucket[g] ^ patterns[j];
-    if (bstart[b + 1] != bstart[b]) atomicAdd(&icount[b], 1u);
+// Candidate slot rows.  Every bucket owns a fixed-capacity row of `cap` candidate slots (guide ids only; the 8-byte
+// planar guide keys stay in a table small enough to live in L2 and are gathered by the compare kernel).  The
+// (bucket, guide) entries are enumerated implicitly (bucket = guide bucket ^ pattern) and binned in two steps so
+// that no per-entry global atomic is needed (device-scope atomics on random addresses run at ~1.3e10/s on MI355X,
+// 4 ms for the 5.6e7 entries of the hg38-scale workload):
+//   A  k_item_partition: a block histograms 64Ki entries over the partitions (= high bits of the bucket id) in LDS,
+//      reserves one contiguous run per partition with ONE global atomic each, and writes (low bucket bits, guide)
+//      records into the partition's staging area;
+//   B  k_item_bin: one block per partition bins its records into the slot rows with LDS atomics and writes the
+//      per-bucket fill counts.
+// An entry that does not fit (partition staging area or slot row full) goes to a short overflow list that a
+// fallback kernel scans one entry per wave.
+constexpr int kPartThreads = 256;
+constexpr int kPartItemsPerBlock = 65536;
+constexpr int kMaxPartBits = 12;  // <= 4096 partitions, <= 4096 buckets per partition
+constexpr int kGidBits = 20;      // guides per batch < 2^20
+
+struct ItemGeom {
+    uint32_t n_guides, n_pat;
+    uint32_t low_bits;       // bucket id = (partition << low_bits) | low
+    uint32_t n_part;
+    uint32_t part_cap;       // staging records per partition
+    uint32_t cap;            // slots per bucket row
+    uint32_t side;
+    uint64_t ovf_cap;
+};
+
+__device__ __forceinline__ void push_overflow(uint64_t *__restrict__ overflow, unsigned long long *__restrict__ ovf_cursor, uint64_t ovf_cap,
+                                              uint32_t side, uint32_t b, uint32_t g) {
+    const unsigned long long o = atomicAdd(ovf_cursor, 1ull);
+    if (o < ovf_cap) overflow[o] = ((uint64_t)side << 63) | ((uint64_t)b << 32) | g;
 }
 
-__global__ void k_item_fill(const uint32_t *__restrict__ gbucket, const uint64_t *__restrict__ gkey, uint32_t n_guides,
-                            const uint32_t *__restrict__ patterns, uint32_t n_pat, const uint32_t *__restrict__ bstart,
-                            const uint32_t *__restrict__ istart, uint32_t *__restrict__ ifill, const uint32_t *__restrict__ item_base,
-                            uint64_t *__restrict__ item_key, uint32_t *__restrict__ item_gid) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n_guides * n_pat) return;
-    const uint32_t g = (uint32_t)(i / n_pat), j = (uint32_t)(i % n_pat);
-    const uint32_t b = gbucket[g] ^ patterns[j];
-    if (bstart[b + 1] == bstart[b]) return;
-    const uint32_t pos = *item_base + istart[b] + atomicAdd(&ifill[b], 1u);
-    item_key[pos] = gkey[g];
-    item_gid[pos] = g;
+__global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
+                                                                 uint32_t *__restrict__ part_fill, uint32_t *__restrict__ part_items,
+                                                                 uint64_t *__restrict__ overflow, unsigned long long *__restrict__ ovf_cursor) {
+    __shared__ uint32_t cur[1 << kMaxPartBits];
+    const uint64_t total = (uint64_t)ig.n_guides * ig.n_pat;
+    const uint64_t begin = (uint64_t)blockIdx.x * kPartItemsPerBlock;
+    const uint64_t end = min(total, begin + (uint64_t)kPartItemsPerBlock);
+    for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) cur[d] = 0;
+    __syncthreads();
+    // entry i = guide (i / n_pat), pattern (i % n_pat); 32-bit arithmetic relative to the block's first entry
+    const uint32_t g_first = (uint32_t)(begin / ig.n_pat), j_first = (uint32_t)(begin - (uint64_t)g_first * ig.n_pat);
+    const uint32_t n_here = (uint32_t)(end - begin);
+    for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
+        const uint32_t x = j_first + o, q = x / ig.n_pat;
+        const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat];
+        atomicAdd(&cur[b >> ig.low_bits], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
+        const uint32_t c = cur[d];
+        cur[d] = c ? atomicAdd(&part_fill[d], c) : 0u;  // start of this block's run inside partition d
+    }
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
+        const uint32_t x = j_first + o, q = x / ig.n_pat, g = g_first + q;
+        const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat];
+        const uint32_t d = b >> ig.low_bits;
+        const uint32_t pos = atomicAdd(&cur[d], 1u);
+        if (pos < ig.part_cap) part_items[(uint64_t)d * ig.part_cap + pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
+        else push_overflow(overflow, ovf_cursor, ig.ovf_cap, ig.side, b, g);
+    }
+}
+
+__global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__restrict__ part_fill, const uint32_t *__restrict__ part_items, ItemGeom ig,
+                                                           uint32_t *__restrict__ ifill, uint32_t *__restrict__ slots, uint64_t *__restrict__ overflow,
+                                                           unsigned long long *__restrict__ ovf_cursor) {
+    __shared__ uint32_t cnt[1 << kMaxPartBits];
+    const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits;
+    for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
+    __syncthreads();
+    const uint32_t n = min(part_fill[d], ig.part_cap);
+    const uint32_t *__restrict__ src = part_items + (uint64_t)d * ig.part_cap;
+    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) {
+        const uint32_t it = src[k], low = it >> kGidBits, g = it & ((1u << kGidBits) - 1u);
+        const uint32_t pos = atomicAdd(&cnt[low], 1u);
+        const uint32_t b = (d << ig.low_bits) | low;
+        if (pos < ig.cap) slots[(uint64_t)b * ig.cap + pos] = g;
+        else push_overflow(overflow, ovf_cursor, ig.ovf_cap, ig.side, b, g);
+    }
+    __syncthreads();
+    for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) ifill[(d << ig.low_bits) + l] = cnt[l];
 }
 
 constexpr int kTileTargets = 64;  // one target per lane
 
-__global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, uint32_t n_buckets,
-                             uint32_t *__restrict__ tcount, unsigned long long *__restrict__ pairs) {
+__global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, uint32_t n_buckets,
+                             uint32_t *__restrict__ tcount) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long mine = 0;
-    if (b < n_buckets) {
-        const uint32_t nt = bstart[b + 1] - bstart[b], ng = istart[b + 1] - istart[b];
-        tcount[b] = ng ? (nt + kTileTargets - 1) / kTileTargets : 0;
-        mine = (unsigned long long)nt * ng;
-    }
-    // wave-reduce the pair count, one atomic per wave
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(pairs, mine);
+    if (b >= n_buckets) return;
+    const uint32_t nt = bstart[b + 1] - bstart[b];
+    tcount[b] = ifill[b] ? (nt + kTileTargets - 1) / kTileTargets : 0;
 }
 
-// tile = {first key, #keys | side << 31, first item, #items}; tiles of both images share one list so that ONE
-// compare launch covers the prefix and the suffix pass
-__global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, const uint32_t *__restrict__ tstart,
-                            uint32_t n_buckets, const uint32_t *__restrict__ item_base, const uint32_t *__restrict__ tile_base, uint32_t side,
+// tile = {first key, #keys | side << 31, first slot, #slots used}; tiles of both images share one list so that
+// ONE compare launch covers the prefix and the suffix pass
+__global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, const uint32_t *__restrict__ tstart,
+                            uint32_t n_buckets, uint32_t cap, uint32_t slot_base, const uint32_t *__restrict__ tile_base, uint32_t side,
                             uint4 *__restrict__ tiles) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t t0 = tstart[b], nt = tstart[b + 1] - t0;
     if (!nt) return;
-    const uint32_t k0 = bstart[b], kn = bstart[b + 1] - k0, g0 = *item_base + istart[b], gn = istart[b + 1] - istart[b];
+    const uint32_t k0 = bstart[b], kn = bstart[b + 1] - k0, gn = min(ifill[b], cap);
     uint4 *out = tiles + *tile_base + t0;
     for (uint32_t c = 0; c < nt; ++c) {
         const uint32_t kb = c * kTileTargets;
-        out[c] = make_uint4(k0 + kb, min(kn - kb, (uint32_t)kTileTargets) | (side << 31), g0, gn);
+        out[c] = make_uint4(k0 + kb, min(kn - kb, (uint32_t)kTileTargets) | (side << 31), slot_base + b * cap, gn);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // THE HOT KERNEL.  One wave owns one tile at a time: <= 64 bucket-mates (one target per lane, streamed coalesced
-// from the scan image) against that bucket's candidate guides (wave-uniform, fetched through the scalar cache).
-// Per (guide, target): 2 x v_xor, v_or, v_bcnt, v_cmp.  Hits are compacted with ballot + mbcnt into a per-wave
-// LDS staging buffer and flushed with ONE global atomic per ~200 hits (a single global cursor saturates at
-// < 1e8 atomics/s, far below the hit rate).
+// from the scan image) against that bucket's candidate guides.  The candidates are fetched 64 at a time with ONE
+// coalesced load of the slot row + one gather of the planar guide keys (L2-resident table), then broadcast lane by
+// lane with v_readlane, so the inner loop touches no memory: per (guide, target) 2 x v_readlane, 2 x v_xor, v_or,
+// v_bcnt, v_cmp.  The next tile's descriptor, keys and slot row are requested before the current tile is
+// processed.  Hits are compacted with ballot + mbcnt into a per-wave LDS staging buffer and flushed with ONE
+// global atomic per ~200 hits (a single global cursor saturates far below the hit rate).
 //   Suffix-image tiles: the same pair can only also be found through the prefix image when its prefix part has
 //   <= r1 mismatches, so it is emitted from a suffix tile only if the prefix part has MORE than r1.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCmpThreads = 256;
 constexpr int kStage = 256;  // staged hits per wave
 
-__global__ __launch_bounds__(kCmpThreads) void k_compare(const uint4 *__restrict__ tiles, const uint32_t *__restrict__ n_tiles_a,
-                                                         const uint32_t *__restrict__ n_tiles_b, const uint64_t *__restrict__ keys_p,
-                                                         const uint32_t *__restrict__ tidx_p, const uint64_t *__restrict__ keys_s,
-                                                         const uint32_t *__restrict__ tidx_s, const uint64_t *__restrict__ item_key,
-                                                         const uint32_t *__restrict__ item_gid, int max_mm, uint32_t prefix_mask, int r1,
-                                                         uint64_t *__restrict__ hits, unsigned long long *__restrict__ cursor, uint64_t cap) {
-    __shared__ uint64_t stage[kCmpThreads / 64][kStage];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kCmpThreads / 64);
-    const uint32_t n_tiles = *n_tiles_a + *n_tiles_b;
-    uint64_t *my = stage[wave];
-    uint32_t fill = 0;
+struct CompareArgs {
+    const uint4 *tiles;
+    const uint32_t *n_tiles_a, *n_tiles_b;
+    const uint64_t *keys[2];
+    const uint32_t *tidx[2];
+    const uint32_t *slots;
+    const uint64_t *gkey;
+    int max_mm;
+    uint32_t prefix_mask;
+    int r1;
+    uint64_t *hits;
+    unsigned long long *cursor;  // [0] hit cursor, [1] pairs (prefix image), [2] pairs (suffix image)
+    uint64_t cap;
+};
 
-    auto flush = [&]() {
+struct HitStage {
+    uint64_t *my;
+    uint32_t fill;
+    uint32_t lane;
+    uint64_t *hits;
+    unsigned long long *cursor;
+    uint64_t cap;
+
+    __device__ __forceinline__ void flush() {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(cursor, (unsigned long long)fill);
         base = __shfl(base, 0, 64);
@@ -192,45 +259,139 @@ __global__ __launch_bounds__(kCmpThreads) void k_compare(const uint4 *__restrict
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         fill = 0;
-    };
-    auto emit = [&](bool hit, uint32_t gid_index, uint32_t ti, const uint32_t *__restrict__ ig) {
-        const uint64_t mask = __ballot(hit);
-        if (mask) {
-            const uint32_t gid = ig[gid_index];
-            if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid << 32) | ti;
-            fill += (uint32_t)__popcll(mask);
-            if (fill > kStage - 64) flush();
-        }
-    };
+    }
+    // wave-uniform call: `mask` = ballot of the lanes that hit guide `gid`
+    __device__ __forceinline__ void push(uint64_t mask, bool hit, uint32_t gid, uint32_t ti) {
+        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid << 32) | ti;
+        fill += (uint32_t)__popcll(mask);
+        if (fill > kStage - 64) flush();
+    }
+};
 
-    for (uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave; t < n_tiles; t += n_waves) {
-        const uint4 tile = tiles[t];
-        const bool suffix = (tile.y >> 31) != 0;  // wave-uniform
-        const uint32_t nk = tile.y & 0x7FFFFFFFu;
-        const bool valid = lane < nk;
-        const uint64_t *__restrict__ keys = suffix ? keys_s : keys_p;
-        const uint32_t *__restrict__ tidx = suffix ? tidx_s : tidx_p;
-        const uint64_t k = valid ? keys[tile.x + lane] : 0;
-        const uint32_t ti = valid ? tidx[tile.x + lane] : 0;
+__global__ __launch_bounds__(kCmpThreads) void k_compare(const CompareArgs a) {
+    __shared__ uint64_t stage[kCmpThreads / 64][kStage];
+    __shared__ unsigned long long blk_pairs[2];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kCmpThreads / 64);
+    const uint32_t n_tiles = *a.n_tiles_a + *a.n_tiles_b;
+    if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
+    __syncthreads();
+    HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap};
+    unsigned long long pairs[2] = {0, 0};
+
+    uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave;
+    // software pipeline: `nxt*` always holds the loads of the tile that will be processed next
+    uint4 tile = make_uint4(0, 0, 0, 0);
+    uint64_t nk = 0;
+    uint32_t nti = 0, ngid = 0;
+    if (t < n_tiles) {
+        tile = a.tiles[t];
+        const uint32_t side = tile.y >> 31, cnt = tile.y & 0x7FFFFFFFu;
+        if (lane < cnt) { nk = a.keys[side][tile.x + lane]; nti = a.tidx[side][tile.x + lane]; }
+        if (lane < tile.w) ngid = a.slots[tile.z + lane];
+    }
+    while (t < n_tiles) {
+        const uint4 cur = tile;
+        const uint64_t k = nk;
+        const uint32_t ti = nti;
+        uint32_t gid = ngid;
+        const bool suffix = (cur.y >> 31) != 0;  // wave-uniform
+        const uint32_t cnt = cur.y & 0x7FFFFFFFu, ng = cur.w;
+        const bool valid = lane < cnt;
+        // guide keys of the first 64 candidates (gather from the L2-resident table)
+        uint64_t gk = (lane < ng) ? a.gkey[gid] : 0;
+        // request the next tile before computing
+        const uint32_t tn = t + n_waves;
+        if (tn < n_tiles) {
+            tile = a.tiles[tn];
+            const uint32_t side = tile.y >> 31, c2 = tile.y & 0x7FFFFFFFu;
+            nk = 0; nti = 0; ngid = 0;
+            if (lane < c2) { nk = a.keys[side][tile.x + lane]; nti = a.tidx[side][tile.x + lane]; }
+            if (lane < tile.w) ngid = a.slots[tile.z + lane];
+        }
+        pairs[suffix ? 1 : 0] += (unsigned long long)cnt * ng;
         const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
-        const uint64_t *__restrict__ ik = item_key + tile.z;
-        const uint32_t *__restrict__ ig = item_gid + tile.z;
-        const uint32_t ng = tile.w;
-        if (!suffix) {
-            for (uint32_t j = 0; j < ng; ++j) {
-                const uint64_t g = ik[j];
-                const uint32_t y = (kh ^ (uint32_t)(g >> 32)) | (kl ^ (uint32_t)g);
-                emit(valid && (__popc(y) <= max_mm), j, ti, ig);
+        const uint64_t valid_mask = __ballot(valid);
+        // one candidate guide against the 64 lanes; `m` = lanes within max_mm (suffix tiles: and not reachable via the prefix image)
+        auto test = [&](uint32_t gh, uint32_t gl, uint32_t &y) -> uint64_t {
+            y = (kh ^ gh) | (kl ^ gl);
+            return __builtin_amdgcn_ballot_w64(__popc(y) <= a.max_mm) & valid_mask;
+        };
+        auto report = [&](uint64_t m, uint32_t y, uint32_t j) {
+            if (suffix) m &= __builtin_amdgcn_ballot_w64(__popc(y & a.prefix_mask) > a.r1);
+            if (m) hs.push(m, (m >> lane) & 1ull, __builtin_amdgcn_readlane(gid, j), ti);
+        };
+        for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+            if (g0) {  // rows longer than 64 candidates: fetch the next 64
+                gid = (g0 + lane < ng) ? a.slots[cur.z + g0 + lane] : 0;
+                gk = (g0 + lane < ng) ? a.gkey[gid] : 0;
             }
-        } else {
-            for (uint32_t j = 0; j < ng; ++j) {
-                const uint64_t g = ik[j];
-                const uint32_t y = (kh ^ (uint32_t)(g >> 32)) | (kl ^ (uint32_t)g);
-                emit(valid && (__popc(y) <= max_mm) && (__popc(y & prefix_mask) > r1), j, ti, ig);
+            const uint32_t gh_v = (uint32_t)(gk >> 32), gl_v = (uint32_t)gk;
+            const uint32_t n = min(ng - g0, 64u), n4 = n & ~3u;
+            uint32_t j = 0;
+            for (; j < n4; j += 4) {
+                uint32_t y0, y1, y2, y3;
+                const uint64_t m0 = test(__builtin_amdgcn_readlane(gh_v, j), __builtin_amdgcn_readlane(gl_v, j), y0);
+                const uint64_t m1 = test(__builtin_amdgcn_readlane(gh_v, j + 1), __builtin_amdgcn_readlane(gl_v, j + 1), y1);
+                const uint64_t m2 = test(__builtin_amdgcn_readlane(gh_v, j + 2), __builtin_amdgcn_readlane(gl_v, j + 2), y2);
+                const uint64_t m3 = test(__builtin_amdgcn_readlane(gh_v, j + 3), __builtin_amdgcn_readlane(gl_v, j + 3), y3);
+                if (m0 | m1 | m2 | m3) {
+                    if (m0) report(m0, y0, j);
+                    if (m1) report(m1, y1, j + 1);
+                    if (m2) report(m2, y2, j + 2);
+                    if (m3) report(m3, y3, j + 3);
+                }
             }
+            for (; j < n; ++j) {
+                uint32_t y;
+                const uint64_t m = test(__builtin_amdgcn_readlane(gh_v, j), __builtin_amdgcn_readlane(gl_v, j), y);
+                if (m) report(m, y, j);
+            }
+        }
+        t = tn;
+    }
+    if (hs.fill) hs.flush();
+    if (lane == 0) {
+        if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);
+        if (pairs[1]) atomicAdd(&blk_pairs[1], pairs[1]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(a.cursor + 1 + threadIdx.x, blk_pairs[threadIdx.x]);
+}
+
+// fallback for candidate entries that did not fit their slot row: one wave per (bucket, guide) entry
+__global__ __launch_bounds__(64) void k_compare_overflow(const uint64_t *__restrict__ overflow, const unsigned long long *__restrict__ n_ovf_ptr,
+                                                         uint64_t ovf_cap, const uint32_t *__restrict__ bstart_p, const uint32_t *__restrict__ bstart_s,
+                                                         CompareArgs a) {
+    __shared__ uint64_t stage[kStage];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n_ovf = min((uint64_t)*n_ovf_ptr, ovf_cap);
+    HitStage hs{stage, 0u, lane, a.hits, a.cursor, a.cap};
+    unsigned long long pairs[2] = {0, 0};
+    for (uint64_t e = blockIdx.x; e < n_ovf; e += gridDim.x) {
+        const uint64_t ent = overflow[e];
+        const uint32_t side = (uint32_t)(ent >> 63), b = (uint32_t)(ent >> 32) & 0x7FFFFFFFu, gid = (uint32_t)ent;
+        const uint32_t *bs = side ? bstart_s : bstart_p;
+        const uint32_t k0 = bs[b], kn = bs[b + 1] - k0;
+        const uint64_t g = a.gkey[gid];
+        pairs[side] += kn;
+        for (uint32_t c = 0; c < kn; c += 64) {
+            const bool valid = c + lane < kn;
+            const uint64_t k = valid ? a.keys[side][k0 + c + lane] : 0;
+            const uint32_t ti = valid ? a.tidx[side][k0 + c + lane] : 0;
+            const uint32_t y = ((uint32_t)(k >> 32) ^ (uint32_t)(g >> 32)) | ((uint32_t)k ^ (uint32_t)g);
+            bool hit = valid && (__popc(y) <= a.max_mm);
+            if (side) hit = hit && (__popc(y & a.prefix_mask) > a.r1);
+            const uint64_t mask = __ballot(hit);
+            if (mask) hs.push(mask, hit, gid, ti);
         }
     }
-    if (fill) flush();
+    if (hs.fill) hs.flush();
+    if (lane == 0) {
+        if (pairs[0]) atomicAdd(a.cursor + 1, pairs[0]);
+        if (pairs[1]) atomicAdd(a.cursor + 2, pairs[1]);
+    }
 }
 
 __global__ void k_add_u64(uint64_t *__restrict__ v, uint64_t n, uint64_t add) {

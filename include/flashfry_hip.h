@@ -165,10 +165,11 @@ typedef struct ffh_timings {
     uint64_t n_raw_hits;      /* hits before the cut-off */
     uint64_t pairs_prefix;    /* full-length comparisons executed by the prefix pass */
     uint64_t pairs_suffix;    /* ... by the suffix pass */
-    uint64_t items_prefix;    /* (bucket, guide) candidate entries */
+    uint64_t items_prefix;    /* (bucket, guide) candidate entries enumerated */
     uint64_t items_suffix;
     uint64_t tiles_prefix;
     uint64_t tiles_suffix;
+    uint64_t overflow_items;  /* candidate entries that did not fit their slot row (handled by the fallback kernel) */
     uint32_t compare_launches; /* guide batches */
     int prefix_bases, prefix_radius, suffix_radius;
 } ffh_timings;
