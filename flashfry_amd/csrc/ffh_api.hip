@@ -205,7 +205,7 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
 
 // targets/positions are already on the device in ctx->targets / ctx->positions
 static int prepare_database(ffh_ctx *ctx) {
-    if (ctx->T >= (1ull << 32) - 64) { ctx->err = "more than 2^32 targets in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
+    if (ctx->T >= (1ull << 31) - 64) { ctx->err = "more than 2^31 targets in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
     FFH_HIP(hipEventRecord(ctx->ev[0], ctx->st));
     // counts -> position offsets; validate counts like BlockManager.scala:232-236
     FFH_HIP(ctx->out_cnt.reserve(ctx->T + 1));
@@ -497,7 +497,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ca.slots = ctx->slots.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
         ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
         ca.r1 = plan.r1; ca.hits = ctx->hits.p; ca.cursor = ctx->d_counters; ca.cap = (uint64_t)ctx->hits.cap;
-        hipLaunchKernelGGL(k_compare, dim3(256 * 8), dim3(kCmpThreads), 0, st, ca);
+        if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(256 * 8), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
+        else hipLaunchKernelGGL(k_compare<true>, dim3(256 * 8), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
         // candidate entries that overflowed their slot row (rare): one wave each
@@ -534,6 +535,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
         ctx->tm.overflow_items += cnt[4];
         ctx->tm.compare_launches++;
+        // image positions -> database indices
+        if (cursor > cursor_before)
+            hipLaunchKernelGGL(k_resolve_hits, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,
+                               (uint64_t)(cursor - cursor_before), ctx->img[0].tidx.p, ctx->img[1].tidx.p);
         // candidate lists carry batch-local guide ids: make this batch's hits global
         if (g0 && cursor > cursor_before)
             hipLaunchKernelGGL(k_add_u64, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
     for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) ifill[(d << ig.low_bits) + l] = cnt[l];
 }
 
-constexpr int kTileTargets = 64;  // one target per lane
+constexpr int kTileTargets = 256;  // targets per work item (a bucket, or a 256-target slice of a large bucket)
+constexpr int kTileChunks = kTileTargets / 64;
 
 __global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, uint32_t n_buckets,
                              uint32_t *__restrict__ tcount) {
@@ -193,8 +194,8 @@ __global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t
     tcount[b] = ifill[b] ? (nt + kTileTargets - 1) / kTileTargets : 0;
 }
 
-// tile = {first key, #keys | side << 31, first slot, #slots used}; tiles of both images share one list so that
-// ONE compare launch covers the prefix and the suffix pass
+// work item ("tile") = {first key, #keys | side << 31, first slot, #slots used}; the items of both images share one
+// list so that ONE compare launch covers the prefix and the suffix pass
 __global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, const uint32_t *__restrict__ tstart,
                             uint32_t n_buckets, uint32_t cap, uint32_t slot_base, const uint32_t *__restrict__ tile_base, uint32_t side,
                             uint4 *__restrict__ tiles) {
@@ -211,18 +212,26 @@ __global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// THE HOT KERNEL.  One wave owns one tile at a time: <= 64 bucket-mates (one target per lane, streamed coalesced
-// from the scan image) against that bucket's candidate guides.  The candidates are fetched 64 at a time with ONE
-// coalesced load of the slot row + one gather of the planar guide keys (L2-resident table), then broadcast lane by
-// lane with v_readlane, so the inner loop touches no memory: per (guide, target) 2 x v_readlane, 2 x v_xor, v_or,
-// v_bcnt, v_cmp.  The next tile's descriptor, keys and slot row are requested before the current tile is
-// processed.  Hits are compacted with ballot + mbcnt into a per-wave LDS staging buffer and flushed with ONE
-// global atomic per ~200 hits (a single global cursor saturates far below the hit rate).
-//   Suffix-image tiles: the same pair can only also be found through the prefix image when its prefix part has
-//   <= r1 mismatches, so it is emitted from a suffix tile only if the prefix part has MORE than r1.
+// THE HOT KERNEL.  One wave owns one work item at a time: <= 256 targets of one bucket (streamed coalesced from the
+// scan image) against that bucket's candidate guides.  The kernel is latency-, not bandwidth-bound unless every
+// load is issued a whole item ahead (HBM round trips under load are ~10x the compute of one item), hence the
+// three-deep software pipeline:
+//      item i+3: descriptor (scalar load)           item i+2: slot row = candidate guide ids (one coalesced load)
+//      item i+1: planar guide keys (gather from the L2-resident table) + all target keys (<= 4 coalesced loads)
+//      item i  : computed entirely out of the wave's LDS strip -- no global access in the loops at all.
+//   * candidates are read back as LDS broadcasts: 4 VALU per (guide, 64 targets): v_xor, v_bitop3 (xor|or), v_bcnt,
+//     v_cmp -- no readlane, no memory wait;
+//   * short chunks (the <= 32 / 16 / 8 target tail of a bucket) are replicated 2 / 4 / 8 times across the wave and
+//     tested against 2 / 4 / 8 different guides per step, so the tail does not waste the lanes;
+//   * a hit is recorded as (guide, side, position in the image); the database index is looked up afterwards by
+//     k_resolve_hits, so the hot loop never waits on memory even when it hits;
+//   * hits are compacted with ballot + mbcnt into a per-wave LDS staging buffer and flushed with ONE global atomic
+//     per ~200 hits (a single global cursor saturates far below the hit rate).
+//   Suffix-image items: the same pair can only also be found through the prefix image when its prefix part has
+//   <= r1 mismatches, so it is emitted from a suffix item only if the prefix part has MORE than r1.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCmpThreads = 256;
-constexpr int kStage = 256;  // staged hits per wave
+constexpr int kStage = 192;  // staged hits per wave
 
 struct CompareArgs {
     const uint4 *tiles;
@@ -260,16 +269,81 @@ struct HitStage {
         __builtin_amdgcn_wave_barrier();
         fill = 0;
     }
-    // wave-uniform call: `mask` = ballot of the lanes that hit guide `gid`
-    __device__ __forceinline__ void push(uint64_t mask, bool hit, uint32_t gid, uint32_t ti) {
-        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid << 32) | ti;
+    // wave-uniform call: `mask` = ballot of the lanes that hit; every hitting lane brings its own (guide, position)
+    __device__ __forceinline__ void push(uint64_t mask, bool hit, uint32_t gid, uint32_t pos) {
+        if (fill > kStage - 64) flush();  // room for one more wave-wide batch
+        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid << 32) | pos;
         fill += (uint32_t)__popcll(mask);
-        if (fill > kStage - 64) flush();
     }
 };
 
-__global__ __launch_bounds__(kCmpThreads) void k_compare(const CompareArgs a) {
+struct WaveCtx {  // per-wave state shared by the chunk loops
+    const CompareArgs *a;
+    HitStage *hs;
+    const uint64_t *key_lds;  // the item's target keys
+    const uint64_t *gk_lds;   // 64 candidate keys (sentinel beyond n)
+    const uint32_t *gid_lds;  // 64 candidate guide ids
+    uint32_t lane;
+    uint32_t side_bit;         // side << 31, or'ed into the recorded position
+    bool suffix;
+};
+
+// one 64-lane step against W guides at once; `cnt` <= 64 / W targets, key_lds[koff ..], image position pos0 + ..
+// CHECK: max_mm is too large for the sentinel to be safe, test the candidate index explicitly
+template <int W, bool CHECK>
+__device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint32_t pos0, uint32_t cnt, uint32_t n) {
+    constexpr uint32_t SUB = 64 / W;
+    const uint32_t tl = w.lane & (SUB - 1), gs = w.lane / SUB;
+    const bool valid = tl < cnt;
+    const uint64_t k = w.key_lds[koff + tl];
+    const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
+    const uint64_t valid_mask = __ballot(valid);
+    const int max_mm = w.a->max_mm;
+    const uint32_t iters = (n + W - 1) / W;
+    auto test = [&](uint32_t idx, uint32_t &y) -> uint64_t {
+        const uint64_t g = w.gk_lds[idx];
+        y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
+        uint64_t m = __builtin_amdgcn_ballot_w64(__popc(y) <= max_mm) & valid_mask;
+        if (CHECK) m &= __builtin_amdgcn_ballot_w64(idx < n);
+        return m;
+    };
+    auto report = [&](uint64_t m, uint32_t y, uint32_t idx) {
+        if (w.suffix) m &= __builtin_amdgcn_ballot_w64(__popc(y & w.a->prefix_mask) > w.a->r1);
+        if (m) {
+            const bool hit = (m >> w.lane) & 1ull;
+            w.hs->push(m, hit, hit ? w.gid_lds[idx] : 0u, (pos0 + tl) | w.side_bit);
+        }
+    };
+    uint32_t j = 0;
+    for (; j + 4 <= iters; j += 4) {
+        uint32_t y0, y1, y2, y3;
+        const uint32_t i0 = j * W + gs, i1 = i0 + W, i2 = i0 + 2 * W, i3 = i0 + 3 * W;
+        const uint64_t m0 = test(i0, y0), m1 = test(i1, y1), m2 = test(i2, y2), m3 = test(i3, y3);
+        if (m0 | m1 | m2 | m3) {
+            if (m0) report(m0, y0, i0);
+            if (m1) report(m1, y1, i1);
+            if (m2) report(m2, y2, i2);
+            if (m3) report(m3, y3, i3);
+        }
+    }
+    for (; j < iters; ++j) {
+        uint32_t y;
+        const uint32_t i0 = j * W + gs;
+        const uint64_t m = test(i0, y);
+        if (m) report(m, y, i0);
+    }
+}
+
+// the read-only streams are separate __restrict__ kernel parameters (noalias lets the compiler keep the descriptor
+// loads on the scalar unit and reorder the vector loads around the hit stores)
+template <bool CHECK>
+__global__ __launch_bounds__(kCmpThreads) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
+                                                         const uint64_t *__restrict__ keys_s, const uint32_t *__restrict__ slots,
+                                                         const uint64_t *__restrict__ gkey, const CompareArgs a) {
     __shared__ uint64_t stage[kCmpThreads / 64][kStage];
+    __shared__ uint64_t key_lds[kCmpThreads / 64][kTileTargets];
+    __shared__ uint64_t gk_lds[kCmpThreads / 64][64];
+    __shared__ uint32_t gid_lds[kCmpThreads / 64][64];
     __shared__ unsigned long long blk_pairs[2];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -279,78 +353,82 @@ __global__ __launch_bounds__(kCmpThreads) void k_compare(const CompareArgs a) {
     __syncthreads();
     HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap};
     unsigned long long pairs[2] = {0, 0};
+    // all-ones planes differ from every real key in the 12 unused high bits of each plane: safe while max_mm < 12
+    const uint64_t sentinel = ~0ull;
+    WaveCtx w{&a, &hs, key_lds[wave], gk_lds[wave], gid_lds[wave], lane, 0u, false};
 
     uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave;
-    // software pipeline: `nxt*` always holds the loads of the tile that will be processed next
-    uint4 tile = make_uint4(0, 0, 0, 0);
-    uint64_t nk = 0;
-    uint32_t nti = 0, ngid = 0;
-    if (t < n_tiles) {
-        tile = a.tiles[t];
-        const uint32_t side = tile.y >> 31, cnt = tile.y & 0x7FFFFFFFu;
-        if (lane < cnt) { nk = a.keys[side][tile.x + lane]; nti = a.tidx[side][tile.x + lane]; }
-        if (lane < tile.w) ngid = a.slots[tile.z + lane];
-    }
-    while (t < n_tiles) {
-        const uint4 cur = tile;
-        const uint64_t k = nk;
-        const uint32_t ti = nti;
-        uint32_t gid = ngid;
-        const bool suffix = (cur.y >> 31) != 0;  // wave-uniform
-        const uint32_t cnt = cur.y & 0x7FFFFFFFu, ng = cur.w;
-        const bool valid = lane < cnt;
-        // guide keys of the first 64 candidates (gather from the L2-resident table)
-        uint64_t gk = (lane < ng) ? a.gkey[gid] : 0;
-        // request the next tile before computing
-        const uint32_t tn = t + n_waves;
-        if (tn < n_tiles) {
-            tile = a.tiles[tn];
-            const uint32_t side = tile.y >> 31, c2 = tile.y & 0x7FFFFFFFu;
-            nk = 0; nti = 0; ngid = 0;
-            if (lane < c2) { nk = a.keys[side][tile.x + lane]; nti = a.tidx[side][tile.x + lane]; }
-            if (lane < tile.w) ngid = a.slots[tile.z + lane];
-        }
-        pairs[suffix ? 1 : 0] += (unsigned long long)cnt * ng;
-        const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
-        const uint64_t valid_mask = __ballot(valid);
-        // one candidate guide against the 64 lanes; `m` = lanes within max_mm (suffix tiles: and not reachable via the prefix image)
-        auto test = [&](uint32_t gh, uint32_t gl, uint32_t &y) -> uint64_t {
-            y = (kh ^ gh) | (kl ^ gl);
-            return __builtin_amdgcn_ballot_w64(__popc(y) <= a.max_mm) & valid_mask;
+    if (t >= n_tiles) goto done;
+    {
+        // every load below is unconditional with a clamped index (straight-line code lets the compiler count
+        // outstanding loads exactly instead of draining the queue)
+        // descriptors past the end are replaced by the last one (its loads are harmless and never consumed)
+        auto load_desc = [&](uint32_t ti) -> uint4 { return tiles[min(ti, n_tiles - 1)]; };
+        auto load_gid = [&](const uint4 &d) -> uint32_t { return slots[d.z + min(lane, max(d.w, 1u) - 1u)]; };
+        auto load_key = [&](const uint4 &d, uint32_t c) -> uint64_t {
+            const uint32_t kc = d.y & 0x7FFFFFFFu;
+            const uint64_t *__restrict__ kp = (d.y >> 31) ? keys_s : keys_p;
+            return kp[d.x + min(c * 64u + lane, max(kc, 1u) - 1u)];
         };
-        auto report = [&](uint64_t m, uint32_t y, uint32_t j) {
-            if (suffix) m &= __builtin_amdgcn_ballot_w64(__popc(y & a.prefix_mask) > a.r1);
-            if (m) hs.push(m, (m >> lane) & 1ull, __builtin_amdgcn_readlane(gid, j), ti);
-        };
-        for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
-            if (g0) {  // rows longer than 64 candidates: fetch the next 64
-                gid = (g0 + lane < ng) ? a.slots[cur.z + g0 + lane] : 0;
-                gk = (g0 + lane < ng) ? a.gkey[gid] : 0;
-            }
-            const uint32_t gh_v = (uint32_t)(gk >> 32), gl_v = (uint32_t)gk;
-            const uint32_t n = min(ng - g0, 64u), n4 = n & ~3u;
-            uint32_t j = 0;
-            for (; j < n4; j += 4) {
-                uint32_t y0, y1, y2, y3;
-                const uint64_t m0 = test(__builtin_amdgcn_readlane(gh_v, j), __builtin_amdgcn_readlane(gl_v, j), y0);
-                const uint64_t m1 = test(__builtin_amdgcn_readlane(gh_v, j + 1), __builtin_amdgcn_readlane(gl_v, j + 1), y1);
-                const uint64_t m2 = test(__builtin_amdgcn_readlane(gh_v, j + 2), __builtin_amdgcn_readlane(gl_v, j + 2), y2);
-                const uint64_t m3 = test(__builtin_amdgcn_readlane(gh_v, j + 3), __builtin_amdgcn_readlane(gl_v, j + 3), y3);
-                if (m0 | m1 | m2 | m3) {
-                    if (m0) report(m0, y0, j);
-                    if (m1) report(m1, y1, j + 1);
-                    if (m2) report(m2, y2, j + 2);
-                    if (m3) report(m3, y3, j + 3);
+        // prologue
+        uint4 d0 = load_desc(t), d1 = load_desc(t + n_waves), d2 = load_desc(t + 2 * n_waves);
+        uint32_t gid0 = load_gid(d0), gid1 = load_gid(d1);
+        uint64_t gk0 = gkey[gid0];
+        uint64_t k0[kTileChunks];
+#pragma unroll
+        for (int c = 0; c < kTileChunks; ++c) k0[c] = load_key(d0, c);
+
+        while (t < n_tiles) {
+            const uint4 cur = d0;
+            const uint32_t side = cur.y >> 31;  // wave-uniform
+            const uint32_t kcnt = cur.y & 0x7FFFFFFFu, ng = cur.w;
+            // ---- stage A: park item i in the LDS strip (waits for everything requested one item ago) ----
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gk_lds[wave][lane] = (lane < ng) ? gk0 : sentinel;
+            gid_lds[wave][lane] = gid0;
+#pragma unroll
+            for (int c = 0; c < kTileChunks; ++c) key_lds[wave][c * 64 + lane] = k0[c];
+            // ---- stage B: request item i+1 (guide keys, target keys), i+2 (slot row), i+3 (descriptor) ----
+            const uint4 d3 = load_desc(t + 3 * n_waves);
+            const uint32_t gid2 = load_gid(d2);
+            gk0 = gkey[gid1];
+#pragma unroll
+            for (int c = 0; c < kTileChunks; ++c) k0[c] = load_key(d1, c);
+            gid0 = gid1; gid1 = gid2;
+            d0 = d1; d1 = d2; d2 = d3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- stage C: compute item i out of LDS ----
+            w.suffix = side != 0;
+            w.side_bit = side << 31;
+            pairs[side] += (unsigned long long)kcnt * ng;
+            for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+                if (g0) {  // rows longer than 64 candidates (rare): fetch the next 64 in place
+                    const uint32_t gi = slots[cur.z + min(g0 + lane, ng - 1)];
+                    const uint64_t gk = gkey[gi];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    gk_lds[wave][lane] = (g0 + lane < ng) ? gk : sentinel;
+                    gid_lds[wave][lane] = gi;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const uint32_t n = min(ng - g0, 64u);
+                for (uint32_t c = 0; c < kcnt; c += 64) {
+                    const uint32_t cnt = min(kcnt - c, 64u);
+                    if (cnt > 32) scan_chunk<1, CHECK>(w, c, cur.x + c, cnt, n);
+                    else if (cnt > 16) scan_chunk<2, CHECK>(w, c, cur.x + c, cnt, n);
+                    else if (cnt > 8) scan_chunk<4, CHECK>(w, c, cur.x + c, cnt, n);
+                    else scan_chunk<8, CHECK>(w, c, cur.x + c, cnt, n);
                 }
             }
-            for (; j < n; ++j) {
-                uint32_t y;
-                const uint64_t m = test(__builtin_amdgcn_readlane(gh_v, j), __builtin_amdgcn_readlane(gl_v, j), y);
-                if (m) report(m, y, j);
-            }
+            t += n_waves;
         }
-        t = tn;
     }
+done:
     if (hs.fill) hs.flush();
     if (lane == 0) {
         if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);
@@ -379,12 +457,13 @@ __global__ __launch_bounds__(64) void k_compare_overflow(const uint64_t *__restr
         for (uint32_t c = 0; c < kn; c += 64) {
             const bool valid = c + lane < kn;
             const uint64_t k = valid ? a.keys[side][k0 + c + lane] : 0;
-            const uint32_t ti = valid ? a.tidx[side][k0 + c + lane] : 0;
             const uint32_t y = ((uint32_t)(k >> 32) ^ (uint32_t)(g >> 32)) | ((uint32_t)k ^ (uint32_t)g);
             bool hit = valid && (__popc(y) <= a.max_mm);
             if (side) hit = hit && (__popc(y & a.prefix_mask) > a.r1);
             const uint64_t mask = __ballot(hit);
-            if (mask) hs.push(mask, hit, gid, ti);
+            if (mask) {
+                hs.push(mask, hit, gid, (k0 + c + lane) | (side << 31));
+            }
         }
     }
     if (hs.fill) hs.flush();
@@ -392,6 +471,17 @@ __global__ __launch_bounds__(64) void k_compare_overflow(const uint64_t *__restr
         if (pairs[0]) atomicAdd(a.cursor + 1, pairs[0]);
         if (pairs[1]) atomicAdd(a.cursor + 2, pairs[1]);
     }
+}
+
+// hit records leave the compare kernels as (guide << 32) | side << 31 | position in that side's scan image;
+// replace the low word by the database index of the target
+__global__ void k_resolve_hits(uint64_t *__restrict__ hits, uint64_t n, const uint32_t *__restrict__ tidx_p, const uint32_t *__restrict__ tidx_s) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = hits[i];
+    const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
+    const uint32_t ti = (lo >> 31) ? tidx_s[pos] : tidx_p[pos];
+    hits[i] = (h & 0xFFFFFFFF00000000ull) | ti;
 }
 
 __global__ void k_add_u64(uint64_t *__restrict__ v, uint64_t n, uint64_t add) {
