@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -88,6 +89,7 @@ struct ffh_ctx {
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
     double db_prepare_ms = 0;
     int plan_a = -1, plan_r1 = -1;
+    unsigned compare_grid = 256 * 8 * 8;
 
     // scan state
     DevBuf<uint64_t> guides;
@@ -325,6 +327,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     ctx->device = device_id;
     ctx->enzyme = enzyme_index;
     ctx->geo = Geometry{G[enzyme_index].c0, G[enzyme_index].lc, G[enzyme_index].scan, G[enzyme_index].cas9_23};
+    if (const char *e = std::getenv("FFH_COMPARE_GRID")) { const long v = std::atol(e); if (v > 0) ctx->compare_grid = (unsigned)v; }
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
@@ -497,8 +500,11 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ca.slots = ctx->slots.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
         ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
         ca.r1 = plan.r1; ca.hits = ctx->hits.p; ca.cursor = ctx->d_counters; ca.cap = (uint64_t)ctx->hits.cap;
-        if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(256 * 8), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
-        else hipLaunchKernelGGL(k_compare<true>, dim3(256 * 8), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
+        // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
+        // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
+        const unsigned cmp_grid = ctx->compare_grid;
+        if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
+        else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
         // candidate entries that overflowed their slot row (rare): one wave each
