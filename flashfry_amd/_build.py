@@ -43,5 +43,27 @@ def build_hip_library(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(ROOT, "flashfry_amd", "host")
+BIN_DIR = os.path.join(ROOT, "flashfry_amd", "bin")
+CLI = os.path.join(BIN_DIR, "flashfry-hip")
+HOST_SOURCES = ["ffhost_core.cpp", "ffhost_table.cpp", "ffhost_index.cpp", "ffhost_cli.cpp"]
+
+
+def build_cli(force=False, verbose=False):
+    """the C++ host CLI (index / discover / score) on top of the C ABI; links libflashfry_hip.so by rpath"""
+    build_hip_library(force=False, verbose=verbose)
+    os.makedirs(BIN_DIR, exist_ok=True)
+    deps = [os.path.join(HOST, f) for f in HOST_SOURCES + ["ffhost.hpp"]] + [LIB, os.path.join(ROOT, "include", "flashfry_hip.h")]
+    if not force and not stale(CLI, deps):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-o", CLI] + [os.path.join(HOST, f) for f in HOST_SOURCES]
+    cmd += ["-L" + LIB_DIR, "-lflashfry_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + LIB_DIR, "-lz", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
+    print(build_cli(force=True, verbose=True))
     print(build_hip_library(force=True, verbose=True))

@@ -18,8 +18,8 @@ FINALIZE_SUMMARIES_ONLY = 1
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
-    "ffh_db_load_soa", "ffh_db_open", "ffh_db_info_get", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
-    "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
+    "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
@@ -89,6 +89,9 @@ def load_library(build=True):
     L.ffh_db_load_blocks.argtypes = [C.c_void_p, i64p, u64p, C.c_uint32]
     L.ffh_db_load_soa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
     L.ffh_db_open.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+    L.ffh_db_open_header.argtypes = [C.c_void_p, C.c_char_p]
+    L.ffh_db_bin_bytes.restype = C.c_uint64
+    L.ffh_db_bin_bytes.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_db_info_get.argtypes = [C.c_void_p, C.POINTER(DbInfo)]
     L.ffh_db_contig.restype = C.c_char_p
     L.ffh_db_contig.argtypes = [C.c_void_p, C.c_uint32]
@@ -97,6 +100,7 @@ def load_library(build=True):
     L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
     L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_discover.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.ffh_score_lists.argtypes = [C.c_void_p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_void_p)]
     L.ffh_result_n_guides.restype = C.c_uint32
     L.ffh_result_n_guides.argtypes = [C.c_void_p]
     L.ffh_result_n_hits.restype = C.c_uint64
@@ -208,6 +212,12 @@ class Context:
     def open(self, path, bin_begin=0, bin_end=0):
         self._check(self.L.ffh_db_open(self.h, path.encode(), bin_begin, bin_end))
 
+    def open_header(self, path):
+        self._check(self.L.ffh_db_open_header(self.h, path.encode()))
+
+    def bin_bytes(self, n_bins):
+        return np.array([self.L.ffh_db_bin_bytes(self.h, b) for b in range(n_bins)], dtype=np.uint64)
+
     def info(self):
         i = DbInfo()
         self._check(self.L.ffh_db_info_get(self.h, C.byref(i)))
@@ -249,6 +259,16 @@ class Context:
     def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False):
         self.scan(guides, max_mismatch)
         return self.finalize(max_offtargets, None, summaries_only)
+
+    def score_lists(self, guides, guide_offsets, hit_targets):
+        """the `score` path: score caller-supplied hit lists (CSR) on the device"""
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        o = np.ascontiguousarray(guide_offsets, dtype=np.uint64)
+        t = np.ascontiguousarray(hit_targets).view(np.uint64)
+        assert len(o) == len(g) + 1
+        out = C.c_void_p()
+        self._check(self.L.ffh_score_lists(self.h, g.ctypes.data_as(u64p), len(g), o.ctypes.data_as(u64p), t.ctypes.data_as(u64p), C.byref(out)))
+        return Result(self.L, out.value)
 
     def timings(self):
         t = Timings()

@@ -86,6 +86,7 @@ struct ffh_ctx {
     DevBuf<uint64_t> targets, positions, pos_off;
     Image img[2];  // 0 prefix, 1 suffix
     std::vector<std::string> contigs;
+    std::vector<uint64_t> bin_bytes;
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
     double db_prepare_ms = 0;
     int plan_a = -1, plan_r1 = -1;
@@ -308,7 +309,7 @@ int ffh_device_count(void) {
 
 const char *ffh_last_error(const ffh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-ffh_ctx *ffh_create(int device_id, int enzyme_index) {
+static bool set_enzyme(ffh_ctx *ctx, int enzyme_index) {
     static const struct { int c0, lc, scan, cas9_23; } G[7] = {
         {0, 0, 0, 0},
         {0, 20, 24, 0},  // 1 Cpf1: comparisonBitEncoding 0x00FFFFFFFFFF, StandardScanParameters.scala:205
@@ -318,15 +319,21 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
         {3, 19, 22, 0},  // 5 19-mer 0x0FFFFFFFFFC0 :121
         {3, 19, 22, 0},  // 6 NGG 19-mer :165
     };
-    if (enzyme_index < 1 || enzyme_index > 6) { g_create_error = "Unable to find the correct parameter pack for enzyme: " + std::to_string(enzyme_index); return nullptr; }
+    if (enzyme_index < 1 || enzyme_index > 6) return false;
+    ctx->enzyme = enzyme_index;
+    ctx->geo = Geometry{G[enzyme_index].c0, G[enzyme_index].lc, G[enzyme_index].scan, G[enzyme_index].cas9_23};
+    return true;
+}
+
+ffh_ctx *ffh_create(int device_id, int enzyme_index) {
+    if (enzyme_index < 0 || enzyme_index > 6) { g_create_error = "Unable to find the correct parameter pack for enzyme: " + std::to_string(enzyme_index); return nullptr; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device available (flashfry_hip has no CPU fallback)"; return nullptr; }
     if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return nullptr; }
     ffh_ctx *ctx = new (std::nothrow) ffh_ctx();
     if (!ctx) { g_create_error = "out of memory"; return nullptr; }
     ctx->device = device_id;
-    ctx->enzyme = enzyme_index;
-    ctx->geo = Geometry{G[enzyme_index].c0, G[enzyme_index].lc, G[enzyme_index].scan, G[enzyme_index].cas9_23};
+    if (enzyme_index) set_enzyme(ctx, enzyme_index);  // 0: taken from the database header by ffh_db_open / ffh_db_open_header
     if (const char *e = std::getenv("FFH_COMPARE_GRID")) { const long v = std::atol(e); if (v > 0) ctx->compare_grid = (unsigned)v; }
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
@@ -386,6 +393,7 @@ int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius) {
 
 int ffh_db_load_soa(ffh_ctx *ctx, const uint64_t *targets, uint64_t n_targets, const uint64_t *positions, uint64_t n_positions, int on_device) {
     if (!ctx || (n_targets && !targets) || (n_positions && !positions)) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    if (ctx->enzyme == 0) { ctx->err = "the context has no enzyme yet: create it with an enzyme index or open a database file"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
     if (on_device) FFH_HIP(hipDeviceSynchronize());  // the producer (e.g. torch) used another stream
     ctx->T = n_targets;
@@ -413,6 +421,7 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
     DbHeader h;
     std::string e = read_db_header(std::string(db_path) + ".header", h);
     if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
+    if (ctx->enzyme == 0) set_enzyme(ctx, h.enzyme_index);
     if (h.enzyme_index != ctx->enzyme) {
         // the context was created for another enzyme than the one recorded in the header (BinaryHeader.scala:127)
         ctx->err = "database enzyme index " + std::to_string(h.enzyme_index) + " differs from the context's " + std::to_string(ctx->enzyme);
@@ -424,10 +433,26 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
     e = read_db_bins(db_path, h, bin_begin, bin_end, longs, offs);
     if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
     ctx->contigs = h.contigs;
+    ctx->bin_bytes = h.uncompressed_bytes;
     int rc = ffh_db_load_blocks(ctx, longs.data(), offs.data(), bin_end - bin_begin);
     ctx->n_bins = h.n_bins; ctx->bin_begin = bin_begin; ctx->bin_end = bin_end;
     return rc;
 }
+
+int ffh_db_open_header(ffh_ctx *ctx, const char *db_path) {
+    if (!ctx || !db_path) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    DbHeader h;
+    const std::string e = read_db_header(std::string(db_path) + ".header", h);
+    if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
+    if (ctx->enzyme == 0) set_enzyme(ctx, h.enzyme_index);
+    if (h.enzyme_index != ctx->enzyme) { ctx->err = "database enzyme index differs from the context's"; return FFH_E_ARG; }
+    ctx->contigs = h.contigs;
+    ctx->bin_bytes = h.uncompressed_bytes;
+    ctx->n_bins = h.n_bins;
+    return FFH_OK;
+}
+
+uint64_t ffh_db_bin_bytes(const ffh_ctx *ctx, uint32_t bin) { return (ctx && bin < ctx->bin_bytes.size()) ? ctx->bin_bytes[bin] : 0; }
 
 int ffh_db_info_get(const ffh_ctx *ctx, ffh_db_info *out) {
     if (!ctx || !out) return FFH_E_ARG;
@@ -683,6 +708,67 @@ int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int ma
     int rc = ffh_scan(ctx, guides, n_guides, max_mismatch);
     if (rc) return rc;
     return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
+}
+
+int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, const uint64_t *guide_offsets, const uint64_t *hit_targets, ffh_result **out) {
+    if (!ctx || !out || (n_guides && (!guides || !guide_offsets))) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    if (ctx->enzyme == 0) { ctx->err = "the context has no enzyme yet"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    const uint32_t G = n_guides;
+    const uint64_t H = G ? guide_offsets[G] : 0;
+    if (H && !hit_targets) { ctx->err = "bad argument"; return FFH_E_ARG; }
+    std::vector<uint32_t> hit_guide((size_t)H), n_ret(G), ot(G), full(G, 0u);
+    for (uint32_t g = 0; g < G; ++g) {
+        if (guide_offsets[g + 1] < guide_offsets[g] || guide_offsets[g + 1] > H) { ctx->err = "guide_offsets must be non-decreasing"; return FFH_E_ARG; }
+        uint64_t tot = 0;
+        for (uint64_t h = guide_offsets[g]; h < guide_offsets[g + 1]; ++h) { hit_guide[(size_t)h] = g; tot += hit_targets[h] >> 48; }
+        n_ret[g] = (uint32_t)(guide_offsets[g + 1] - guide_offsets[g]);
+        ot[g] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
+    }
+    ctx->scanned = false;  // the scratch arrays of a previous scan are reused below
+    FFH_HIP(ctx->guides.reserve((size_t)G + 1));
+    FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
+    FFH_HIP(ctx->ot_count.reserve((size_t)G + 1));
+    FFH_HIP(ctx->full.reserve((size_t)G + 1));
+    FFH_HIP(ctx->ret_off.reserve((size_t)G + 2));
+    FFH_HIP(ctx->summ.reserve((size_t)G + 1));
+    FFH_HIP(ctx->out_target.reserve(H + 1));
+    FFH_HIP(ctx->out_tidx.reserve(H + 1));
+    FFH_HIP(ctx->out_mm.reserve(H + 1));
+    FFH_HIP(ctx->out_cnt.reserve(H + 1));
+    FFH_HIP(ctx->out_cfd.reserve(H + 1));
+    FFH_HIP(ctx->out_hsu.reserve(H + 1));
+    if (G) {
+        FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)G * 8, hipMemcpyHostToDevice, st));
+        FFH_HIP(hipMemcpyAsync(ctx->n_ret.p, n_ret.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
+        FFH_HIP(hipMemcpyAsync(ctx->ot_count.p, ot.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
+        FFH_HIP(hipMemcpyAsync(ctx->full.p, full.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
+        FFH_HIP(hipMemcpyAsync(ctx->ret_off.p, guide_offsets, ((size_t)G + 1) * 8, hipMemcpyHostToDevice, st));
+    }
+    if (H) {
+        FFH_HIP(hipMemcpyAsync(ctx->out_target.p, hit_targets, H * 8, hipMemcpyHostToDevice, st));
+        FFH_HIP(hipMemcpyAsync(ctx->out_tidx.p, hit_guide.data(), H * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_score_list, dim3(blocks_for(H, 256)), dim3(256), 0, st, ctx->out_target.p, ctx->out_tidx.p, H, ctx->guides.p, ctx->geo, ctx->d_tab,
+                           ctx->out_mm.p, ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p);
+    }
+    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
+                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
+    FFH_HIP(hipGetLastError());
+    ffh_result *r = new (std::nothrow) ffh_result();
+    if (!r) { ctx->err = "out of memory"; return FFH_E_NOMEM; }
+    r->n_guides = G; r->n_hits = H; r->n_positions = 0; r->scores_valid = ctx->geo.cas9_23;
+    r->summaries.resize(G); r->guide_offsets.assign(guide_offsets, guide_offsets + (G ? G + 1 : 0));
+    if (!G) r->guide_offsets.assign(1, 0);
+    r->hit_targets.assign(hit_targets, hit_targets + H); r->hit_mm.resize(H); r->hit_cfd.resize(H); r->pos_offsets.assign(H + 1, 0);
+    hipError_t e = hipSuccess;
+    if (G) e = hipMemcpyAsync(r->summaries.data(), ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm.data(), ctx->out_mm.p, H, hipMemcpyDeviceToHost, st);
+    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd.data(), ctx->out_cfd.p, H * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
+    *out = r;
+    return FFH_OK;
 }
 
 int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out) {

@@ -527,34 +527,24 @@ __global__ void k_cutoff(const uint64_t *__restrict__ hits, const uint32_t *__re
     full[g] = run >= overflow;
 }
 
+
 struct ScoreTables {
     double cfd_mm[20 * 4 * 4];
     double cfd_pam[16];
     double hsu_coeff[20];
 };
 
-// per retained hit: target long, mismatches, position count, pam*CFD (Doench2016CFDScore.scala:67-73) and the
-// Hsu2013 hit score (CrisprMitEduOffTarget.scala:107-148); both NaN for a 0-mismatch hit (the on-target itself).
-__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, const uint32_t *__restrict__ seg_begin,
-                             const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ targets,
-                             const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
-                             uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
-                             double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_hits) return;
-    const uint32_t g = (uint32_t)(hits[i] >> 32), ti = (uint32_t)hits[i];
-    const uint32_t local = (uint32_t)i - seg_begin[g];
-    if (local >= n_ret[g]) return;
-    const uint64_t o = ret_off[g] + local;
-    const uint64_t t = targets[ti], gd = guides[g];
+// mismatches + pam*CFD (Doench2016CFDScore.scala:67-73,132-151) + Hsu2013 hit score (CrisprMitEduOffTarget.scala:107-148)
+// of one (guide, target) pair; both scores are NaN for a 0-mismatch hit (the on-target itself) and for enzymes the
+// models are not defined over.  The multiplications run in the reference's order (position 0..19, PAM last).
+__device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab, int &mm_out, double &cfd,
+                                           double &hsu) {
     const uint64_t pg = planar_key(gd, geo.c0, geo.lc), pt = planar_key(t, geo.c0, geo.lc);
     const uint32_t y = ((uint32_t)(pg >> 32) ^ (uint32_t)(pt >> 32)) | ((uint32_t)pg ^ (uint32_t)pt);
     const int mm = __popc(y);
-    out_target[o] = t;
-    out_mm[o] = (uint8_t)mm;
-    out_cnt[o] = (uint32_t)(t >> 48);
-    out_tidx[o] = ti;
-    double cfd = __builtin_nan(""), hsu = __builtin_nan("");
+    mm_out = mm;
+    cfd = __builtin_nan("");
+    hsu = __builtin_nan("");
     if (geo.cas9_23 && mm != 0) {
         // base i (0 = 5' end) of a 23-mer sits at bits [2(22-i)+1 : 2(22-i)]
         double score = 1.0, part_one = 1.0;
@@ -583,8 +573,46 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
         if (p22 == 2u) adj = p21 == 2u ? 1.0 : p21 == 0u ? 0.26 : p21 == 1u ? 0.11 : 0.01;
         hsu = total * adj;
     }
+}
+
+// per retained hit of a discover scan: target long, mismatches, position count, database index and the two scores
+__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, const uint32_t *__restrict__ seg_begin,
+                             const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ targets,
+                             const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
+                             uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
+                             double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hits) return;
+    const uint32_t g = (uint32_t)(hits[i] >> 32), ti = (uint32_t)hits[i];
+    const uint32_t local = (uint32_t)i - seg_begin[g];
+    if (local >= n_ret[g]) return;
+    const uint64_t o = ret_off[g] + local;
+    const uint64_t t = targets[ti];
+    int mm;
+    double cfd, hsu;
+    score_pair(guides[g], t, geo, tab, mm, cfd, hsu);
+    out_target[o] = t;
+    out_mm[o] = (uint8_t)mm;
+    out_cnt[o] = (uint32_t)(t >> 48);
+    out_tidx[o] = ti;
     out_cfd[o] = cfd;
     out_hsu[o] = hsu;
+}
+
+// the same for caller-supplied hit lists (the `score` path: hit lists re-read from a discover table)
+__global__ void k_score_list(const uint64_t *__restrict__ hit_targets, const uint32_t *__restrict__ hit_guide, uint64_t n_hits,
+                             const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint8_t *__restrict__ out_mm,
+                             uint32_t *__restrict__ out_cnt, double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hits) return;
+    const uint64_t t = hit_targets[i];
+    int mm;
+    double cfd, hsu;
+    score_pair(guides[hit_guide[i]], t, geo, tab, mm, cfd, hsu);
+    out_mm[i] = (uint8_t)mm;
+    out_cnt[i] = (uint32_t)(t >> 48);
+    out_cfd[i] = cfd;
+    out_hsu[i] = hsu;
 }
 
 struct GuideSummary {  // mirrors ffh_guide_summary

@@ -1,0 +1,218 @@
+// ffhost_cli.cpp -- `flashfry-hip index | discover | score`: the reference's CLI surface for the accelerated path
+// (Main.scala:51-57; options accept both -x and --x spellings like the picocli annotations of the reference).
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <numeric>
+
+#include "ffhost.hpp"
+
+namespace ffhost {
+
+// ---- tiny option parser ----------------------------------------------------------------------------------------
+struct Options {
+    std::map<std::string, std::string> kv;
+    bool has(const std::string &k) const { return kv.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d = "") const { auto it = kv.find(k); return it == kv.end() ? d : it->second; }
+    int num(const std::string &k, int d) const { return has(k) ? std::atoi(kv.at(k).c_str()) : d; }
+    double real(const std::string &k, double d) const { return has(k) ? std::atof(kv.at(k).c_str()) : d; }
+};
+
+static Options parse(int argc, char **argv, const std::vector<std::string> &flags, const std::vector<std::string> &valued) {
+    Options o;
+    for (int i = 0; i < argc; ++i) {
+        std::string a = argv[i];
+        while (!a.empty() && a[0] == '-') a.erase(0, 1);
+        std::string val;
+        const size_t eq = a.find('=');
+        if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+        if (std::find(flags.begin(), flags.end(), a) != flags.end()) { o.kv[a] = "1"; continue; }
+        if (std::find(valued.begin(), valued.end(), a) != valued.end()) {
+            if (eq == std::string::npos) {
+                if (i + 1 >= argc) throw Error("Missing value for option --" + a);
+                val = argv[++i];
+            }
+            o.kv[a] = val;
+            continue;
+        }
+        throw Error("Unknown option: " + std::string(argv[i]));
+    }
+    return o;
+}
+
+static void require(const Options &o, const std::vector<std::string> &keys) {
+    for (const auto &k : keys)
+        if (!o.has(k)) throw Error("Missing required option: --" + k);
+}
+
+// --gpus N = devices 0..N-1; --devices 0,1,1 names them explicitly (a device may appear twice: two bin shards on it)
+static std::vector<int> deviceList(const Options &o) {
+    std::vector<int> d;
+    if (o.has("devices")) {
+        const std::string s = o.str("devices");
+        for (size_t a = 0; a <= s.size();) {
+            size_t b = s.find(',', a);
+            if (b == std::string::npos) b = s.size();
+            if (b > a) d.push_back(std::atoi(s.substr(a, b - a).c_str()));
+            a = b + 1;
+        }
+    }
+    if (d.empty()) {
+        const int n = std::max(1, o.num("gpus", 1));
+        for (int i = 0; i < n; ++i) d.push_back(i);
+    }
+    return d;
+}
+
+// ---- index: modules/BuildOffTargetDatabase.scala:57-89 --------------------------------------------------------------
+int runIndex(int argc, char **argv) {
+    const Options o = parse(argc, argv, {}, {"reference", "database", "tmpLocation", "enzyme", "binSize"});
+    require(o, {"reference", "database"});  // --tmpLocation is accepted and ignored: the sites are sorted in memory
+    const ParameterPack &pack = ParameterPack::nameToParameterPack(o.str("enzyme", "spCas9ngg"));
+    buildOffTargetDatabase(o.str("reference"), o.str("database"), pack, o.num("binSize", 7));
+    return 0;
+}
+
+// ---- discover: modules/OffTargetDiscovery.scala:79-153 --------------------------------------------------------------
+int runDiscover(int argc, char **argv) {
+    const Options o = parse(argc, argv, {"positionOutput", "forceLinear"},
+                            {"fasta", "database", "output", "maxMismatch", "flankingSequence", "maximumOffTargets", "minGC", "maxGC", "gpus", "devices"});
+    require(o, {"fasta", "database", "output"});
+    const int maxMismatch = o.num("maxMismatch", 4), flank = o.num("flankingSequence", 6), maxOT = o.num("maximumOffTargets", 2000);
+    const double minGC = o.real("minGC", 0.0), maxGC = o.real("maxGC", 1.0);
+    if (!(minGC >= 0 && minGC <= 1.0) || !(maxGC >= 0 && maxGC <= 1.0)) throw Error("minGC / maxGC must be within [0, 1]");  // :81-82
+    const std::string db = o.str("database");
+    std::fprintf(stderr, "Reading the header....\n");
+    const HeaderInfo hdr = readHeaderInfo(db);  // :89
+    const ParameterPack &pack = ParameterPack::indexToParameterPack(hdr.enzymeIndex);
+    BitEncoding bitCoder(pack);
+    BitPosition posCoder;
+    for (const auto &c : hdr.contigs) posCoder.addReference(c);
+    const std::vector<CRISPRSite> sites = findTargetSites(o.str("fasta"), pack, flank);  // :93
+    std::fprintf(stderr, "Setting up the guide recording for our %zu candidate guides....\n", sites.size());
+    std::vector<CRISPRSiteOT> guides;
+    for (const auto &s : sites) {  // filter_by_GC :96 + new CRISPRSiteOT :100-102
+        const double gc = gcContent(s.bases);
+        if (!(gc >= minGC && gc <= maxGC)) continue;
+        CRISPRSiteOT g;
+        g.target = s;
+        g.longEncoding = bitCoder.bitEncodeString(s.bases, 1);
+        g.overflow = maxOT;
+        guides.push_back(std::move(g));
+    }
+    std::fprintf(stderr, "Filtered GC guide count %zu\n", guides.size());
+    // ResultsAggregator sorts the guides by start (ResultsAggregator.scala:35); ties keep input order here
+    std::stable_sort(guides.begin(), guides.end(), [](const CRISPRSiteOT &a, const CRISPRSiteOT &b) { return a.target.position < b.target.position; });
+    std::fprintf(stderr, "scanning against the known targets from the genome with %zu guides\n", guides.size());
+    const bool positions = o.has("positionOutput");
+    const ScanStats st = GpuTraverser::scan(db, guides, maxMismatch, maxOT, deviceList(o), positions);  // replaces :120-131
+    std::fprintf(stderr, "Performed a total of %llu guide to target comparisons (%llu targets resident on %d GPU(s); load %.1f ms, scan %.1f ms, finalize %.1f ms)\n",
+                 (unsigned long long)st.executedComparisons, (unsigned long long)st.targets, st.gpus, st.loadMs, st.scanMs, st.finalizeMs);
+    std::fprintf(stderr, "Writing final output for %zu guides\n", guides.size());
+    TabDelimitedOutput out(o.str("output"), bitCoder, posCoder, {}, true, positions);  // :141-146
+    for (auto &g : guides) {
+        for (auto &h : g.offTargets) h.hasCfd = false;  // discover writes no per-hit scores (scoring models = [])
+        out.write(g);
+    }
+    out.close();
+    return 0;
+}
+
+// ---- score: modules/ScoreResults.scala:90-154 -----------------------------------------------------------------------
+int runScore(int argc, char **argv) {
+    const Options o = parse(argc, argv, {"includeOTs", "numericOutput", "countOnTargetInScore"},
+                            {"input", "output", "scoringMetrics", "maxMismatch", "database", "inputAnnotationBed", "shortestGuideEnergy", "transformPositions",
+                             "maxReciprocalMismatch"});
+    require(o, {"input", "output", "scoringMetrics", "database"});
+    const HeaderInfo hdr = readHeaderInfo(o.str("database"));  // :91 (the database body is never opened)
+    const ParameterPack &pack = ParameterPack::indexToParameterPack(hdr.enzymeIndex);
+    BitEncoding bitEnc(pack);
+    BitPosition posEnc;
+    for (const auto &c : hdr.contigs) posEnc.addReference(c);
+    const int maxMismatch = o.has("maxMismatch") ? o.num("maxMismatch", 0) : 0x7FFFFFFF;
+    std::fprintf(stderr, "Loading CRISPR objects (filtering out overflow guides).. \n");
+    std::vector<CRISPRSiteOT> guides = readTabDelimited(o.str("input"), bitEnc, posEnc, maxMismatch, true);  // :95
+    std::vector<Metric> models;
+    {
+        std::string m = o.str("scoringMetrics");
+        size_t a = 0;
+        while (a <= m.size()) {
+            size_t b = m.find(',', a);
+            if (b == std::string::npos) b = m.size();
+            const std::string name = m.substr(a, b - a);
+            if (!name.empty()) {
+                const Metric mt = metricByName(name);
+                if (metricValidOverEnzyme(mt, pack)) models.push_back(mt);  // :111-118
+                else std::fprintf(stderr, "DROPPING SCORING METHOD: %s; it's not valid over enzyme parameter pack: %s\n", name.c_str(), pack.name);
+            }
+            a = b + 1;
+        }
+    }
+    // every hit-list model is computed by the same device epilogue as discover (no CPU scoring path)
+    std::vector<uint64_t> longs(guides.size()), offsets(guides.size() + 1, 0), hitTargets;
+    for (size_t g = 0; g < guides.size(); ++g) {
+        longs[g] = guides[g].longEncoding;
+        for (const auto &h : guides[g].offTargets) hitTargets.push_back(h.sequence);
+        offsets[g + 1] = hitTargets.size();
+    }
+    ffh_ctx *ctx = ffh_create(0, hdr.enzymeIndex);
+    if (!ctx) throw Error(ffh_last_error(nullptr));
+    ffh_result *res = nullptr;
+    if (ffh_score_lists(ctx, longs.data(), (uint32_t)guides.size(), offsets.data(), hitTargets.data(), &res)) {
+        const std::string e = ffh_last_error(ctx);
+        ffh_destroy(ctx);
+        throw Error(e);
+    }
+    const bool wantCfd = std::find(models.begin(), models.end(), Metric::Doench2016CFD) != models.end();
+    for (size_t g = 0; g < guides.size(); ++g) {
+        guides[g].summary = ffh_result_summaries(res)[g];
+        for (size_t k = 0; k < guides[g].offTargets.size(); ++k) {
+            const double c = ffh_result_hit_cfd(res)[offsets[g] + k];
+            guides[g].offTargets[k].hasCfd = wantCfd && c == c;  // Doench2016CFDScore attaches pam*cfd to every scored hit (:72)
+            guides[g].offTargets[k].cfd = c;
+        }
+    }
+    ffh_result_free(res);
+    ffh_destroy(ctx);
+    std::stable_sort(guides.begin(), guides.end(), [](const CRISPRSiteOT &a, const CRISPRSiteOT &b) { return a.target.position < b.target.position; });  // :137
+    TabDelimitedOutput out(o.str("output"), bitEnc, posEnc, models, o.has("includeOTs"), true, o.has("numericOutput"));  // :142-147
+    for (const auto &g : guides) out.write(g);
+    out.close();
+    return 0;
+}
+
+}  // namespace ffhost
+
+static void usage() {
+    std::fprintf(stderr,
+                 "flashfry-hip <index|discover|score> [options]   (MI355X build of FlashFry's discover/score path)\n"
+                 "  index    --reference FILE --database FILE [--enzyme spcas9ngg] [--binSize 7] [--tmpLocation DIR]\n"
+                 "  discover --database FILE --fasta FILE --output FILE [--positionOutput] [--maxMismatch 4] [--flankingSequence 6]\n"
+                 "           [--maximumOffTargets 2000] [--minGC 0] [--maxGC 1] [--forceLinear] [--gpus N]\n"
+                 "  score    --input FILE --output FILE --scoringMetrics hsu2013,doench2016cfd,minot,dangerous --database FILE\n"
+                 "           [--maxMismatch N] [--includeOTs] [--numericOutput]\n");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { usage(); return 2; }
+    const std::string cmd = argv[1];
+    const auto t0 = std::chrono::steady_clock::now();
+    try {
+        int rc;
+        if (cmd == "index") rc = ffhost::runIndex(argc - 2, argv + 2);
+        else if (cmd == "discover") rc = ffhost::runDiscover(argc - 2, argv + 2);
+        else if (cmd == "score") rc = ffhost::runScore(argc - 2, argv + 2);
+        else { usage(); return 2; }
+        std::fprintf(stderr, "Total runtime %.2f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());  // Main.scala:63
+        return rc;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "flashfry-hip %s: %s\n", cmd.c_str(), e.what());
+        return 1;
+    }
+}

@@ -58,6 +58,7 @@ int ffh_device_count(void);
 
 /* enzyme_index as stored in the database header: 1 Cpf1, 2 spCas9, 3 spCas9-NGG, 4 spCas9-NAG, 5 spCas9 19-mer,
  * 6 spCas9-NGG 19-mer (ParameterPack.indexToParameterPack, standards/StandardScanParameters.scala:61-69).
+ * enzyme_index 0 defers the choice to the header of the database opened later (BinaryHeader.scala:127).
  * Returns NULL on failure; ffh_last_error(NULL) then tells why. */
 ffh_ctx *ffh_create(int device_id, int enzyme_index);
 void ffh_destroy(ffh_ctx *ctx);
@@ -84,6 +85,12 @@ int ffh_db_load_soa(ffh_ctx *ctx, const uint64_t *targets, uint64_t n_targets, c
  * DatabaseWriter.scala:58-111).  Only bins [bin_begin, bin_end) are loaded: the static shard of this GPU.
  * bin_end == 0 means "to the last bin". */
 int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t bin_end);
+
+/* Header only (enzyme, bin table, contig names) -- what `score` needs (modules/ScoreResults.scala:91): no GPU memory
+ * is touched and nothing is scanned. */
+int ffh_db_open_header(ffh_ctx *ctx, const char *db_path);
+/* uncompressed payload bytes of a bin as recorded in the header (BlockOffset.uncompressedSize); used to balance shards */
+uint64_t ffh_db_bin_bytes(const ffh_ctx *ctx, uint32_t bin);
 
 typedef struct ffh_db_info {
     uint64_t n_targets;      /* unique target sequences resident (this shard) */
@@ -122,6 +129,13 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shar
 
 int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets,
                  unsigned flags, ffh_result **out);
+
+/* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
+ * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the
+ * lists are taken as they are (no cut-off, overflow = 0).  No database needs to be loaded.  The result carries
+ * summaries, mismatches and per-hit CFD; its position arrays are empty. */
+int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, const uint64_t *guide_offsets,
+                    const uint64_t *hit_targets, ffh_result **out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Results: guides in input order; per guide the retained hit list in database order, already cut off.
