@@ -1,0 +1,50 @@
+"""world_size-2/3 CPU tests (gloo) of the multi-GPU plumbing: shard bins, continue the ordered cut-off across ranks,
+reduce the per-guide aggregates."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,max_ot", [(2, 40), (3, 2000), (2, 0)])
+def test_sharded_discover_over_gloo(tmp_path, world, max_ot):
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, "5", str(max_ot)]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.load(open(out))
+    assert res["world"] == world
+    for k in ("ok_hits", "ok_totals", "ok_overflow", "ok_hist", "ok_closest"):
+        assert res[k], (k, res)
+    assert res["max_cfd_err"] <= 1e-9 and res["max_cfdmax_err"] == 0.0 and res["max_hsu_err"] <= 1e-9, res
+    if max_ot == 40:
+        assert 0 < res["n_overflowed"] < res["n_guides"] and res["crossing"] > 0  # the cut-off really crossed a shard boundary
+
+
+def test_shard_bins_balances_bytes():
+    from flashfry_amd import dist as ffdist
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(8, 10000, size=16384)
+    for world in (1, 2, 3, 8):
+        cuts = ffdist.shard_bins(sizes, world)
+        assert cuts[0][0] == 0 and cuts[-1][1] == 16384
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        loads = [sizes[a:b].sum() for a, b in cuts]
+        assert max(loads) - min(loads) <= 2 * sizes.max()
+    assert ffdist.shard_bins([0, 0, 0, 0], 2) == [(0, 0), (0, 4)] or len(ffdist.shard_bins([0, 0, 0, 0], 2)) == 2
