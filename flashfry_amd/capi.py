@@ -49,7 +49,7 @@ class Timings(C.Structure):
                 ("sort_ms", C.c_double), ("finalize_ms", C.c_double), ("total_scan_ms", C.c_double),
                 ("n_raw_hits", C.c_uint64), ("pairs_prefix", C.c_uint64), ("pairs_suffix", C.c_uint64),
                 ("items_prefix", C.c_uint64), ("items_suffix", C.c_uint64), ("tiles_prefix", C.c_uint64),
-                ("tiles_suffix", C.c_uint64), ("overflow_items", C.c_uint64), ("compare_launches", C.c_uint32), ("prefix_bases", C.c_int),
+                ("tiles_suffix", C.c_uint64), ("compare_launches", C.c_uint32), ("prefix_bases", C.c_int),
                 ("prefix_radius", C.c_int), ("suffix_radius", C.c_int)]
 
     def as_dict(self):

@@ -101,13 +101,13 @@ struct ffh_ctx {
     uint64_t *hits_sorted = nullptr;
     uint64_t n_raw = 0;
     DevBuf<uint32_t> seg_begin, seg_end;
-    unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] overflow-list cursor
+    unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] load-time check counter
 
     // per-pass scratch
     DevBuf<uint64_t> gkey;                                  // planar guide keys of the current batch (L2-resident)
-    DevBuf<uint32_t> gbucket[2], patterns[2], tstart[2];
-    DevBuf<uint32_t> icount, ifill, tcount, slots, part_fill, part_items, scan_tmp32;
-    DevBuf<uint64_t> overflow, scan_tmp64;
+    DevBuf<uint32_t> gbucket[2], patterns[2], tstart[2], istart[2];
+    DevBuf<uint32_t> icount, ifill, tcount, item_gid, part_fill, part_start, part_items, scan_tmp32;
+    DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint4> tiles;
     DevBuf<uint32_t> sort_table, sort_offs;
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
@@ -243,53 +243,46 @@ static int prepare_database(ffh_ctx *ctx) {
     return FFH_OK;
 }
 
-// ---- candidate slot rows + tiles of one image (no host synchronisation: counts stay on the device) -----------
-static uint32_t slot_capacity(double mean) {  // Poisson tail: mean + 6 sigma + 8, rounded up to a power of two
-    double want = mean + 6.0 * std::sqrt(std::max(mean, 0.0)) + 8.0;
-    uint32_t cap = 16;
-    while ((double)cap < want && cap < (1u << 20)) cap <<= 1;
-    return cap;
-}
-
-static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, uint32_t cap, uint32_t slot_base, const uint32_t *tile_base) {
+// ---- candidate lists (CSR) + work items of one image (no host synchronisation: counts stay on the device) ------
+static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, uint32_t item_base, const uint32_t *tile_base) {
     Image &im = ctx->img[which];
     const int width = im.width;
     const uint32_t nb = 1u << (2 * width);
     const std::vector<uint32_t> &pat = patterns_for(ctx, width, radius);
     const uint32_t np = (uint32_t)pat.size();
     hipStream_t st = ctx->st;
-    DevBuf<uint32_t> &patterns = ctx->patterns[which], &tstart = ctx->tstart[which], &gbucket = ctx->gbucket[which];
+    DevBuf<uint32_t> &patterns = ctx->patterns[which], &tstart = ctx->tstart[which], &gbucket = ctx->gbucket[which], &istart = ctx->istart[which];
     FFH_HIP(patterns.reserve(np));
     FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
     FFH_HIP(gbucket.reserve(ng));
-    FFH_HIP(ctx->ifill.reserve((size_t)nb + 1));
+    FFH_HIP(istart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->tcount.reserve((size_t)nb + 1));
     FFH_HIP(tstart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
     const uint64_t *gptr = ctx->guides.p + g0;
     if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p);
     else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p);
-    // two-step binning of the implicit (bucket, guide) entries into the slot rows (see ffh_kernels.hpp)
+    // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
     const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
     ig.n_guides = ng; ig.n_pat = np;
     const uint32_t part_bits = (uint32_t)std::min(kMaxPartBits, std::max(0, 2 * width - kMaxPartBits));
     ig.low_bits = 2u * (uint32_t)width - part_bits;
     ig.n_part = 1u << part_bits;
-    const double per_part = (double)n_enum / (double)ig.n_part;
-    ig.part_cap = (uint32_t)std::min<double>((double)n_enum + 64.0, per_part + 8.0 * std::sqrt(per_part) + 1024.0);
-    ig.cap = cap; ig.side = (uint32_t)which; ig.ovf_cap = (uint64_t)ctx->overflow.cap;
-    FFH_HIP(ctx->part_fill.reserve(ig.n_part));
-    FFH_HIP(ctx->part_items.reserve((size_t)ig.n_part * ig.part_cap));
-    FFH_HIP(hipMemsetAsync(ctx->part_fill.p, 0, (size_t)ig.n_part * 4, st));
-    hipLaunchKernelGGL(k_item_partition, dim3(blocks_for(n_enum, kPartItemsPerBlock)), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_fill.p,
-                       ctx->part_items.p, ctx->overflow.p, ctx->d_counters + 4);
-    hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_fill.p, ctx->part_items.p, ig, ctx->ifill.p, ctx->slots.p + slot_base,
-                       ctx->overflow.p, ctx->d_counters + 4);
-    hipLaunchKernelGGL(k_tile_count, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, ctx->ifill.p, nb, ctx->tcount.p);
+    ig.item_base = item_base;
+    FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
+    FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
+    FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
+    uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
+    FFH_HIP(hipMemsetAsync(ctx->part_fill.p, 0, ((size_t)2 * ig.n_part + 2) * 4, st));
+    const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
+    hipLaunchKernelGGL(k_item_partition<false>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
+    exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
+    hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
+    hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p);
+    hipLaunchKernelGGL(k_tile_count, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, nb, ctx->tcount.p);
     exclusive_scan<uint32_t, uint32_t>(ctx->tcount.p, nb, tstart.p, ctx->scan_tmp32.p, st);
-    hipLaunchKernelGGL(k_tile_fill, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, ctx->ifill.p, tstart.p, nb, cap, slot_base, tile_base, (uint32_t)which,
-                       ctx->tiles.p);
+    hipLaunchKernelGGL(k_tile_fill, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, tstart.p, nb, tile_base, (uint32_t)which, ctx->tiles.p);
     FFH_HIP(hipGetLastError());
     return FFH_OK;
 }
@@ -364,8 +357,8 @@ void ffh_destroy(ffh_ctx *ctx) {
     ctx->targets.release(); ctx->positions.release(); ctx->pos_off.release();
     for (auto &im : ctx->img) { im.bstart.release(); im.keys.release(); im.tidx.release(); }
     ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->seg_begin.release(); ctx->seg_end.release();
-    for (int w = 0; w < 2; ++w) { ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->tstart[w].release(); }
-    ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->slots.release(); ctx->overflow.release(); ctx->part_fill.release(); ctx->part_items.release();
+    for (int w = 0; w < 2; ++w) { ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->tstart[w].release(); ctx->istart[w].release(); }
+    ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->item_gid.release(); ctx->part_fill.release(); ctx->part_start.release(); ctx->part_items.release();
     ctx->tcount.release(); ctx->scan_tmp32.release(); ctx->scan_tmp64.release();
     ctx->tiles.release(); ctx->sort_table.release(); ctx->sort_offs.release();
     ctx->n_ret.release(); ctx->ot_count.release(); ctx->full.release(); ctx->prior.release(); ctx->out_cnt.release(); ctx->out_tidx.release(); ctx->totals.release();
@@ -484,15 +477,13 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     ctx->tm.prefix_bases = plan.a; ctx->tm.prefix_radius = plan.r1; ctx->tm.suffix_radius = plan.r2;
     const double np_p = ball_size(plan.a, plan.r1), np_s = ball_size(plan.s, plan.r2);
     const uint64_t nbp = 1ull << (2 * plan.a), nbs = 1ull << (2 * plan.s);
-    // batch size: mean slot-row occupancy <= 256 on both images, and both slot tables addressable with 32 bits
+    // batch size: the candidate CSR of both images must stay addressable with 32 bits (and a sane size)
     double max_batch = (double)std::max<uint32_t>(n_guides, 1);
-    max_batch = std::min(max_batch, 256.0 * (double)nbp / np_p);
-    if (plan.r2 >= 0) max_batch = std::min(max_batch, 256.0 * (double)nbs / np_s);
+    max_batch = std::min(max_batch, (double)(1ull << 30) / (np_p + np_s));
     max_batch = std::min(max_batch, (double)((1u << kGidBits) - 1u));
     uint32_t batch = (uint32_t)std::max(1.0, std::floor(max_batch));
     const uint64_t tile_cap = std::min<uint64_t>(nbp, ctx->T) + std::min<uint64_t>(nbs, ctx->T) + 2 * (ctx->T / kTileTargets) + 4;
     const uint32_t *zero = (const uint32_t *)(ctx->d_counters + 3);
-    FFH_HIP(ctx->overflow.reserve(1u << 20));
     FFH_HIP(ctx->tiles.reserve(tile_cap));
     FFH_HIP(hipEventRecord(ctx->ev[0], st));
     float ms_cmp = 0, ms_prep = 0;
@@ -502,19 +493,16 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         unsigned long long snap[3] = {0, 0, 0};
         FFH_HIP(hipMemcpyAsync(snap, ctx->d_counters, sizeof snap, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipStreamSynchronize(st));
-        const uint32_t cap_p = slot_capacity((double)ng * np_p / (double)nbp);
-        const uint32_t cap_s = plan.r2 >= 0 ? slot_capacity((double)ng * np_s / (double)nbs) : 0;
-        const uint64_t slots_total = nbp * cap_p + nbs * cap_s;
-        if (slots_total >= (1ull << 32)) { ctx->err = "candidate slot table too large"; return FFH_E_ARG; }
-        FFH_HIP(ctx->slots.reserve(slots_total + 64));
+        const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
+        if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
+        FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
         FFH_HIP(ctx->gkey.reserve((size_t)ng + 64));
-        FFH_HIP(hipMemsetAsync(ctx->d_counters + 4, 0, 8, st));
         FFH_HIP(hipEventRecord(ctx->ev[2], st));
-        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, cap_p, 0u, zero);
+        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, 0u, zero);
         if (rc) return rc;
         const uint32_t *n_tiles0 = ctx->tstart[0].p + nbp, *n_tiles1 = zero;
         if (plan.r2 >= 0) {
-            rc = prepare_side(ctx, 1, plan.r2, g0, ng, cap_s, (uint32_t)(nbp * cap_p), n_tiles0);
+            rc = prepare_side(ctx, 1, plan.r2, g0, ng, (uint32_t)n_items_p, n_tiles0);
             if (rc) return rc;
             n_tiles1 = ctx->tstart[1].p + nbs;
         }
@@ -522,7 +510,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         CompareArgs ca;
         ca.tiles = ctx->tiles.p; ca.n_tiles_a = n_tiles0; ca.n_tiles_b = n_tiles1;
         ca.keys[0] = ctx->img[0].keys.p; ca.keys[1] = ctx->img[1].keys.p; ca.tidx[0] = ctx->img[0].tidx.p; ca.tidx[1] = ctx->img[1].tidx.p;
-        ca.slots = ctx->slots.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
+        ca.slots = ctx->item_gid.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
         ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
         ca.r1 = plan.r1; ca.hits = ctx->hits.p; ca.cursor = ctx->d_counters; ca.cap = (uint64_t)ctx->hits.cap;
         // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
@@ -532,9 +520,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
-        // candidate entries that overflowed their slot row (rare): one wave each
-        hipLaunchKernelGGL(k_compare_overflow, dim3(1024), dim3(64), 0, st, ctx->overflow.p, ctx->d_counters + 4, (uint64_t)ctx->overflow.cap, ctx->img[0].bstart.p,
-                           ctx->img[1].bstart.p, ca);
         unsigned long long cnt[5] = {0, 0, 0, 0, 0};
         uint32_t stats[2] = {0, 0};
         FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
@@ -543,18 +528,11 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(hipStreamSynchronize(st));
         FFH_HIP(hipGetLastError());
         const unsigned long long cursor = cnt[0];
-        const bool hits_overflow = cursor > ctx->hits.cap, cand_overflow = cnt[4] > ctx->overflow.cap;
-        if (hits_overflow || cand_overflow) {  // grow / shrink and redo this batch (earlier batches are kept)
+        if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept)
             std::vector<uint64_t> keep((size_t)cursor_before);
-            if (hits_overflow) {
-                if (cursor_before) FFH_HIP(hipMemcpy(keep.data(), ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToHost));
-                FFH_HIP(ctx->hits.reserve((size_t)(cursor + cursor / 2)));
-                if (cursor_before) FFH_HIP(hipMemcpy(ctx->hits.p, keep.data(), (size_t)cursor_before * 8, hipMemcpyHostToDevice));
-            }
-            if (cand_overflow) {
-                if (batch == 1) FFH_HIP(ctx->overflow.reserve((size_t)cnt[4] + 64));
-                else batch = std::max(1u, batch / 2);
-            }
+            if (cursor_before) FFH_HIP(hipMemcpy(keep.data(), ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToHost));
+            FFH_HIP(ctx->hits.reserve((size_t)(cursor + cursor / 2)));
+            if (cursor_before) FFH_HIP(hipMemcpy(ctx->hits.p, keep.data(), (size_t)cursor_before * 8, hipMemcpyHostToDevice));
             FFH_HIP(hipMemcpy(ctx->d_counters, snap, sizeof snap, hipMemcpyHostToDevice));
             continue;
         }
@@ -564,7 +542,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ms_prep += a; ms_cmp += b;
         ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
-        ctx->tm.overflow_items += cnt[4];
         ctx->tm.compare_launches++;
         // image positions -> database indices
         if (cursor > cursor_before)

@@ -97,18 +97,19 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
     gbucket[g] = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
 }
 
-// Candidate slot rows.  Every bucket owns a fixed-capacity row of `cap` candidate slots (guide ids only; the 8-byte
-// planar guide keys stay in a table small enough to live in L2 and are gathered by the compare kernel).  The
-// (bucket, guide) entries are enumerated implicitly (bucket = guide bucket ^ pattern) and binned in two steps so
-// that no per-entry global atomic is needed (device-scope atomics on random addresses run at ~1.3e10/s on MI355X,
-// 4 ms for the 5.6e7 entries of the hg38-scale workload):
-//   A  k_item_partition: a block histograms 64Ki entries over the partitions (= high bits of the bucket id) in LDS,
-//      reserves one contiguous run per partition with ONE global atomic each, and writes (low bucket bits, guide)
-//      records into the partition's staging area;
-//   B  k_item_bin: one block per partition bins its records into the slot rows with LDS atomics and writes the
-//      per-bucket fill counts.
-// An entry that does not fit (partition staging area or slot row full) goes to a short overflow list that a
-// fallback kernel scans one entry per wave.
+// Candidate lists in CSR form: for every bucket the ids of the guides whose Hamming ball reaches it (the 8-byte planar
+// guide keys stay in a table small enough to live in L2 and are gathered by the compare kernel).  The
+// (bucket, guide) entries are enumerated implicitly (bucket = guide bucket ^ pattern) and binned EXACTLY -- no
+// capacity guess, so skewed guide sets (tiling libraries, repeats) cost nothing extra -- and without per-entry global
+// atomics (device-scope atomics on random addresses run at ~1.3e10/s on MI355X: 4 ms for the 5.6e7 entries of the
+// hg38-scale workload):
+//   A1 k_item_count_parts : a block histograms 64Ki entries over the partitions (= high bits of the bucket id) in LDS
+//                           and adds its counts to the global partition sizes (one atomic per partition and block);
+//      exclusive scan of the <= 4096 partition sizes;
+//   A2 k_item_partition   : same enumeration, each block reserves one run per partition (one atomic each) and writes
+//                           (low bucket bits, guide) records into the partition's exactly-sized staging range;
+//   B  k_item_bin         : one block per partition counts its records per bucket in LDS, scans the counts, writes
+//                           the CSR offsets of its buckets and scatters the guide ids into place (LDS atomics only).
 constexpr int kPartThreads = 256;
 constexpr int kPartItemsPerBlock = 65536;
 constexpr int kMaxPartBits = 12;  // <= 4096 partitions, <= 4096 buckets per partition
@@ -118,21 +119,13 @@ struct ItemGeom {
     uint32_t n_guides, n_pat;
     uint32_t low_bits;       // bucket id = (partition << low_bits) | low
     uint32_t n_part;
-    uint32_t part_cap;       // staging records per partition
-    uint32_t cap;            // slots per bucket row
-    uint32_t side;
-    uint64_t ovf_cap;
+    uint32_t item_base;      // first CSR slot of this image (the two images share the item array)
 };
 
-__device__ __forceinline__ void push_overflow(uint64_t *__restrict__ overflow, unsigned long long *__restrict__ ovf_cursor, uint64_t ovf_cap,
-                                              uint32_t side, uint32_t b, uint32_t g) {
-    const unsigned long long o = atomicAdd(ovf_cursor, 1ull);
-    if (o < ovf_cap) overflow[o] = ((uint64_t)side << 63) | ((uint64_t)b << 32) | g;
-}
-
+template <bool WRITE>
 __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
-                                                                 uint32_t *__restrict__ part_fill, uint32_t *__restrict__ part_items,
-                                                                 uint64_t *__restrict__ overflow, unsigned long long *__restrict__ ovf_cursor) {
+                                                                 const uint32_t *__restrict__ part_start, uint32_t *__restrict__ part_fill,
+                                                                 uint32_t *__restrict__ part_items) {
     __shared__ uint32_t cur[1 << kMaxPartBits];
     const uint64_t total = (uint64_t)ig.n_guides * ig.n_pat;
     const uint64_t begin = (uint64_t)blockIdx.x * kPartItemsPerBlock;
@@ -150,64 +143,78 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
         const uint32_t c = cur[d];
-        cur[d] = c ? atomicAdd(&part_fill[d], c) : 0u;  // start of this block's run inside partition d
+        if (!WRITE) { if (c) atomicAdd(&part_fill[d], c); }                    // A1: partition sizes
+        else cur[d] = c ? part_start[d] + atomicAdd(&part_fill[d], c) : 0u;  // A2: start of this block's run
     }
+    if (!WRITE) return;
     __syncthreads();
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = x / ig.n_pat, g = g_first + q;
         const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat];
-        const uint32_t d = b >> ig.low_bits;
-        const uint32_t pos = atomicAdd(&cur[d], 1u);
-        if (pos < ig.part_cap) part_items[(uint64_t)d * ig.part_cap + pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
-        else push_overflow(overflow, ovf_cursor, ig.ovf_cap, ig.side, b, g);
+        const uint32_t pos = atomicAdd(&cur[b >> ig.low_bits], 1u);
+        part_items[pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
     }
 }
 
-__global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__restrict__ part_fill, const uint32_t *__restrict__ part_items, ItemGeom ig,
-                                                           uint32_t *__restrict__ ifill, uint32_t *__restrict__ slots, uint64_t *__restrict__ overflow,
-                                                           unsigned long long *__restrict__ ovf_cursor) {
+__global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
+                                                           uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid) {
     __shared__ uint32_t cnt[1 << kMaxPartBits];
+    __shared__ uint32_t scan_lds[8];
     const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits;
     for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
     __syncthreads();
-    const uint32_t n = min(part_fill[d], ig.part_cap);
-    const uint32_t *__restrict__ src = part_items + (uint64_t)d * ig.part_cap;
-    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) {
-        const uint32_t it = src[k], low = it >> kGidBits, g = it & ((1u << kGidBits) - 1u);
-        const uint32_t pos = atomicAdd(&cnt[low], 1u);
-        const uint32_t b = (d << ig.low_bits) | low;
-        if (pos < ig.cap) slots[(uint64_t)b * ig.cap + pos] = g;
-        else push_overflow(overflow, ovf_cursor, ig.ovf_cap, ig.side, b, g);
-    }
+    const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
+    const uint32_t *__restrict__ src = part_items + p0;
+    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) atomicAdd(&cnt[src[k] >> kGidBits], 1u);
     __syncthreads();
-    for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) ifill[(d << ig.low_bits) + l] = cnt[l];
+    // exclusive scan of the nlow counters: every thread owns nlow / 256 consecutive ones
+    const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; ++k)
+        if (l0 + k < nlow) mine += cnt[l0 + k];
+    uint32_t tot;
+    uint32_t off = block_exclusive_scan<uint32_t>(mine, scan_lds, tot);
+    const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
+    for (uint32_t k = 0; k < per; ++k)
+        if (l0 + k < nlow) {
+            const uint32_t c = cnt[l0 + k];
+            istart[((uint64_t)d << ig.low_bits) + l0 + k] = gbase + off;
+            cnt[l0 + k] = off;  // becomes the scatter cursor
+            off += c;
+        }
+    if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) {
+        const uint32_t it = src[k];
+        const uint32_t pos = atomicAdd(&cnt[it >> kGidBits], 1u);
+        item_gid[gbase + pos] = it & ((1u << kGidBits) - 1u);
+    }
 }
 
 constexpr int kTileTargets = 256;  // targets per work item (a bucket, or a 256-target slice of a large bucket)
 constexpr int kTileChunks = kTileTargets / 64;
 
-__global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, uint32_t n_buckets,
+__global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, uint32_t n_buckets,
                              uint32_t *__restrict__ tcount) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t nt = bstart[b + 1] - bstart[b];
-    tcount[b] = ifill[b] ? (nt + kTileTargets - 1) / kTileTargets : 0;
+    tcount[b] = (istart[b + 1] != istart[b]) ? (nt + kTileTargets - 1) / kTileTargets : 0;
 }
 
-// work item ("tile") = {first key, #keys | side << 31, first slot, #slots used}; the items of both images share one
-// list so that ONE compare launch covers the prefix and the suffix pass
-__global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ ifill, const uint32_t *__restrict__ tstart,
-                            uint32_t n_buckets, uint32_t cap, uint32_t slot_base, const uint32_t *__restrict__ tile_base, uint32_t side,
-                            uint4 *__restrict__ tiles) {
+// work item ("tile") = {first key, #keys | side << 31, first candidate, #candidates}; the items of both images share
+// one list so that ONE compare launch covers the prefix and the suffix pass
+__global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, const uint32_t *__restrict__ tstart,
+                            uint32_t n_buckets, const uint32_t *__restrict__ tile_base, uint32_t side, uint4 *__restrict__ tiles) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets) return;
     const uint32_t t0 = tstart[b], nt = tstart[b + 1] - t0;
     if (!nt) return;
-    const uint32_t k0 = bstart[b], kn = bstart[b + 1] - k0, gn = min(ifill[b], cap);
+    const uint32_t k0 = bstart[b], kn = bstart[b + 1] - k0, g0 = istart[b], gn = istart[b + 1] - g0;
     uint4 *out = tiles + *tile_base + t0;
     for (uint32_t c = 0; c < nt; ++c) {
         const uint32_t kb = c * kTileTargets;
-        out[c] = make_uint4(k0 + kb, min(kn - kb, (uint32_t)kTileTargets) | (side << 31), slot_base + b * cap, gn);
+        out[c] = make_uint4(k0 + kb, min(kn - kb, (uint32_t)kTileTargets) | (side << 31), g0, gn);
     }
 }
 
@@ -436,41 +443,6 @@ done:
     }
     __syncthreads();
     if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(a.cursor + 1 + threadIdx.x, blk_pairs[threadIdx.x]);
-}
-
-// fallback for candidate entries that did not fit their slot row: one wave per (bucket, guide) entry
-__global__ __launch_bounds__(64) void k_compare_overflow(const uint64_t *__restrict__ overflow, const unsigned long long *__restrict__ n_ovf_ptr,
-                                                         uint64_t ovf_cap, const uint32_t *__restrict__ bstart_p, const uint32_t *__restrict__ bstart_s,
-                                                         CompareArgs a) {
-    __shared__ uint64_t stage[kStage];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t n_ovf = min((uint64_t)*n_ovf_ptr, ovf_cap);
-    HitStage hs{stage, 0u, lane, a.hits, a.cursor, a.cap};
-    unsigned long long pairs[2] = {0, 0};
-    for (uint64_t e = blockIdx.x; e < n_ovf; e += gridDim.x) {
-        const uint64_t ent = overflow[e];
-        const uint32_t side = (uint32_t)(ent >> 63), b = (uint32_t)(ent >> 32) & 0x7FFFFFFFu, gid = (uint32_t)ent;
-        const uint32_t *bs = side ? bstart_s : bstart_p;
-        const uint32_t k0 = bs[b], kn = bs[b + 1] - k0;
-        const uint64_t g = a.gkey[gid];
-        pairs[side] += kn;
-        for (uint32_t c = 0; c < kn; c += 64) {
-            const bool valid = c + lane < kn;
-            const uint64_t k = valid ? a.keys[side][k0 + c + lane] : 0;
-            const uint32_t y = ((uint32_t)(k >> 32) ^ (uint32_t)(g >> 32)) | ((uint32_t)k ^ (uint32_t)g);
-            bool hit = valid && (__popc(y) <= a.max_mm);
-            if (side) hit = hit && (__popc(y & a.prefix_mask) > a.r1);
-            const uint64_t mask = __ballot(hit);
-            if (mask) {
-                hs.push(mask, hit, gid, (k0 + c + lane) | (side << 31));
-            }
-        }
-    }
-    if (hs.fill) hs.flush();
-    if (lane == 0) {
-        if (pairs[0]) atomicAdd(a.cursor + 1, pairs[0]);
-        if (pairs[1]) atomicAdd(a.cursor + 2, pairs[1]);
-    }
 }
 
 // hit records leave the compare kernels as (guide << 32) | side << 31 | position in that side's scan image;

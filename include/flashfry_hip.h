@@ -183,7 +183,6 @@ typedef struct ffh_timings {
     uint64_t items_suffix;
     uint64_t tiles_prefix;
     uint64_t tiles_suffix;
-    uint64_t overflow_items;  /* candidate entries that did not fit their slot row (handled by the fallback kernel) */
     uint32_t compare_launches; /* guide batches */
     int prefix_bases, prefix_radius, suffix_radius;
 } ffh_timings;
