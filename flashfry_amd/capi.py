@@ -119,37 +119,51 @@ def load_library(build=True):
     return L
 
 
-def _copy(ptr, n, dtype):
-    if n == 0:
+class _ResultOwner:
+    """frees the ffh_result when the last numpy view of it is gone"""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.ffh_result_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _view(owner, ptr, n, dtype):
+    """zero-copy numpy view of a result array; the view keeps the result alive"""
+    dtype = np.dtype(dtype)
+    if n == 0 or not ptr:
         return np.zeros(0, dtype=dtype)
-    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    addr = ptr if isinstance(ptr, int) else C.cast(ptr, C.c_void_p).value
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(addr)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype, count=n)
 
 
 class Result:
-    """Host copy of an ffh_result: guides in input order, hits in database order, already cut off."""
+    """An ffh_result: guides in input order, hits in database order, already cut off.  The arrays are read-only views
+    of the library's (page-locked) result block, released when the last of them is garbage-collected."""
 
     def __init__(self, L, h, lists=True):
-        try:
-            n = L.ffh_result_n_guides(h)
-            H = L.ffh_result_n_hits(h)
-            P = L.ffh_result_n_positions(h)
-            self.n_guides, self.n_hits, self.n_positions = n, H, P
-            self.scores_valid = bool(L.ffh_result_scores_valid(h))
-            sp = L.ffh_result_summaries(h)
-            if n:
-                buf = (C.c_char * (n * 72)).from_address(sp)
-                self.summaries = np.frombuffer(buf, dtype=SUMMARY_DTYPE, count=n).copy()
-            else:
-                self.summaries = np.zeros(0, dtype=SUMMARY_DTYPE)
-            self.guide_offsets = _copy(L.ffh_result_guide_offsets(h), n + 1, np.uint64)
-            if lists:
-                self.hit_targets = _copy(L.ffh_result_hit_targets(h), H, np.uint64)
-                self.hit_mismatches = _copy(L.ffh_result_hit_mismatches(h), H, np.uint8)
-                self.hit_cfd = _copy(L.ffh_result_hit_cfd(h), H, np.float64)
-                self.pos_offsets = _copy(L.ffh_result_pos_offsets(h), H + 1, np.uint64)
-                self.positions = _copy(L.ffh_result_positions(h), P, np.uint64)
-        finally:
-            L.ffh_result_free(h)
+        own = _ResultOwner(L, h)
+        n = L.ffh_result_n_guides(h)
+        H = L.ffh_result_n_hits(h)
+        P = L.ffh_result_n_positions(h)
+        self.n_guides, self.n_hits, self.n_positions = n, H, P
+        self.scores_valid = bool(L.ffh_result_scores_valid(h))
+        self.summaries = _view(own, L.ffh_result_summaries(h), n, SUMMARY_DTYPE)
+        self.guide_offsets = _view(own, L.ffh_result_guide_offsets(h), n + 1, np.uint64)
+        if lists:
+            self.hit_targets = _view(own, L.ffh_result_hit_targets(h), H, np.uint64)
+            self.hit_mismatches = _view(own, L.ffh_result_hit_mismatches(h), H, np.uint8)
+            self.hit_cfd = _view(own, L.ffh_result_hit_cfd(h), H, np.float64)
+            self.pos_offsets = _view(own, L.ffh_result_pos_offsets(h), H + 1, np.uint64)
+            self.positions = _view(own, L.ffh_result_positions(h), P, np.uint64)
 
     def hits(self, g):
         a, b = int(self.guide_offsets[g]), int(self.guide_offsets[g + 1])

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -65,14 +67,70 @@ struct Evt {
 
 }  // namespace
 
+// page-locked host blocks for results, recycled across calls (hipHostMalloc of several MB costs ~1 ms; pageable
+// destinations make every device-to-host copy go through a bounce buffer)
+struct PinnedPool {
+    std::mutex m;
+    std::vector<std::pair<void *, size_t>> free_blocks;
+    void *get(size_t bytes, size_t &cap) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].second >= bytes && free_blocks[i].second <= 4 * bytes + (1u << 20)) {
+                    void *p = free_blocks[i].first;
+                    cap = free_blocks[i].second;
+                    free_blocks.erase(free_blocks.begin() + (long)i);
+                    return p;
+                }
+        }
+        void *p = nullptr;
+        cap = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return p;
+    }
+    void put(void *p, size_t cap) {
+        std::lock_guard<std::mutex> g(m);
+        if (free_blocks.size() >= 4) { (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
+        free_blocks.emplace_back(p, cap);
+    }
+    ~PinnedPool() { for (auto &b : free_blocks) (void)hipHostFree(b.first); }
+};
+
 struct ffh_result {
     uint32_t n_guides = 0;
     uint64_t n_hits = 0, n_positions = 0;
     int scores_valid = 0;
-    std::vector<ffh_guide_summary> summaries;
-    std::vector<uint64_t> guide_offsets, hit_targets, pos_offsets, positions;
-    std::vector<uint8_t> hit_mm;
-    std::vector<double> hit_cfd;
+    // all arrays live in one pinned block owned by the context's pool
+    std::shared_ptr<PinnedPool> pool;
+    void *block = nullptr;
+    size_t block_cap = 0;
+    ffh_guide_summary *summaries = nullptr;
+    uint64_t *guide_offsets = nullptr, *hit_targets = nullptr, *pos_offsets = nullptr, *positions = nullptr;
+    double *hit_cfd = nullptr;
+    uint8_t *hit_mm = nullptr;
+
+    // lays the arrays out in one block; lists == false keeps only summaries + guide offsets
+    bool allocate(const std::shared_ptr<PinnedPool> &p, uint32_t G, uint64_t H, uint64_t P, bool lists) {
+        pool = p;
+        n_guides = G; n_hits = H; n_positions = lists ? P : 0;
+        auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        size_t o_sum = 0, o_goff = o_sum + up((size_t)G * sizeof(ffh_guide_summary)), o_ht = o_goff + up(((size_t)G + 1) * 8);
+        size_t o_cfd = o_ht, o_poff = o_ht, o_pos = o_ht, o_mm = o_ht, total = o_ht;
+        if (lists) {
+            o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + up((size_t)H * 8); o_pos = o_poff + up(((size_t)H + 1) * 8);
+            o_mm = o_pos + up((size_t)P * 8); total = o_mm + up((size_t)H);
+        }
+        block = pool->get(total + 64, block_cap);
+        if (!block) return false;
+        char *b = (char *)block;
+        summaries = (ffh_guide_summary *)(b + o_sum); guide_offsets = (uint64_t *)(b + o_goff);
+        if (lists) {
+            hit_targets = (uint64_t *)(b + o_ht); hit_cfd = (double *)(b + o_cfd); pos_offsets = (uint64_t *)(b + o_poff);
+            positions = (uint64_t *)(b + o_pos); hit_mm = (uint8_t *)(b + o_mm);
+        }
+        return true;
+    }
+    ~ffh_result() { if (block && pool) pool->put(block, block_cap); }
 };
 
 struct ffh_ctx {
@@ -97,9 +155,10 @@ struct ffh_ctx {
     uint32_t n_guides = 0;
     int max_mm = 0;
     bool scanned = false;
-    DevBuf<uint64_t> hits, hits_alt;
+    DevBuf<uint64_t> hits, hits_alt, hit_t;   // hit_t: target long of every raw hit, sorted order
     uint64_t *hits_sorted = nullptr;
     uint64_t n_raw = 0;
+    int tbits = 1;   // hit key = (guide << tbits) | database index
     DevBuf<uint32_t> seg_begin, seg_end;
     unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] load-time check counter
 
@@ -122,6 +181,7 @@ struct ffh_ctx {
 
     hipEvent_t ev[8] = {};
     ffh_timings tm{};
+    std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 };
 
 static unsigned blocks_for(uint64_t n, unsigned threads) { return (unsigned)std::max<uint64_t>(1, (n + threads - 1) / threads); }
@@ -356,7 +416,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     if (ctx->st) (void)hipStreamSynchronize(ctx->st);
     ctx->targets.release(); ctx->positions.release(); ctx->pos_off.release();
     for (auto &im : ctx->img) { im.bstart.release(); im.keys.release(); im.tidx.release(); }
-    ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->seg_begin.release(); ctx->seg_end.release();
+    ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->hit_t.release(); ctx->seg_begin.release(); ctx->seg_end.release();
     for (int w = 0; w < 2; ++w) { ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->tstart[w].release(); ctx->istart[w].release(); }
     ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->item_gid.release(); ctx->part_fill.release(); ctx->part_start.release(); ctx->part_items.release();
     ctx->tcount.release(); ctx->scan_tmp32.release(); ctx->scan_tmp64.release();
@@ -473,6 +533,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
 
+    ctx->tbits = 1;
+    while (ctx->tbits < 32 && (1ull << ctx->tbits) < std::max<uint64_t>(ctx->T, 2)) ++ctx->tbits;
     const Plan plan = choose_plan(ctx, std::min(max_mm, ctx->geo.lc));
     ctx->tm.prefix_bases = plan.a; ctx->tm.prefix_radius = plan.r1; ctx->tm.suffix_radius = plan.r2;
     const double np_p = ball_size(plan.a, plan.r1), np_s = ball_size(plan.s, plan.r2);
@@ -543,14 +605,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
         ctx->tm.compare_launches++;
-        // image positions -> database indices
+        // (batch-local guide, image position) -> sort key (global guide << tbits) | database index
         if (cursor > cursor_before)
             hipLaunchKernelGGL(k_resolve_hits, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,
-                               (uint64_t)(cursor - cursor_before), ctx->img[0].tidx.p, ctx->img[1].tidx.p);
-        // candidate lists carry batch-local guide ids: make this batch's hits global
-        if (g0 && cursor > cursor_before)
-            hipLaunchKernelGGL(k_add_u64, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,
-                               (uint64_t)(cursor - cursor_before), (uint64_t)g0 << 32);
+                               (uint64_t)(cursor - cursor_before), ctx->img[0].tidx.p, ctx->img[1].tidx.p, g0, ctx->tbits);
         cursor_before = cursor;
         g0 += ng;
     }
@@ -566,16 +624,19 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
         SortScratch ss;
         ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        int tbits = 1, gbits = 1;
-        while (tbits < 32 && (1ull << tbits) < std::max<uint64_t>(ctx->T, 2)) ++tbits;
+        int gbits = 1;
         while (gbits < 32 && (1ull << gbits) < std::max<uint64_t>(n_guides, 2)) ++gbits;
-        ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, tbits, 32, 32 + gbits, ss, st);
+        ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
     }
     FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));
     FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
     FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, ((size_t)n_guides + 1) * 4, st));
     FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, ((size_t)n_guides + 1) * 4, st));
-    if (ctx->n_raw) hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->seg_begin.p, ctx->seg_end.p);
+    FFH_HIP(ctx->hit_t.reserve(ctx->n_raw + 1));
+    if (ctx->n_raw) {
+        hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->seg_end.p);
+        hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
+    }
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
     unsigned long long counters[3] = {0, 0, 0};
     FFH_HIP(hipMemcpyAsync(counters, ctx->d_counters, sizeof counters, hipMemcpyDeviceToHost, st));
@@ -597,8 +658,8 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(ctx->totals.reserve((size_t)ctx->n_guides + 1));
     if (ctx->n_guides) {
-        hipLaunchKernelGGL(k_shard_totals, dim3(blocks_for(ctx->n_guides, 128)), dim3(128), 0, ctx->st, ctx->hits_sorted, ctx->seg_begin.p, ctx->seg_end.p,
-                           ctx->targets.p, ctx->n_guides, clamp, ctx->totals.p);
+        hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
+                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p);
         FFH_HIP(hipMemcpyAsync(totals, ctx->totals.p, (size_t)ctx->n_guides * 4, hipMemcpyDeviceToHost, ctx->st));
     }
     FFH_HIP(hipStreamSynchronize(ctx->st));
@@ -624,8 +685,8 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (G) FFH_HIP(hipMemcpyAsync(ctx->prior.p, prior_totals, (size_t)G * 4, hipMemcpyHostToDevice, st));
         d_prior = ctx->prior.p;
     }
-    if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->hits_sorted, ctx->seg_begin.p, ctx->seg_end.p, ctx->targets.p, d_prior, G,
-                              (uint32_t)max_offtargets, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p);
+    if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
+                              ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr);
     exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
     uint64_t Hr = 0;
     FFH_HIP(hipMemcpyAsync(&Hr, ctx->ret_off.p + G, 8, hipMemcpyDeviceToHost, st));
@@ -638,13 +699,13 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     FFH_HIP(ctx->out_hsu.reserve(Hr + 1));
     FFH_HIP(ctx->out_posoff.reserve(Hr + 2));
     if (ctx->n_raw)
-        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
-                           ctx->targets.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
+        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
+                           ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
                            ctx->out_hsu.p);
     exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, Hr, ctx->out_posoff.p, ctx->scan_tmp64.p, st);
     uint64_t Pr = 0;
     FFH_HIP(hipMemcpyAsync(&Pr, ctx->out_posoff.p + Hr, 8, hipMemcpyDeviceToHost, st));
-    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
+    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
                               ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
     FFH_HIP(hipStreamSynchronize(st));
     const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY);
@@ -656,21 +717,18 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     FFH_HIP(hipEventRecord(ctx->ev[1], st));
     FFH_HIP(hipGetLastError());
     ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r) { ctx->err = "out of memory"; return FFH_E_NOMEM; }
-    r->n_guides = G; r->n_hits = Hr; r->n_positions = want_lists ? Pr : 0; r->scores_valid = ctx->geo.cas9_23;
+    if (!r || !r->allocate(ctx->pool, G, Hr, Pr, want_lists)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+    r->scores_valid = ctx->geo.cas9_23;
     static_assert(sizeof(GuideSummary) == sizeof(ffh_guide_summary), "summary layouts must agree");
-    r->summaries.resize(G);
     hipError_t e = hipSuccess;
-    if (G) e = hipMemcpyAsync(r->summaries.data(), ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
-    r->guide_offsets.resize((size_t)G + 1);
-    if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets.data(), ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
+    if (G) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
     if (want_lists) {
-        r->hit_targets.resize(Hr); r->hit_mm.resize(Hr); r->hit_cfd.resize(Hr); r->pos_offsets.resize(Hr + 1); r->positions.resize(Pr);
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_targets.data(), ctx->out_target.p, Hr * 8, hipMemcpyDeviceToHost, st);
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm.data(), ctx->out_mm.p, Hr, hipMemcpyDeviceToHost, st);
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd.data(), ctx->out_cfd.p, Hr * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets.data(), ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
-        if (Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions.data(), ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_targets, ctx->out_target.p, Hr * 8, hipMemcpyDeviceToHost, st);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm, ctx->out_mm.p, Hr, hipMemcpyDeviceToHost, st);
+        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd, ctx->out_cfd.p, Hr * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets, ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions, ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
@@ -729,19 +787,20 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
         hipLaunchKernelGGL(k_score_list, dim3(blocks_for(H, 256)), dim3(256), 0, st, ctx->out_target.p, ctx->out_tidx.p, H, ctx->guides.p, ctx->geo, ctx->d_tab,
                            ctx->out_mm.p, ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p);
     }
-    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 128)), dim3(128), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
+    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
                               ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
     FFH_HIP(hipGetLastError());
     ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r) { ctx->err = "out of memory"; return FFH_E_NOMEM; }
-    r->n_guides = G; r->n_hits = H; r->n_positions = 0; r->scores_valid = ctx->geo.cas9_23;
-    r->summaries.resize(G); r->guide_offsets.assign(guide_offsets, guide_offsets + (G ? G + 1 : 0));
-    if (!G) r->guide_offsets.assign(1, 0);
-    r->hit_targets.assign(hit_targets, hit_targets + H); r->hit_mm.resize(H); r->hit_cfd.resize(H); r->pos_offsets.assign(H + 1, 0);
+    if (!r || !r->allocate(ctx->pool, G, H, 0, true)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+    r->scores_valid = ctx->geo.cas9_23;
+    if (G) std::memcpy(r->guide_offsets, guide_offsets, ((size_t)G + 1) * 8);
+    else r->guide_offsets[0] = 0;
+    if (H) std::memcpy(r->hit_targets, hit_targets, (size_t)H * 8);
+    std::memset(r->pos_offsets, 0, ((size_t)H + 1) * 8);
     hipError_t e = hipSuccess;
-    if (G) e = hipMemcpyAsync(r->summaries.data(), ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
-    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm.data(), ctx->out_mm.p, H, hipMemcpyDeviceToHost, st);
-    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd.data(), ctx->out_cfd.p, H * 8, hipMemcpyDeviceToHost, st);
+    if (G) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm, ctx->out_mm.p, H, hipMemcpyDeviceToHost, st);
+    if (H && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd, ctx->out_cfd.p, H * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
     *out = r;
@@ -758,13 +817,13 @@ uint32_t ffh_result_n_guides(const ffh_result *r) { return r->n_guides; }
 uint64_t ffh_result_n_hits(const ffh_result *r) { return r->n_hits; }
 uint64_t ffh_result_n_positions(const ffh_result *r) { return r->n_positions; }
 int ffh_result_scores_valid(const ffh_result *r) { return r->scores_valid; }
-const ffh_guide_summary *ffh_result_summaries(const ffh_result *r) { return r->summaries.data(); }
-const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { return r->guide_offsets.data(); }
-const uint64_t *ffh_result_hit_targets(const ffh_result *r) { return r->hit_targets.data(); }
-const uint8_t *ffh_result_hit_mismatches(const ffh_result *r) { return r->hit_mm.data(); }
-const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd.data(); }
-const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { return r->pos_offsets.data(); }
-const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions.data(); }
+const ffh_guide_summary *ffh_result_summaries(const ffh_result *r) { return r->summaries; }
+const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { return r->guide_offsets; }
+const uint64_t *ffh_result_hit_targets(const ffh_result *r) { return r->hit_targets; }
+const uint8_t *ffh_result_hit_mismatches(const ffh_result *r) { return r->hit_mm; }
+const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd; }
+const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { return r->pos_offsets; }
+const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions; }
 void ffh_result_free(ffh_result *r) { delete r; }
 
 }  // extern "C"

@@ -445,60 +445,85 @@ done:
     if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(a.cursor + 1 + threadIdx.x, blk_pairs[threadIdx.x]);
 }
 
-// hit records leave the compare kernels as (guide << 32) | side << 31 | position in that side's scan image;
-// replace the low word by the database index of the target
-__global__ void k_resolve_hits(uint64_t *__restrict__ hits, uint64_t n, const uint32_t *__restrict__ tidx_p, const uint32_t *__restrict__ tidx_s) {
+// hit records leave the compare kernel as (guide << 32) | side << 31 | position in that side's scan image; rewrite them
+// as the sort key (global guide << tbits) | database index (tbits = bits needed for a database index)
+__global__ void k_resolve_hits(uint64_t *__restrict__ hits, uint64_t n, const uint32_t *__restrict__ tidx_p, const uint32_t *__restrict__ tidx_s,
+                               uint32_t guide_base, int tbits) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t h = hits[i];
     const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
     const uint32_t ti = (lo >> 31) ? tidx_s[pos] : tidx_p[pos];
-    hits[i] = (h & 0xFFFFFFFF00000000ull) | ti;
-}
-
-__global__ void k_add_u64(uint64_t *__restrict__ v, uint64_t n, uint64_t add) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] += add;
+    hits[i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// epilogue: ordered cut-off (crispr/CRISPRSiteOT.scala:39-46) + per-hit scores + per-guide aggregates
+// epilogue: ordered cut-off (crispr/CRISPRSiteOT.scala:39-46) + per-hit scores + per-guide aggregates.
+// The hits are sorted by (guide, database index); one WAVE works on one guide's segment.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_segments(const uint64_t *__restrict__ hits, uint64_t n, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
+__global__ void k_segments(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t g = (uint32_t)(hits[i] >> 32);
-    if (i == 0 || (uint32_t)(hits[i - 1] >> 32) != g) seg_begin[g] = (uint32_t)i;
-    if (i == n - 1 || (uint32_t)(hits[i + 1] >> 32) != g) seg_end[g] = (uint32_t)(i + 1);
+    const uint32_t g = (uint32_t)(hits[i] >> tbits);
+    if (i == 0 || (uint32_t)(hits[i - 1] >> tbits) != g) seg_begin[g] = (uint32_t)i;
+    if (i == n - 1 || (uint32_t)(hits[i + 1] >> tbits) != g) seg_end[g] = (uint32_t)(i + 1);
 }
 
-// sum of positions over all hits of this shard, saturating (multi-GPU exchange)
-__global__ void k_shard_totals(const uint64_t *__restrict__ hits, const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end,
-                               const uint64_t *__restrict__ targets, uint32_t n_guides, uint32_t clamp, uint32_t *__restrict__ totals) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_guides) return;
-    uint32_t run = 0;
-    for (uint32_t h = seg_begin[g]; h < seg_end[g] && run < clamp; ++h) run += (uint32_t)(targets[(uint32_t)hits[h]] >> 48);
-    totals[g] = run < clamp ? run : clamp;
+// the target long of every raw hit, in sorted order (the one random gather of the epilogue)
+__global__ void k_hit_targets(const uint64_t *__restrict__ hits, uint64_t n, int tbits, const uint64_t *__restrict__ targets, uint64_t *__restrict__ st) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[i] = targets[hits[i] & ((1ull << tbits) - 1ull)];
 }
 
-// a hit is kept iff the running total BEFORE it is < overflow; the total grows by the hit's position count
-__global__ void k_cutoff(const uint64_t *__restrict__ hits, const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end,
-                         const uint64_t *__restrict__ targets, const uint32_t *__restrict__ prior, uint32_t n_guides, uint32_t overflow,
-                         uint32_t *__restrict__ n_ret, uint32_t *__restrict__ ot_count, uint32_t *__restrict__ full) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_guides) return;
-    const uint32_t p0 = prior ? prior[g] : 0;
-    uint32_t run = p0, kept = 0;
-    for (uint32_t h = seg_begin[g]; h < seg_end[g] && run < overflow; ++h) {
-        run += (uint32_t)(targets[(uint32_t)hits[h]] >> 48);
-        ++kept;
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
     }
-    n_ret[g] = kept;
-    ot_count[g] = run - p0;
-    full[g] = run >= overflow;
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double bcast_f64(double v, uint32_t l) {  // lane l's value in every lane (through SGPRs)
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, l), hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, 64));
+    return v;
 }
 
+// a hit is kept iff the running position total BEFORE it is < overflow; the total grows by the hit's position count.
+// Counts are >= 1, so the kept hits of a 64-hit chunk are a prefix of it.  With totals != nullptr the kernel instead
+// reports min(sum of all counts, overflow) (multi-GPU exchange).
+__global__ __launch_bounds__(256) void k_cutoff(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
+                                                const uint32_t *__restrict__ prior, uint32_t n_guides, uint32_t overflow, uint32_t *__restrict__ n_ret,
+                                                uint32_t *__restrict__ ot_count, uint32_t *__restrict__ full, uint32_t *__restrict__ totals) {
+    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_guides) return;
+    const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
+    uint32_t run = p0, kept = 0;
+    for (uint32_t i = b; i < e && run < overflow; i += 64) {
+        const bool in = i + lane < e;
+        const uint32_t c = in ? (uint32_t)(st[i + lane] >> 48) : 0u;
+        const uint32_t incl = wave_inclusive_scan_u32(c, lane);
+        const bool keep = in && (run + (incl - c) < overflow);
+        const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
+        kept += nk;
+        if (nk) run += __shfl(incl, nk - 1, 64);
+    }
+    if (lane == 0) {
+        if (totals) totals[g] = min(run, overflow);
+        else { n_ret[g] = kept; ot_count[g] = run - p0; full[g] = run >= overflow; }
+    }
+}
 
 struct ScoreTables {
     double cfd_mm[20 * 4 * 4];
@@ -548,18 +573,19 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
 }
 
 // per retained hit of a discover scan: target long, mismatches, position count, database index and the two scores
-__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, const uint32_t *__restrict__ seg_begin,
-                             const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ targets,
+__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, int tbits, const uint32_t *__restrict__ seg_begin,
+                             const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ st,
                              const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
                              uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
                              double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
-    const uint32_t g = (uint32_t)(hits[i] >> 32), ti = (uint32_t)hits[i];
+    const uint64_t key = hits[i];
+    const uint32_t g = (uint32_t)(key >> tbits), ti = (uint32_t)(key & ((1ull << tbits) - 1ull));
     const uint32_t local = (uint32_t)i - seg_begin[g];
     if (local >= n_ret[g]) return;
     const uint64_t o = ret_off[g] + local;
-    const uint64_t t = targets[ti];
+    const uint64_t t = st[i];
     int mm;
     double cfd, hsu;
     score_pair(guides[g], t, geo, tab, mm, cfd, hsu);
@@ -592,34 +618,54 @@ struct GuideSummary {  // mirrors ffh_guide_summary
     double cfd_max, cfd_sum, hsu_sum;
 };
 
-// one thread per guide walks its retained hits IN DATABASE ORDER so the f64 sums associate exactly like the
-// reference's sequential folds (Doench2016CFDScore.scala:79, CrisprMitEduOffTarget.scala:104)
-__global__ void k_guide_aggregate(const uint64_t *__restrict__ ret_off, const uint32_t *__restrict__ n_ret, const uint32_t *__restrict__ ot_count,
-                                  const uint32_t *__restrict__ full, const uint8_t *__restrict__ mm, const uint32_t *__restrict__ cnt,
-                                  const double *__restrict__ cfd, const double *__restrict__ hsu, uint32_t n_guides, GuideSummary *__restrict__ out) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per guide.  Integer aggregates are wave reductions (exact in any order); the two f64 sums are accumulated
+// hit by hit IN DATABASE ORDER (lane values broadcast one after the other) so that they associate exactly like the
+// reference's sequential folds (Doench2016CFDScore.scala:79, CrisprMitEduOffTarget.scala:104).
+__global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restrict__ ret_off, const uint32_t *__restrict__ n_ret,
+                                                         const uint32_t *__restrict__ ot_count, const uint32_t *__restrict__ full,
+                                                         const uint8_t *__restrict__ mm, const uint32_t *__restrict__ cnt, const double *__restrict__ cfd,
+                                                         const double *__restrict__ hsu, uint32_t n_guides, GuideSummary *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_guides) return;
-    GuideSummary s;
-    s.n_hits = n_ret[g]; s.ot_count = ot_count[g]; s.overflow = full[g];
-    for (int k = 0; k < 5; ++k) s.hist[k] = 0;
-    s.closest = 0xFFFFFFFFu; s.closest_count = 0; s.in_genome = 0; s.n_scored = 0;
-    s.cfd_max = 0.0; s.cfd_sum = 0.0; s.hsu_sum = 0.0;
+    const uint32_t n = n_ret[g];
     const uint64_t b = ret_off[g];
-    for (uint32_t k = 0; k < s.n_hits; ++k) {
-        const uint32_t m = mm[b + k], c = cnt[b + k];
-        if (m <= 4) s.hist[m] += c;                                        // ClosestHit.scala:57-59
-        if (m < s.closest && m > 0) { s.closest = m; s.closest_count = c; } // :62-64
-        else if (m == s.closest) s.closest_count += c;                      // :65-67
-        if (m == 0) s.in_genome += c;                                       // DangerousSequences.scala:62
-        const double f = cfd[b + k];
-        if (f == f) {  // scored (not the on-target)
-            s.cfd_sum += f * (double)c;
-            if (s.n_scored == 0 || f > s.cfd_max) s.cfd_max = f;
-            s.hsu_sum += hsu[b + k];
-            s.n_scored++;
+    uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, n_scored = 0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0;
+    for (uint32_t i = 0; i < n; i += 64) {  // pass 1: histogram, closest level, ordered f64 sums
+        const bool in = i + lane < n;
+        const uint32_t m = in ? mm[b + i + lane] : 0xFFu, c = in ? cnt[b + i + lane] : 0u;
+        const double f = in ? cfd[b + i + lane] : __builtin_nan(""), h = in ? hsu[b + i + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) hist[k] += (m == (uint32_t)k) ? c : 0u;     // ClosestHit.scala:57-59
+        if (in && m > 0 && m < closest) closest = m;                               // :62-64
+        const double fc = f * (double)c;
+        uint64_t scored = __ballot(in && f == f);                                  // NaN = the on-target itself, not scored
+        while (scored) {                                                           // wave-uniform walk in hit order
+            const uint32_t l = (uint32_t)__builtin_ctzll(scored);
+            scored &= scored - 1;
+            cfd_sum += bcast_f64(fc, l);
+            hsu_sum += bcast_f64(h, l);
+            cfd_max = fmax(cfd_max, bcast_f64(f, l));                              // scores are >= 0, the empty max is 0.0
+            ++n_scored;
         }
     }
-    out[g] = s;
+    closest = wave_min_u32(closest);
+    uint32_t closest_count = 0, in_genome = 0;
+    for (uint32_t i = 0; i < n; i += 64) {  // pass 2: occurrences at the closest level (ClosestHit.scala:62-67)
+        const bool in = i + lane < n;
+        const uint32_t m = in ? mm[b + i + lane] : 0xFFu, c = in ? cnt[b + i + lane] : 0u;
+        closest_count += (m == closest) ? c : 0u;
+    }
+    GuideSummary s;
+    s.n_hits = n; s.ot_count = ot_count[g]; s.overflow = full[g];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s.hist[k] = wave_sum_u32(hist[k]);
+    in_genome = s.hist[0];                                                          // DangerousSequences.scala:62
+    s.closest = closest;
+    s.closest_count = closest == 0xFFFFFFFFu ? 0u : wave_sum_u32(closest_count);
+    s.in_genome = in_genome; s.n_scored = n_scored;
+    s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
+    if (lane == 0) out[g] = s;
 }
 
 __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ out_off,

@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
 // recursive over block sums.  Block = 256 threads x 16 items = 4096 items.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 16;
+constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
 template <typename T>
@@ -48,14 +48,34 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *lds /* >= 8 entries */
     return wave_off + incl - v;
 }
 
+// a thread's kScanItems consecutive inputs; full tiles are fetched with 16-byte loads
+template <typename TIn, typename TOut>
+__device__ __forceinline__ void scan_load_items(const TIn *__restrict__ in, uint64_t n, uint64_t base, TOut (&v)[kScanItems]) {
+    if (base + kScanItems <= n) {
+        constexpr int kPer = 16 / sizeof(TIn);
+        struct alignas(16) Pack { TIn e[kPer]; };
+        const Pack *src = reinterpret_cast<const Pack *>(in + base);
+#pragma unroll
+        for (int q = 0; q < kScanItems / kPer; ++q) {
+            const Pack p = src[q];
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) v[q * kPer + e] = (TOut)p.e[e];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) v[k] = (base + k < n) ? (TOut)in[base + k] : (TOut)0;
+    }
+}
+
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const TIn *__restrict__ in, uint64_t n, TOut *__restrict__ bsum) {
     __shared__ TOut lds[8];
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    TOut v[kScanItems];
+    scan_load_items<TIn, TOut>(in, n, base, v);
     TOut s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k)
-        if (base + k < n) s += (TOut)in[base + k];
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
     TOut tot;
     block_exclusive_scan<TOut>(s, lds, tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
@@ -67,18 +87,29 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn *__restri
     __shared__ TOut lds[8];
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
     TOut v[kScanItems];
+    scan_load_items<TIn, TOut>(in, n, base, v);
     TOut s = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        v[k] = (base + k < n) ? (TOut)in[base + k] : (TOut)0;
-        s += v[k];
-    }
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
     TOut tot;
     TOut off = block_exclusive_scan<TOut>(s, lds, tot) + boff[blockIdx.x];
+    if (base + kScanItems <= n) {
+        constexpr int kPer = 16 / sizeof(TOut);
+        struct alignas(16) Pack { TOut e[kPer]; };
+        Pack *dst = reinterpret_cast<Pack *>(out + base);
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        if (base + k < n) out[base + k] = off;
-        off += v[k];
+        for (int q = 0; q < kScanItems / kPer; ++q) {
+            Pack p;
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) { p.e[e] = off; off += v[q * kPer + e]; }
+            dst[q] = p;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (base + k < n) out[base + k] = off;
+            off += v[k];
+        }
     }
     // the grand total goes to out[n]
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanThreads - 1) out[n] = off;
@@ -89,13 +120,14 @@ template <typename TIn, typename TOut>
 inline void exclusive_scan(const TIn *in, uint64_t n, TOut *out, TOut *scratch, hipStream_t st) {
     uint64_t nb = (n + kScanTile - 1) / kScanTile;
     if (nb == 0) nb = 1;
-    TOut *bsum = scratch;           // nb entries (+1 for the recursive total)
-    TOut *next = scratch + nb + 1;  // scratch of the next level
+    const uint64_t nb_pad = (nb + 1 + 7) & ~7ull;  // keep every sub-buffer 16-byte aligned for the vector loads
+    TOut *bsum = scratch;            // nb entries (+1 for the recursive total)
+    TOut *next = scratch + nb_pad;   // scratch of the next level
     hipLaunchKernelGGL((k_scan_reduce<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, bsum);
     if (nb > 1) {
         // scan block sums in place-ish: bsum -> boff (stored in `next` region's head), recursive
         TOut *boff = next;
-        exclusive_scan<TOut, TOut>(bsum, nb, boff, next + nb + 1, st);
+        exclusive_scan<TOut, TOut>(bsum, nb, boff, next + nb_pad, st);
         hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, boff, out);
     } else {
         // single block: offset 0
@@ -110,7 +142,7 @@ inline uint64_t scan_scratch_elems_safe(uint64_t n) {
     while (true) {
         uint64_t nb = (n + kScanTile - 1) / kScanTile;
         if (nb == 0) nb = 1;
-        tot += 2 * (nb + 1);
+        tot += 2 * ((nb + 1 + 7) & ~7ull);
         if (nb <= 1) break;
         n = nb;
     }
@@ -122,8 +154,8 @@ inline uint64_t scan_scratch_elems_safe(uint64_t n) {
 // One wave per block; a block owns a contiguous chunk of kSortChunk keys and ranks them row by row (64 keys per
 // row) so the scatter is stable.  Per pass: histogram -> scan of the digit-major (256 x nblocks) table -> scatter.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSortRows = 32;
-constexpr int kSortChunk = kSortRows * kWave;  // 2048 keys per block
+constexpr int kSortRows = 16;
+constexpr int kSortChunk = kSortRows * kWave;  // 1024 keys per block
 
 __global__ __launch_bounds__(64) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
                                                    uint32_t *__restrict__ table /* [256][nblocks] */, uint32_t nblocks) {
@@ -144,13 +176,21 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint64_t *__restrict_
                                                       const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks) {
     __shared__ uint32_t cur[256];
     const uint32_t lane = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+    // the whole chunk is requested before anything else (one latency instead of one per row)
+    uint64_t kreg[kSortRows];
+#pragma unroll
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * 64 + lane;
+        kreg[r] = i < n ? keys[i] : 0;
+    }
     for (int i = lane; i < 256; i += 64) cur[i] = offs[(uint64_t)i * nblocks + blockIdx.x];
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+#pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
         const uint64_t i = base + (uint64_t)r * 64 + lane;
         const bool valid = i < n;
-        const uint64_t key = valid ? keys[i] : 0;
+        const uint64_t key = kreg[r];
         const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
         // lanes holding the same digit: intersect the 8 per-bit ballots
         uint64_t peers = __ballot(valid);
