@@ -165,7 +165,14 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
     __syncthreads();
     const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
     const uint32_t *__restrict__ src = part_items + p0;
-    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) atomicAdd(&cnt[src[k] >> kGidBits], 1u);
+    constexpr int kU = 8;  // records in flight per thread (the loop is latency-bound otherwise)
+    for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
+        uint32_t r[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[r[u] >> kGidBits], 1u);
+    }
     __syncthreads();
     // exclusive scan of the nlow counters: every thread owns nlow / 256 consecutive ones
     const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
@@ -184,10 +191,16 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
         }
     if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) {
-        const uint32_t it = src[k];
-        const uint32_t pos = atomicAdd(&cnt[it >> kGidBits], 1u);
-        item_gid[gbase + pos] = it & ((1u << kGidBits) - 1u);
+    for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
+        uint32_t r[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (k0 + u * kPartThreads + threadIdx.x < n) {
+                const uint32_t pos = atomicAdd(&cnt[r[u] >> kGidBits], 1u);
+                item_gid[gbase + pos] = r[u] & ((1u << kGidBits) - 1u);
+            }
     }
 }
 

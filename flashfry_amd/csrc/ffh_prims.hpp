@@ -151,48 +151,76 @@ inline uint64_t scan_scratch_elems_safe(uint64_t n) {
 
 // ---------------------------------------------------------------------------------------------------------
 // LSD radix sort of u64 keys, 8 bits per pass, only over the caller-given bit ranges.
-// One wave per block; a block owns a contiguous chunk of kSortChunk keys and ranks them row by row (64 keys per
-// row) so the scatter is stable.  Per pass: histogram -> scan of the digit-major (256 x nblocks) table -> scatter.
+// A 256-thread block owns a contiguous chunk of 4096 keys.  Per pass: histogram -> scan of the digit-major
+// (256 x nblocks) table -> scatter.  The scatter ranks the chunk stably (wave w owns rows w*16..w*16+15, ranked row
+// by row with ballots), stages it digit-ordered in LDS and writes every digit's run contiguously, so the global
+// stores are coalesced runs instead of 8-byte scatters.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kSortRows = 16;
-constexpr int kSortChunk = kSortRows * kWave;  // 1024 keys per block
+constexpr int kSortThreads = 256;
+constexpr int kSortRows = 16;                               // rows of 64 keys per wave
+constexpr int kSortChunk = kSortThreads * kSortRows;        // 4096 keys per block
 
-__global__ __launch_bounds__(64) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
-                                                   uint32_t *__restrict__ table /* [256][nblocks] */, uint32_t nblocks) {
+__global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
+                                                             uint32_t *__restrict__ table /* [256][nblocks] */, uint32_t nblocks) {
     __shared__ uint32_t h[256];
-    const uint32_t lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) h[i] = 0;
+    h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+#pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
-        uint64_t i = base + (uint64_t)r * 64 + lane;
+        const uint64_t i = base + (uint64_t)r * kSortThreads + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
     }
     __syncthreads();
-    for (int i = lane; i < 256; i += 64) table[(uint64_t)i * nblocks + blockIdx.x] = h[i];
+    table[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
-                                                      const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks) {
-    __shared__ uint32_t cur[256];
-    const uint32_t lane = threadIdx.x;
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
+                                                                const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks) {
+    __shared__ uint64_t staged[kSortChunk];      // the chunk, digit-ordered
+    __shared__ uint32_t wave_cnt[4][256];        // per-wave digit counts -> per-wave start inside the digit's run
+    __shared__ uint32_t dig_start[256];          // start of every digit's run inside the chunk
+    __shared__ uint32_t dig_goff[256];           // global offset of every digit's run
+    __shared__ uint32_t scan_lds[8];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
-    // the whole chunk is requested before anything else (one latency instead of one per row)
+    const uint32_t here = (uint32_t)min((uint64_t)kSortChunk, n - base);
+    // wave w owns keys [w*1024, w*1024 + 1024) of the chunk, 16 rows of 64
     uint64_t kreg[kSortRows];
 #pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
-        const uint64_t i = base + (uint64_t)r * 64 + lane;
-        kreg[r] = i < n ? keys[i] : 0;
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        kreg[r] = i < here ? keys[base + i] : 0;
     }
-    for (int i = lane; i < 256; i += 64) cur[i] = offs[(uint64_t)i * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+    dig_goff[threadIdx.x] = offs[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
     __syncthreads();
+    // pass 1: per-wave digit counts
 #pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
-        const uint64_t i = base + (uint64_t)r * 64 + lane;
-        const bool valid = i < n;
-        const uint64_t key = kreg[r];
-        const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
-        // lanes holding the same digit: intersect the 8 per-bit ballots
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        if (i < here) atomicAdd(&wave_cnt[wave][(uint32_t)(kreg[r] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    // digit d (= threadIdx.x): run start inside the chunk, and each wave's start inside that run
+    {
+        const uint32_t c0 = wave_cnt[0][threadIdx.x], c1 = wave_cnt[1][threadIdx.x], c2 = wave_cnt[2][threadIdx.x], c3 = wave_cnt[3][threadIdx.x];
+        uint32_t tot;
+        const uint32_t start = block_exclusive_scan<uint32_t>(c0 + c1 + c2 + c3, scan_lds, tot);
+        dig_start[threadIdx.x] = start;
+        wave_cnt[0][threadIdx.x] = start;
+        wave_cnt[1][threadIdx.x] = start + c0;
+        wave_cnt[2][threadIdx.x] = start + c0 + c1;
+        wave_cnt[3][threadIdx.x] = start + c0 + c1 + c2;
+    }
+    __syncthreads();
+    // pass 2: stable rank inside the wave, row by row; wave_cnt[wave][d] is the wave's running cursor
+#pragma unroll
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        const bool valid = i < here;
+        const uint32_t d = (uint32_t)(kreg[r] >> shift) & 0xFF;
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -201,11 +229,21 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint64_t *__restrict_
         }
         const uint32_t rank = mbcnt(peers);
         uint32_t pos = 0;
-        if (valid) pos = cur[d] + rank;
-        __syncthreads();
-        if (valid && rank == (uint32_t)__popcll(peers) - 1) cur[d] = pos + 1;  // last peer advances the cursor
-        __syncthreads();
-        if (valid) out[pos] = key;
+        if (valid) pos = wave_cnt[wave][d] + rank;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == (uint32_t)__popcll(peers) - 1) wave_cnt[wave][d] = pos + 1;  // last peer advances the cursor
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) staged[pos] = kreg[r];
+    }
+    __syncthreads();
+    // pass 3: contiguous copy-out; element i of the digit-ordered chunk goes to the digit's global run
+    for (uint32_t i = threadIdx.x; i < here; i += kSortThreads) {
+        const uint64_t key = staged[i];
+        const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+        out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
     }
 }
 
@@ -227,9 +265,9 @@ inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, 
     int ranges[2][2] = {{lo_a, hi_a}, {lo_b, hi_b}};
     for (int rg = 0; rg < 2; ++rg)
         for (int shift = ranges[rg][0]; shift < ranges[rg][1]; shift += 8) {
-            hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(64), 0, st, src, n, shift, s.table, nb);
+            hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
             exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
-            hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(64), 0, st, src, dst, n, shift, s.offs, nb);
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb);
             uint64_t *t = src; src = dst; dst = t;
         }
     return src;
