@@ -315,49 +315,53 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     constexpr uint32_t SUB = 64 / W;
     const uint32_t tl = w.lane & (SUB - 1), gs = w.lane / SUB;
     const bool valid = tl < cnt;
-    const uint64_t k = w.key_lds[koff + tl];
+    // lanes without a target carry the all-ones key: it differs from every candidate (real or sentinel) in >= 12 bits
+    const uint64_t k = valid ? w.key_lds[koff + tl] : ~0ull;
     const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
     const uint64_t valid_mask = __ballot(valid);
-    const int max_mm = w.a->max_mm;
+    const uint32_t max_mm = (uint32_t)w.a->max_mm;
     const uint32_t iters = (n + W - 1) / W;
-    auto test = [&](uint32_t idx, uint32_t &y) -> uint64_t {
+    auto dist = [&](uint32_t idx, uint32_t &y) -> uint32_t {  // mismatches of this lane's target vs candidate idx
         const uint64_t g = w.gk_lds[idx];
         y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
-        uint64_t m = __builtin_amdgcn_ballot_w64(__popc(y) <= max_mm) & valid_mask;
-        if (CHECK) m &= __builtin_amdgcn_ballot_w64(idx < n);
-        return m;
+        return (uint32_t)__popc(y);
     };
-    auto report = [&](uint64_t m, uint32_t y, uint32_t idx) {
-        if (w.suffix) m &= __builtin_amdgcn_ballot_w64(__popc(y & w.a->prefix_mask) > w.a->r1);
+    auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
+        uint64_t m = __builtin_amdgcn_ballot_w64(p <= max_mm);
+        if (CHECK) m &= valid_mask & __builtin_amdgcn_ballot_w64(idx < n);  // the sentinels are not safe for max_mm >= 12
+        if (w.suffix) m &= __builtin_amdgcn_ballot_w64((uint32_t)__popc(y & w.a->prefix_mask) > (uint32_t)w.a->r1);
         if (m) {
             const bool hit = (m >> w.lane) & 1ull;
             w.hs->push(m, hit, hit ? w.gid_lds[idx] : 0u, (pos0 + tl) | w.side_bit);
         }
     };
+    // four candidates per step; ONE vector compare and ONE scalar branch decide whether any of the 256 pairs is within
+    // max_mm (the scalar unit is shared by the CU's four SIMDs: mask algebra per pair would make it the bottleneck)
     uint32_t j = 0;
     for (; j + 4 <= iters; j += 4) {
         uint32_t y0, y1, y2, y3;
         const uint32_t i0 = j * W + gs, i1 = i0 + W, i2 = i0 + 2 * W, i3 = i0 + 3 * W;
-        const uint64_t m0 = test(i0, y0), m1 = test(i1, y1), m2 = test(i2, y2), m3 = test(i3, y3);
-        if (m0 | m1 | m2 | m3) {
-            if (m0) report(m0, y0, i0);
-            if (m1) report(m1, y1, i1);
-            if (m2) report(m2, y2, i2);
-            if (m3) report(m3, y3, i3);
+        const uint32_t p0 = dist(i0, y0), p1 = dist(i1, y1), p2 = dist(i2, y2), p3 = dist(i3, y3);
+        const uint32_t best = min(min(p0, p1), min(p2, p3));
+        if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
+            report(p0, y0, i0);
+            report(p1, y1, i1);
+            report(p2, y2, i2);
+            report(p3, y3, i3);
         }
     }
     for (; j < iters; ++j) {
         uint32_t y;
         const uint32_t i0 = j * W + gs;
-        const uint64_t m = test(i0, y);
-        if (m) report(m, y, i0);
+        const uint32_t p = dist(i0, y);
+        if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, i0);
     }
 }
 
 // the read-only streams are separate __restrict__ kernel parameters (noalias lets the compiler keep the descriptor
 // loads on the scalar unit and reorder the vector loads around the hit stores)
 template <bool CHECK>
-__global__ __launch_bounds__(kCmpThreads) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
+__global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
                                                          const uint64_t *__restrict__ keys_s, const uint32_t *__restrict__ slots,
                                                          const uint64_t *__restrict__ gkey, const CompareArgs a) {
     __shared__ uint64_t stage[kCmpThreads / 64][kStage];
@@ -373,8 +377,9 @@ __global__ __launch_bounds__(kCmpThreads) void k_compare(const uint4 *__restrict
     __syncthreads();
     HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap};
     unsigned long long pairs[2] = {0, 0};
-    // all-ones planes differ from every real key in the 12 unused high bits of each plane: safe while max_mm < 12
-    const uint64_t sentinel = ~0ull;
+    // padding candidate: the 12 unused high bits of both planes set, the 20 used ones clear.  It differs from every real
+    // key in those 12 bits and from the all-ones key of an idle lane in the 20 low ones: never within max_mm < 12
+    const uint64_t sentinel = 0xFFF00000FFF00000ull;
     WaveCtx w{&a, &hs, key_lds[wave], gk_lds[wave], gid_lds[wave], lane, 0u, false};
 
     uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave;
