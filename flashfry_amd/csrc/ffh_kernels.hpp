@@ -329,7 +329,7 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
         uint64_t m = __builtin_amdgcn_ballot_w64(p <= max_mm);
         if (CHECK) m &= valid_mask & __builtin_amdgcn_ballot_w64(idx < n);  // the sentinels are not safe for max_mm >= 12
-        if (w.suffix) m &= __builtin_amdgcn_ballot_w64((uint32_t)__popc(y & w.a->prefix_mask) > (uint32_t)w.a->r1);
+        if (m && w.suffix) m &= __builtin_amdgcn_ballot_w64((uint32_t)__popc(y & w.a->prefix_mask) > (uint32_t)w.a->r1);
         if (m) {
             const bool hit = (m >> w.lane) & 1ull;
             w.hs->push(m, hit, hit ? w.gid_lds[idx] : 0u, (pos0 + tl) | w.side_bit);
@@ -389,11 +389,12 @@ __global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restr
         // outstanding loads exactly instead of draining the queue)
         // descriptors past the end are replaced by the last one (its loads are harmless and never consumed)
         auto load_desc = [&](uint32_t ti) -> uint4 { return tiles[min(ti, n_tiles - 1)]; };
-        auto load_gid = [&](const uint4 &d) -> uint32_t { return slots[d.z + min(lane, max(d.w, 1u) - 1u)]; };
+        // uniform base pointer + small per-lane index: the loads use the scalar-base addressing form
+        auto load_gid = [&](const uint4 &d) -> uint32_t { return (slots + d.z)[min(lane, max(d.w, 1u) - 1u)]; };
         auto load_key = [&](const uint4 &d, uint32_t c) -> uint64_t {
             const uint32_t kc = d.y & 0x7FFFFFFFu;
-            const uint64_t *__restrict__ kp = (d.y >> 31) ? keys_s : keys_p;
-            return kp[d.x + min(c * 64u + lane, max(kc, 1u) - 1u)];
+            const uint64_t *__restrict__ kp = ((d.y >> 31) ? keys_s : keys_p) + d.x;
+            return kp[min(c * 64u + lane, max(kc, 1u) - 1u)];
         };
         // prologue
         uint4 d0 = load_desc(t), d1 = load_desc(t + n_waves), d2 = load_desc(t + 2 * n_waves);
