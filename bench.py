@@ -38,7 +38,47 @@ def parse():
     ap.add_argument("--max-offtargets", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--workload", default="hg38-scale")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure the compare kernel's HBM traffic")
+    ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"), help="where the PMC passes write their CSVs")
     return ap.parse_args()
+
+
+def measure_traffic(args):
+    """HBM bytes per k_compare launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes: separate
+    `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE) with --kernel-trace only, values in KiB, and FETCH_SIZE
+    calibrated on a kernel of the same access pattern with a known byte count: ffh::k_image_hist reads exactly 8 B per
+    resident target with the same 8-byte-per-lane coalesced loads (gfx950 reports half of the bytes of such streams)."""
+    import csv
+    import shutil
+    import subprocess
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(args.traffic_dir, counter)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d, exist_ok=True)
+        cmd = [prof, "--kernel-trace", "--pmc", counter, "--kernel-include-regex", "k_compare<|k_image_hist", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic",
+               "--targets", str(args.targets), "--guides", str(args.guides), "--max-mismatch", str(args.max_mismatch), "--max-offtargets", str(args.max_offtargets)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=900)
+        path = os.path.join(d, "pmc_counter_collection.csv")
+        if r.returncode != 0 or not os.path.exists(path):
+            return None
+        vals = {}
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] == counter:
+                vals.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+        out[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
+    try:
+        cmp_fetch = [v for k, v in out["FETCH_SIZE"].items() if "k_compare" in k][0]
+        cmp_write = [v for k, v in out["WRITE_SIZE"].items() if "k_compare" in k][0]
+        cal = [v for k, v in out["FETCH_SIZE"].items() if "k_image_hist" in k][0]
+    except (IndexError, KeyError):
+        return None
+    return {"fetch_kib": cmp_fetch, "write_kib": cmp_write, "calibration_fetch_kib": cal}
 
 
 def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max_ot, budget_s):
@@ -115,6 +155,12 @@ def main():
             cpu = {"value": None, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     del db
     torch.cuda.empty_cache()
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_traffic:
+        try:
+            pmc = measure_traffic(args)
+        except Exception:
+            pmc = None
 
     def step():
         ctx.scan(guides_np, args.max_mismatch)
@@ -162,6 +208,13 @@ def main():
         b_survey = 8 * T + 8 * G + 16 * raw_hits + 8 * kept_pos  # SURVEY.md §8d formula for the whole discover
         achieved = b_alg / (cmp_ms * 1e-3) / 1e9
         pairs = float(np.mean([t["pairs_prefix"] + t["pairs_suffix"] for t in tms]))
+        traffic, traffic_note = None, None
+        if pmc:
+            # calibration: k_image_hist streams exactly 8 B per target; scale = true bytes / reported bytes (2.0 on gfx950)
+            scale = (8.0 * T) / (pmc["calibration_fetch_kib"] * 1024.0)
+            traffic = pmc["fetch_kib"] * 1024.0 * scale + pmc["write_kib"] * 1024.0
+            traffic_note = {"fetch_size_kib": pmc["fetch_kib"], "write_size_kib": pmc["write_kib"], "fetch_scale_from_calibration": scale,
+                            "calibration": "ffh::k_image_hist reads 8 B per target with the same coalesced 8-byte loads; WRITE_SIZE uncalibrated"}
         out = {
             "metric": "guide x target comparisons/s (discover, <=%d mismatches, CFD+Hsu2013 aggregate)" % args.max_mismatch,
             "value": G * T_total * args.steps / dt,
@@ -174,7 +227,7 @@ def main():
                        "guides": G, "targets_per_gpu": T, "targets_total": T_total, "positions_per_gpu": P,
                        "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "ffh::k_compare", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
+                         "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
                          "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3)},
             "cpu_baseline": cpu,
             "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},

@@ -149,6 +149,7 @@ struct ffh_ctx {
     double db_prepare_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
+    uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
     // scan state
     DevBuf<uint64_t> guides;
@@ -388,6 +389,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     ctx->device = device_id;
     if (enzyme_index) set_enzyme(ctx, enzyme_index);  // 0: taken from the database header by ffh_db_open / ffh_db_open_header
     if (const char *e = std::getenv("FFH_COMPARE_GRID")) { const long v = std::atol(e); if (v > 0) ctx->compare_grid = (unsigned)v; }
+    if (const char *e = std::getenv("FFH_MAX_GUIDE_BATCH")) { const long v = std::atol(e); if (v > 0) ctx->max_guide_batch = (uint32_t)v; }
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
@@ -543,6 +545,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     double max_batch = (double)std::max<uint32_t>(n_guides, 1);
     max_batch = std::min(max_batch, (double)(1ull << 30) / (np_p + np_s));
     max_batch = std::min(max_batch, (double)((1u << kGidBits) - 1u));
+    if (ctx->max_guide_batch) max_batch = std::min(max_batch, (double)ctx->max_guide_batch);
     uint32_t batch = (uint32_t)std::max(1.0, std::floor(max_batch));
     const uint64_t tile_cap = std::min<uint64_t>(nbp, ctx->T) + std::min<uint64_t>(nbs, ctx->T) + 2 * (ctx->T / kTileTargets) + 4;
     const uint32_t *zero = (const uint32_t *)(ctx->d_counters + 3);

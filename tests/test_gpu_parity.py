@@ -132,6 +132,35 @@ def test_other_enzymes(capi, oracle, enzyme):
     assert_same_scores(oracle, enzyme, guides, gpu, ora)
 
 
+@pytest.mark.parametrize("max_mm", [11, 12, 20, 25])
+def test_huge_mismatch_budgets(capi, oracle, max_mm):
+    """maxMismatch >= the guide length: every target is a hit; exercises the single-image fallback plan and the
+    sentinel-free compare variant (max_mm >= 12), with the cut-off deciding what is kept"""
+    odb, t, p, g = make_case(oracle, 3000, 12, enzyme=3, seed=3)
+    gpu, ora, tm = run_both(capi, oracle, odb, t, p, g, 3, max_mm, 150)
+    assert_same_hits(gpu, ora)
+    assert ora.full.any() and (ora.full.all() or max_mm < 20)
+    gpu, ora, tm = run_both(capi, oracle, odb, t, p, g[:3], 3, max_mm, 10 ** 7)
+    assert_same_hits(gpu, ora)
+    if max_mm >= 20:
+        assert gpu.n_hits == 3 * len(t)
+    assert_same_scores(oracle, 3, g[:3], gpu, ora)
+
+
+def test_guide_batches(capi, oracle, monkeypatch):
+    """the candidate lists are built per guide batch; any batch size gives the same result"""
+    odb, t, p, g = dense_case(oracle, seed=9)
+    ora = odb.discover(g, 4, 60)
+    for batch in ("1000000", "97", "7"):
+        monkeypatch.setenv("FFH_MAX_GUIDE_BATCH", batch)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            gpu = ctx.discover(g, 4, 60)
+            assert ctx.timings().compare_launches == max(1, -(-len(g) // int(batch)))
+        assert_same_hits(gpu, ora)
+        assert_same_scores(oracle, 3, g, gpu, ora)
+
+
 def test_edge_cases(capi, oracle):
     odb, t, p, g = make_case(oracle, 5000, 50, enzyme=3, seed=2)
     with capi.Context(3) as ctx:
