@@ -110,10 +110,12 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
 //                           (low bucket bits, guide) records into the partition's exactly-sized staging range;
 //   B  k_item_bin         : one block per partition counts its records per bucket in LDS, scans the counts, writes
 //                           the CSR offsets of its buckets and scatters the guide ids into place (LDS atomics only).
-constexpr int kPartThreads = 256;
-constexpr int kPartItemsPerBlock = 65536;
-constexpr int kMaxPartBits = 12;  // <= 4096 partitions, <= 4096 buckets per partition
-constexpr int kGidBits = 20;      // guides per batch < 2^20
+constexpr int kPartThreads = 1024;
+constexpr int kPartItemsPerBlock = 262144;
+constexpr int kMaxPartBits = 12;   // <= 4096 partitions
+constexpr int kMaxLowBits = 12;    // <= 4096 buckets per partition (11 bits preferred: see prepare_side)
+constexpr int kBinStage = 26624;   // candidate ids staged in LDS per partition (104 KB); larger partitions scatter to memory
+constexpr int kGidBits = 20;       // guides per batch < 2^20
 
 struct ItemGeom {
     uint32_t n_guides, n_pat;
@@ -121,6 +123,29 @@ struct ItemGeom {
     uint32_t n_part;
     uint32_t item_base;      // first CSR slot of this image (the two images share the item array)
 };
+
+// exclusive scan over the 1024 threads of a block (16 waves)
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *lds /* >= 16 */, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kPartThreads / 64; ++w) {
+        const uint32_t s = lds[w];
+        if ((uint32_t)w < wave) off += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return off + incl - v;
+}
 
 template <bool WRITE>
 __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
@@ -156,16 +181,20 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     }
 }
 
+// One block per partition.  The partition's candidate ids are put in bucket order inside LDS and leave as one
+// contiguous, coalesced copy: scattering 4-byte stores straight to memory costs a partial-line write-back each once the
+// concurrently open output windows exceed the L2 (1.1 ms for the 5.3e7 entries of the hg38-scale prefix image).
 __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
                                                            uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid) {
-    __shared__ uint32_t cnt[1 << kMaxPartBits];
-    __shared__ uint32_t scan_lds[8];
+    __shared__ uint32_t cnt[1 << kMaxLowBits];
+    __shared__ uint32_t stage[kBinStage];
+    __shared__ uint32_t scan_lds[16];
     const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits;
     for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
     __syncthreads();
     const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
     const uint32_t *__restrict__ src = part_items + p0;
-    constexpr int kU = 8;  // records in flight per thread (the loop is latency-bound otherwise)
+    constexpr int kU = 4;  // records in flight per thread
     for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
         uint32_t r[kU];
 #pragma unroll
@@ -174,13 +203,13 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
         for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[r[u] >> kGidBits], 1u);
     }
     __syncthreads();
-    // exclusive scan of the nlow counters: every thread owns nlow / 256 consecutive ones
+    // exclusive scan of the nlow counters: every thread owns nlow / 1024 consecutive ones (at most 2)
     const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
     uint32_t mine = 0;
     for (uint32_t k = 0; k < per; ++k)
         if (l0 + k < nlow) mine += cnt[l0 + k];
     uint32_t tot;
-    uint32_t off = block_exclusive_scan<uint32_t>(mine, scan_lds, tot);
+    uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
     const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
     for (uint32_t k = 0; k < per; ++k)
         if (l0 + k < nlow) {
@@ -191,6 +220,7 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
         }
     if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
     __syncthreads();
+    const bool staged = n <= (uint32_t)kBinStage;
     for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
         uint32_t r[kU];
 #pragma unroll
@@ -199,9 +229,14 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
         for (int u = 0; u < kU; ++u)
             if (k0 + u * kPartThreads + threadIdx.x < n) {
                 const uint32_t pos = atomicAdd(&cnt[r[u] >> kGidBits], 1u);
-                item_gid[gbase + pos] = r[u] & ((1u << kGidBits) - 1u);
+                const uint32_t gid = r[u] & ((1u << kGidBits) - 1u);
+                if (staged) stage[pos] = gid;
+                else item_gid[gbase + pos] = gid;
             }
     }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) item_gid[gbase + k] = stage[k];
 }
 
 constexpr int kTileTargets = 256;  // targets per work item (a bucket, or a 256-target slice of a large bucket)
