@@ -162,6 +162,23 @@ def main():
         except Exception:
             pmc = None
 
+    # device copy rate measured in the same run (SURVEY.md section 8d asks for the roofline fraction against it too)
+    stream_gbps = None
+    if rank == 0:
+        a = torch.empty(1 << 27, dtype=torch.int64, device=dev).random_()
+        b = torch.empty_like(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(4):
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        stream_gbps = 2 * a.numel() * 8 / (best * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+
     def step():
         ctx.scan(guides_np, args.max_mismatch)
         prior = None
@@ -228,7 +245,8 @@ def main():
                        "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "ffh::k_compare", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
-                         "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3)},
+                         "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3),
+                         "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
             "cpu_baseline": cpu,
             "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
             "discover_wall_s": dt / args.steps,
