@@ -18,7 +18,7 @@ FINALIZE_SUMMARIES_ONLY = 1
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
-    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
+    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
@@ -42,6 +42,14 @@ class DbInfo(C.Structure):
     _fields_ = [("n_targets", C.c_uint64), ("n_positions", C.c_uint64), ("n_bins", C.c_uint32), ("bin_begin", C.c_uint32),
                 ("bin_end", C.c_uint32), ("enzyme_index", C.c_int), ("prefix_bases", C.c_int), ("suffix_bases", C.c_int),
                 ("prepare_ms", C.c_double)]
+
+
+class LoadStats(C.Structure):
+    _fields_ = [("open_ms", C.c_double), ("inflate_ms", C.c_double), ("decode_ms", C.c_double), ("prepare_ms", C.c_double),
+                ("compressed_bytes", C.c_uint64), ("raw_bytes", C.c_uint64), ("threads", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 class Timings(C.Structure):
@@ -93,6 +101,7 @@ def load_library(build=True):
     L.ffh_db_bin_bytes.restype = C.c_uint64
     L.ffh_db_bin_bytes.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_db_info_get.argtypes = [C.c_void_p, C.POINTER(DbInfo)]
+    L.ffh_db_load_stats.argtypes = [C.c_void_p, C.POINTER(LoadStats)]
     L.ffh_db_contig.restype = C.c_char_p
     L.ffh_db_contig.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -236,6 +245,11 @@ class Context:
         i = DbInfo()
         self._check(self.L.ffh_db_info_get(self.h, C.byref(i)))
         return i
+
+    def load_stats(self):
+        st = LoadStats()
+        self._check(self.L.ffh_db_load_stats(self.h, C.byref(st)))
+        return st
 
     def contigs(self):
         out, i = [], 1

@@ -4,10 +4,12 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -17,6 +19,7 @@
 
 #include "../../include/flashfry_hip.h"
 #include "ffh_dbfile.hpp"
+#include "ffh_ingest.hpp"
 #include "ffh_kernels.hpp"
 #include "cfd_table.inc"
 
@@ -147,6 +150,7 @@ struct ffh_ctx {
     std::vector<uint64_t> bin_bytes;
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
     double db_prepare_ms = 0;
+    ffh_load_stats load{};
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
@@ -465,17 +469,110 @@ int ffh_db_load_soa(ffh_ctx *ctx, const uint64_t *targets, uint64_t n_targets, c
     return prepare_database(ctx);
 }
 
+// raw bin payloads already on the device -> ctx->targets / ctx->positions (ffh_ingest.hpp), then the scan images
+static int decode_blocks_on_device(ffh_ctx *ctx, const int64_t *d_raw, const std::vector<uint64_t> &bin_off, const std::vector<uint64_t> &bin_len) {
+    const uint32_t nb = (uint32_t)bin_off.size();
+    hipStream_t st = ctx->st;
+    DevBuf<uint64_t> d_off, d_pbase, d_scr64;
+    DevBuf<uint32_t> d_hdr, d_plen, d_marks, d_rank, d_scr32;
+    struct Guard {
+        std::function<void()> f;
+        ~Guard() { f(); }
+    } guard{[&]() { d_off.release(); d_pbase.release(); d_scr64.release(); d_hdr.release(); d_plen.release(); d_marks.release(); d_rank.release(); d_scr32.release(); }};
+    std::vector<uint64_t> ends(nb + 1, 0);  // the kernels take off[b] .. off[b + 1]: the bins must lie back to back, as DatabaseWriter.scala:75-92 writes them
+    for (uint32_t b = 0; b < nb; ++b) {
+        ends[b] = bin_off[b];
+        if (b + 1 < nb && bin_off[b] + bin_len[b] != bin_off[b + 1]) { ctx->err = "bin payloads are not stored back to back"; return FFH_E_FORMAT; }
+    }
+    ends[nb] = nb ? bin_off[nb - 1] + bin_len[nb - 1] : 0;
+    FFH_HIP(d_off.reserve(nb + 1));
+    FFH_HIP(d_pbase.reserve(nb + 2));
+    FFH_HIP(d_scr64.reserve(scan_scratch_elems_safe(nb + 1)));
+    FFH_HIP(d_hdr.reserve(nb + 1));
+    FFH_HIP(d_plen.reserve(nb + 8));
+    unsigned long long *d_err = ctx->d_counters + 10;
+    FFH_HIP(hipMemcpyAsync(d_off.p, ends.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, st));
+    FFH_HIP(hipMemsetAsync(d_err, 0xFF, 8, st));
+    FFH_HIP(hipMemsetAsync(d_plen.p, 0, (size_t)(nb + 8) * 4, st));
+    if (nb) hipLaunchKernelGGL(k_block_heads, dim3(blocks_for(nb, 256)), dim3(256), 0, st, d_raw, d_off.p, nb, d_hdr.p, d_plen.p, d_err);
+    exclusive_scan<uint32_t, uint64_t>(d_plen.p, nb, d_pbase.p, d_scr64.p, st);
+    unsigned long long herr = ~0ull;
+    uint64_t n_payload = 0;
+    auto report = [&](unsigned long long key) -> int {
+        const uint32_t bin = (uint32_t)(key >> 36), code = (uint32_t)(key & 15u);
+        switch (code) {
+            case kBlkEmpty: ctx->err = "empty block for bin " + std::to_string(bin); break;
+            case kBlkShortTable: ctx->err = "indexed block shorter than its lookup table"; break;
+            case kBlkNotContiguous: ctx->err = "indexed block: sub-bin table is not contiguous"; break;
+            case kBlkSliceRange: ctx->err = "indexed block: sub-bin slice out of range"; break;
+            case kBlkCover: ctx->err = "indexed block: sub-bin sizes do not cover the payload"; break;
+            case kBlkType: {
+                int64_t type = 0;
+                (void)hipMemcpy(&type, d_raw + ends[bin], 8, hipMemcpyDeviceToHost);
+                ctx->err = "Invalid bin type, unknown value: " + std::to_string((long long)type);  // BlockManager.scala:85-87
+                break;
+            }
+            case kBlkCount: ctx->err = "Encoded position count should be greater than zero"; break;  // :232-233
+            default: ctx->err = "Failed to correctly parse block, the number of position entries exceeds the buffer size"; break;  // :235-236
+        }
+        return FFH_E_FORMAT;
+    };
+    FFH_HIP(hipMemcpyAsync(&n_payload, d_pbase.p + nb, 8, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));  // bins with a bad header have no payload; the walk still visits the others so that the FIRST bad bin is reported
+    if (n_payload >= (1ull << 32) - 64) { ctx->err = "more than 2^32 payload longs in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
+    FFH_HIP(d_marks.reserve(n_payload + 8));
+    FFH_HIP(d_rank.reserve(n_payload + 8));
+    FFH_HIP(d_scr32.reserve(scan_scratch_elems_safe(n_payload + 1)));
+    FFH_HIP(hipMemsetAsync(d_marks.p, 0, (size_t)(n_payload + 8) * 4, st));
+    if (nb) hipLaunchKernelGGL(k_block_walk, dim3(nb), dim3(256), 0, st, d_raw, d_off.p, nb, d_hdr.p, d_plen.p, d_pbase.p, d_marks.p, d_err);
+    exclusive_scan<uint32_t, uint32_t>(d_marks.p, n_payload, d_rank.p, d_scr32.p, st);
+    uint32_t nt = 0;
+    FFH_HIP(hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipMemcpyAsync(&nt, d_rank.p + n_payload, 4, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));
+    if (herr != ~0ull) return report(herr);
+    ctx->T = nt;
+    ctx->P = n_payload - nt;
+    FFH_HIP(ctx->targets.reserve(ctx->T + 1));
+    FFH_HIP(ctx->positions.reserve(ctx->P + 1));
+    if (n_payload)
+        hipLaunchKernelGGL(k_block_split, dim3(blocks_for(n_payload, 256)), dim3(256), 0, st, d_raw, d_off.p, nb, d_hdr.p, d_pbase.p, d_rank.p, n_payload,
+                           ctx->targets.p, ctx->positions.p);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(st));
+    return FFH_OK;
+}
+
 int ffh_db_load_blocks(ffh_ctx *ctx, const int64_t *longs, const uint64_t *bin_offsets, uint32_t n_bins) {
     if (!ctx || !longs || !bin_offsets) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
-    std::vector<uint64_t> t, p;
-    const std::string e = decode_blocks(longs, bin_offsets, n_bins, t, p);
-    if (!e.empty()) { ctx->err = e; return FFH_E_FORMAT; }
+    if (ctx->enzyme == 0) { ctx->err = "the context has no enzyme yet: create it with an enzyme index or open a database file"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> off(bin_offsets, bin_offsets + n_bins), len(n_bins);
+    for (uint32_t b = 0; b < n_bins; ++b) {
+        if (bin_offsets[b + 1] < bin_offsets[b]) { ctx->err = "bin offsets must not decrease"; return FFH_E_ARG; }
+        len[b] = bin_offsets[b + 1] - bin_offsets[b];
+        off[b] -= bin_offsets[0];
+    }
+    const uint64_t n_longs = n_bins ? bin_offsets[n_bins] - bin_offsets[0] : 0;
+    DevBuf<int64_t> d_raw;
+    FFH_HIP(d_raw.reserve(n_longs + 1));
+    if (n_longs) FFH_HIP(hipMemcpyAsync(d_raw.p, longs + bin_offsets[0], n_longs * 8, hipMemcpyHostToDevice, ctx->st));
+    const auto t1 = std::chrono::steady_clock::now();
+    int rc = decode_blocks_on_device(ctx, d_raw.p, off, len);
+    d_raw.release();
+    if (rc) return rc;
+    ctx->load = ffh_load_stats{};
+    ctx->load.raw_bytes = n_longs * 8;
+    ctx->load.inflate_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    ctx->load.decode_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     ctx->n_bins = n_bins; ctx->bin_begin = 0; ctx->bin_end = n_bins;
-    return ffh_db_load_soa(ctx, t.data(), t.size(), p.data(), p.size(), 0);
+    return prepare_database(ctx);
 }
 
 int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t bin_end) {
     if (!ctx || !db_path) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    const auto t0 = std::chrono::steady_clock::now();
     DbHeader h;
     std::string e = read_db_header(std::string(db_path) + ".header", h);
     if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
@@ -486,15 +583,43 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
         return FFH_E_ARG;
     }
     if (bin_end == 0 || bin_end > h.n_bins) bin_end = h.n_bins;
-    std::vector<int64_t> longs;
-    std::vector<uint64_t> offs;
-    e = read_db_bins(db_path, h, bin_begin, bin_end, longs, offs);
+    FFH_HIP(hipSetDevice(ctx->device));
+    BodyFile body;
+    std::vector<uint64_t> off, len;
+    uint64_t need_lo = 0, need_hi = 0;
+    e = open_body(db_path, body);
+    if (e.empty()) e = locate_bins(body, h, bin_begin, bin_end, need_lo, need_hi, off, len);
     if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
+    const auto t1 = std::chrono::steady_clock::now();
+    DevBuf<int64_t> d_raw;
+    FFH_HIP(d_raw.reserve((need_hi - need_lo) / 8 + 1));
+    IngestStats is;
+    e = inflate_to_device(body, need_lo, need_hi, (uint8_t *)d_raw.p, ctx->device, is);
+    if (!e.empty()) { d_raw.release(); ctx->err = e; return FFH_E_FORMAT; }
+    const auto t2 = std::chrono::steady_clock::now();
+    int rc = decode_blocks_on_device(ctx, d_raw.p, off, len);
+    d_raw.release();
+    if (rc) return rc;
+    const auto t3 = std::chrono::steady_clock::now();
     ctx->contigs = h.contigs;
     ctx->bin_bytes = h.uncompressed_bytes;
-    int rc = ffh_db_load_blocks(ctx, longs.data(), offs.data(), bin_end - bin_begin);
+    ctx->load = ffh_load_stats{};
+    ctx->load.open_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    ctx->load.inflate_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    ctx->load.decode_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    ctx->load.compressed_bytes = is.compressed_bytes;
+    ctx->load.raw_bytes = is.raw_bytes;
+    ctx->load.threads = is.threads;
+    rc = prepare_database(ctx);
     ctx->n_bins = h.n_bins; ctx->bin_begin = bin_begin; ctx->bin_end = bin_end;
     return rc;
+}
+
+int ffh_db_load_stats(const ffh_ctx *ctx, ffh_load_stats *out) {
+    if (!ctx || !out) return FFH_E_ARG;
+    *out = ctx->load;
+    out->prepare_ms = ctx->db_prepare_ms;
+    return FFH_OK;
 }
 
 int ffh_db_open_header(ffh_ctx *ctx, const char *db_path) {

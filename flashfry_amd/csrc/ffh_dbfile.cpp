@@ -1,13 +1,21 @@
-// ffh_dbfile.cpp -- see ffh_dbfile.hpp.  Host C++ only (zlib + std::thread).
+// ffh_dbfile.cpp -- see ffh_dbfile.hpp.  Host side of the ingest: header parse, BGZF member directory, parallel
+// inflate into page-locked buffers with the copies to the device overlapped (zlib + std::thread + HIP streams).
 #include "ffh_dbfile.hpp"
 
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <thread>
 
 namespace ffh {
@@ -56,43 +64,53 @@ std::string read_db_header(const std::string &path, DbHeader &h) {  // BinaryHea
     return "";
 }
 
-struct Member { size_t coff, clen_total, cdata_off, cdata_len; uint32_t isize, crc; uint64_t uoff; };
+BodyFile::~BodyFile() {
+    if (data && data != (const uint8_t *)MAP_FAILED) munmap((void *)data, size);
+    if (fd >= 0) close(fd);
+}
 
-std::string read_db_bins(const std::string &path, const DbHeader &h, uint32_t b0, uint32_t b1, std::vector<int64_t> &longs,
-                         std::vector<uint64_t> &offs) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) return "cannot open database " + path;
-    std::fseek(f, 0, SEEK_END);
-    const long fsz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> raw((size_t)fsz);
-    if (fsz && std::fread(raw.data(), 1, (size_t)fsz, f) != (size_t)fsz) { std::fclose(f); return "short read on " + path; }
-    std::fclose(f);
-    // pass 1: walk the members (each carries its own compressed and uncompressed size)
-    std::vector<Member> ms;
-    uint64_t utotal = 0;
-    for (size_t off = 0; off + 18 <= (size_t)fsz;) {
-        const uint8_t *p = raw.data() + off;
+std::string open_body(const std::string &path, BodyFile &bf) {
+    bf.fd = open(path.c_str(), O_RDONLY);
+    if (bf.fd < 0) return "cannot open database " + path;
+    struct stat sb;
+    if (fstat(bf.fd, &sb) != 0) return "cannot stat database " + path;
+    bf.size = (size_t)sb.st_size;
+    if (bf.size) {
+        void *m = mmap(nullptr, bf.size, PROT_READ, MAP_PRIVATE, bf.fd, 0);
+        if (m == MAP_FAILED) { bf.data = nullptr; return "cannot map database " + path; }
+        bf.data = (const uint8_t *)m;
+        (void)madvise(m, bf.size, MADV_WILLNEED);
+    }
+    // walk the members: each carries its own compressed and uncompressed size (SAM spec 4.1: gzip member, 'BC' extra subfield)
+    for (size_t off = 0; off + 18 <= bf.size;) {
+        const uint8_t *p = bf.data + off;
         if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return "bad BGZF member in " + path;
         const int xlen = p[10] | (p[11] << 8);
         int bsize = -1;
-        for (int x = 0; x + 4 <= xlen;) {
-            const uint8_t *s = p + 12 + x;
-            const int slen = s[2] | (s[3] << 8);
-            if (s[0] == 'B' && s[1] == 'C' && slen == 2) bsize = (s[4] | (s[5] << 8)) + 1;
+        for (int x = 0; x + 4 <= xlen && off + 12 + (size_t)x + 6 <= bf.size;) {
+            const uint8_t *sf = p + 12 + x;
+            const int slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) bsize = (sf[4] | (sf[5] << 8)) + 1;
             x += 4 + slen;
         }
-        if (bsize < 0 || off + (size_t)bsize > (size_t)fsz) return "BGZF member without BC subfield in " + path;
+        if (bsize < 12 + xlen + 8 || off + (size_t)bsize > bf.size) return "BGZF member without BC subfield in " + path;
         Member m;
-        m.coff = off; m.clen_total = (size_t)bsize; m.cdata_off = off + 12 + (size_t)xlen; m.cdata_len = (size_t)bsize - 12 - (size_t)xlen - 8;
+        m.cdata_off = off + 12 + (size_t)xlen; m.cdata_len = (size_t)bsize - 12 - (size_t)xlen - 8;
         std::memcpy(&m.crc, p + bsize - 8, 4);
         std::memcpy(&m.isize, p + bsize - 4, 4);
-        m.uoff = utotal;
-        utotal += m.isize;
-        ms.push_back(m);
+        if (m.isize > 65536) return "BGZF member larger than 64 KiB in " + path;
+        m.coff = off;
+        m.uoff = bf.utotal;
+        bf.utotal += m.isize;
+        bf.members.push_back(m);
         off += (size_t)bsize;
     }
-    // which uncompressed range do we need?
+    return "";
+}
+
+std::string locate_bins(const BodyFile &bf, const DbHeader &h, uint32_t b0, uint32_t b1, uint64_t &need_lo, uint64_t &need_hi,
+                        std::vector<uint64_t> &bin_off, std::vector<uint64_t> &bin_len) {
+    const std::vector<Member> &ms = bf.members;
     auto linear = [&](uint64_t vptr, uint64_t &out) -> bool {  // BlockCompressedInputStream.seek(virtual pointer)
         const uint64_t c = vptr >> 16, within = vptr & 0xffff;
         size_t lo = 0, hi = ms.size();
@@ -103,99 +121,106 @@ std::string read_db_bins(const std::string &path, const DbHeader &h, uint32_t b0
     };
     if (b1 == 0 || b1 > h.n_bins) b1 = h.n_bins;
     if (b0 > b1) return "bad bin range";
-    std::vector<uint64_t> lin(b1 - b0);
-    uint64_t need_lo = UINT64_MAX, need_hi = 0, total_longs = 0;
+    bin_off.assign(b1 - b0, 0);
+    bin_len.assign(b1 - b0, 0);
+    need_lo = UINT64_MAX; need_hi = 0;
     for (uint32_t b = b0; b < b1; ++b) {
         if (h.uncompressed_bytes[b] % 8) return "bin size is not a multiple of 8";
-        if (!linear(h.virtual_offset[b], lin[b - b0])) return "bin pointer does not address a BGZF member";
-        if (lin[b - b0] + h.uncompressed_bytes[b] > utotal) return "bin runs past the end of the database";
-        need_lo = std::min(need_lo, lin[b - b0]);
-        need_hi = std::max(need_hi, lin[b - b0] + h.uncompressed_bytes[b]);
-        total_longs += h.uncompressed_bytes[b] / 8;
+        uint64_t lin = 0;
+        if (!linear(h.virtual_offset[b], lin)) return "bin pointer does not address a BGZF member";
+        if (lin + h.uncompressed_bytes[b] > bf.utotal) return "bin runs past the end of the database";
+        bin_off[b - b0] = lin;
+        bin_len[b - b0] = h.uncompressed_bytes[b] / 8;
+        need_lo = std::min(need_lo, lin);
+        need_hi = std::max(need_hi, lin + h.uncompressed_bytes[b]);
     }
-    if (b1 == b0) { longs.clear(); offs.assign(1, 0); return ""; }
-    // pass 2: inflate the members that overlap [need_lo, need_hi) in parallel
-    std::vector<uint8_t> data((size_t)(need_hi - need_lo));
-    std::atomic<size_t> next_member(0);
+    if (b1 == b0) { need_lo = need_hi = 0; return ""; }
+    for (auto &o : bin_off) {
+        if ((o - need_lo) % 8) return "bin payloads are not 8-byte aligned to each other";
+        o = (o - need_lo) / 8;
+    }
+    return "";
+}
+
+// Members are independent deflate streams: every host thread inflates groups of consecutive members into its own
+// page-locked buffers and queues the copy to the device on its own stream, so inflate, PCIe and the next inflate overlap.
+std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats) {
+    const std::vector<Member> &ms = bf.members;
+    stats.threads = 0; stats.compressed_bytes = 0; stats.raw_bytes = need_hi - need_lo;
+    if (need_hi <= need_lo) return "";
+    size_t m0 = 0, m1 = ms.size();
+    {   // members overlapping [need_lo, need_hi)
+        size_t lo = 0, hi = ms.size();
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff + ms[mid].isize <= need_lo) lo = mid + 1; else hi = mid; }
+        m0 = lo;
+        lo = m0; hi = ms.size();
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff < need_hi) lo = mid + 1; else hi = mid; }
+        m1 = lo;
+    }
+    constexpr size_t kGroup = 64;                 // members per chunk: <= 4 MiB of payload
+    constexpr size_t kChunkBytes = kGroup * 65536;
+    const size_t nchunks = (m1 - m0 + kGroup - 1) / kGroup;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("FFH_LOAD_THREADS")) { const long v = std::atol(e); if (v > 0) nthreads = (unsigned)v; }
+    nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(nthreads ? nthreads : 1, 128u), nchunks));
+    stats.threads = nthreads;
+    for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26;
+    std::atomic<size_t> next_chunk(0);
     std::atomic<int> failed(0);
+    std::mutex err_mu;
+    std::string err;
+    auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> g(err_mu); if (err.empty()) err = m; failed = 1; };
     auto worker = [&]() {
-        std::vector<uint8_t> tmp(65536 + 64);
-        for (;;) {
-            const size_t i = next_member.fetch_add(1);
-            if (i >= ms.size()) break;
-            const Member &m = ms[i];
-            if (m.isize == 0 || m.uoff + m.isize <= need_lo || m.uoff >= need_hi) continue;
-            z_stream zs;
-            std::memset(&zs, 0, sizeof zs);
-            inflateInit2(&zs, -15);
-            zs.next_in = raw.data() + m.cdata_off; zs.avail_in = (uInt)m.cdata_len;
-            zs.next_out = tmp.data(); zs.avail_out = (uInt)tmp.size();
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.total_out != m.isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), tmp.data(), m.isize) != m.crc) { failed = 1; continue; }
-            const uint64_t s = std::max<uint64_t>(m.uoff, need_lo), e = std::min<uint64_t>(m.uoff + m.isize, need_hi);
-            std::memcpy(data.data() + (s - need_lo), tmp.data() + (s - m.uoff), (size_t)(e - s));
+        if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed in a loader thread"); return; }
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        uint8_t *buf[2] = {nullptr, nullptr};
+        bool used[2] = {false, false};
+        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) {
+            he = hipHostMalloc((void **)&buf[i], kChunkBytes, hipHostMallocDefault);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
         }
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        const bool zok = inflateInit2(&zs, -15) == Z_OK;
+        if (he != hipSuccess || !zok) fail(std::string("loader thread set-up failed: ") + (zok ? hipGetErrorString(he) : "zlib"));
+        int slot = 0;
+        while (!failed) {
+            const size_t c = next_chunk.fetch_add(1);
+            if (c >= nchunks) break;
+            if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { fail("copy to the device failed"); break; }
+            const size_t a = m0 + c * kGroup, b = std::min(m1, a + kGroup);
+            const uint64_t u0 = ms[a].uoff, u1 = ms[b - 1].uoff + ms[b - 1].isize;
+            for (size_t i = a; i < b && !failed; ++i) {
+                const Member &m = ms[i];
+                if (m.isize == 0) continue;
+                inflateReset(&zs);
+                zs.next_in = const_cast<Bytef *>(bf.data + m.cdata_off); zs.avail_in = (uInt)m.cdata_len;
+                zs.next_out = buf[slot] + (m.uoff - u0); zs.avail_out = (uInt)m.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.total_out != m.isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf[slot] + (m.uoff - u0), m.isize) != m.crc)
+                    fail("BGZF inflate / crc failure in the database body");
+            }
+            if (failed) break;
+            const uint64_t s = std::max(u0, need_lo), e = std::min(u1, need_hi);
+            if (e > s) {
+                if (hipMemcpyAsync(d_raw + (s - need_lo), buf[slot] + (s - u0), (size_t)(e - s), hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipEventRecord(ev[slot], st) != hipSuccess) { fail("copy to the device failed"); break; }
+                used[slot] = true;
+                slot ^= 1;
+            }
+        }
+        if (st && hipStreamSynchronize(st) != hipSuccess) fail("copy to the device failed");
+        if (zok) inflateEnd(&zs);
+        for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (buf[i]) (void)hipHostFree(buf[i]); }
+        if (st) (void)hipStreamDestroy(st);
     };
-    unsigned nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
     worker();
     for (auto &t : pool) t.join();
-    if (failed) return "BGZF inflate / crc failure in " + path;
-    // bytes -> longs in native (little-endian) order, utils/Utils.scala:167-186
-    longs.resize((size_t)total_longs);
-    offs.assign((size_t)(b1 - b0) + 1, 0);
-    uint64_t w = 0;
-    for (uint32_t b = b0; b < b1; ++b) {
-        offs[b - b0] = w;
-        std::memcpy(longs.data() + w, data.data() + (lin[b - b0] - need_lo), (size_t)h.uncompressed_bytes[b]);
-        w += h.uncompressed_bytes[b] / 8;
-    }
-    offs[b1 - b0] = w;
-    return "";
-}
-
-std::string decode_blocks(const int64_t *longs, const uint64_t *offs, uint32_t n_bins, std::vector<uint64_t> &targets,
-                          std::vector<uint64_t> &positions) {
-    const int kSub = 256;  // 4^4 sub-bins, BlockManager.scala:40-49
-    for (uint32_t b = 0; b < n_bins; ++b) {
-        const int64_t *blk = longs + offs[b];
-        uint64_t n = offs[b + 1] - offs[b];
-        if (n == 0) return "empty block for bin " + std::to_string(b);  // BlockManager.scala:72 would fail
-        const int64_t type = blk[0];
-        ++blk; --n;
-        if (type == 2) {  // indexed: validate the table the way compareIndexedBlock walks it (:160-170), then the payload is contiguous
-            if (n < (uint64_t)kSub) return "indexed block shorter than its lookup table";
-            long long last_pos = 0, last_size = 0;
-            uint64_t covered = 0;
-            for (int i = 0; i < kSub; ++i) {
-                const int pos = (int)(blk[i] >> 32);
-                const int size = (int)((int64_t)((uint64_t)blk[i] << 32) >> 32);
-                if (last_pos != 0 && pos >= 0 && pos != last_pos + last_size) return "indexed block: sub-bin table is not contiguous";
-                last_pos = pos > 0 ? pos : 0;
-                last_size = size;
-                if (pos >= 0 && size > 0) {
-                    if ((uint64_t)pos + (uint64_t)size > n - kSub) return "indexed block: sub-bin slice out of range";
-                    covered += (uint64_t)size;
-                }
-            }
-            if (covered != n - kSub) return "indexed block: sub-bin sizes do not cover the payload";
-            blk += kSub; n -= kSub;
-        } else if (type != 1) {
-            return "Invalid bin type, unknown value: " + std::to_string((long long)type);  // :85-87
-        }
-        for (uint64_t off = 0; off < n;) {  // compareLinearBlock :225-252
-            const uint64_t t = (uint64_t)blk[off];
-            const int count = (int)(int16_t)(t >> 48);
-            if (count <= 0) return "Encoded position count should be greater than zero";
-            if (n < off + (uint64_t)count + 1) return "Failed to correctly parse block, the number of position entries exceeds the buffer size";
-            targets.push_back(t);
-            for (int k = 0; k < count; ++k) positions.push_back((uint64_t)blk[off + 1 + k]);
-            off += (uint64_t)count + 1;
-        }
-    }
-    return "";
+    return failed ? err : "";
 }
 
 }  // namespace ffh

@@ -1,8 +1,8 @@
 // ffh_dbfile.hpp -- host-side reader of FlashFry's on-disk off-target database for the HIP library:
 // text "<db>.header" (reference/binary/BinaryHeader.scala:69-160) + BGZF body written bin by bin
-// (reference/binary/DatabaseWriter.scala:58-111), and the decoder of bin payloads into structure-of-arrays
-// (the walk of BlockManager.compareLinearBlock / compareIndexedBlock, blocks/BlockManager.scala:143-254,
-// without the comparisons).  BGZF members are independent, so they are inflated on all host cores.
+// (reference/binary/DatabaseWriter.scala:58-111; read side SeekTraverser.scala:113-120, LinearTraverser.scala:122-130).
+// BGZF members are independent, so they are inflated on all host cores, straight into page-locked staging buffers
+// whose copies to the device overlap the next inflate.  The bin payloads are decoded on the device (ffh_ingest.hpp).
 #pragma once
 #include <stdint.h>
 
@@ -24,12 +24,38 @@ struct DbHeader {
 // returns "" on success, else the error message
 std::string read_db_header(const std::string &header_path, DbHeader &out);
 
-// inflates the body and returns the payload longs of bins [bin_begin, bin_end) concatenated, plus offsets (in longs)
-std::string read_db_bins(const std::string &body_path, const DbHeader &h, uint32_t bin_begin, uint32_t bin_end,
-                         std::vector<int64_t> &longs, std::vector<uint64_t> &bin_offsets);
+// one BGZF member (gzip member with a 'BC' extra subfield, <= 64 KiB of payload)
+struct Member {
+    size_t coff, cdata_off, cdata_len;  // file offset of the member / of its deflate stream
+    uint32_t isize, crc;
+    uint64_t uoff;                      // offset of its payload in the uncompressed stream
+};
 
-// decodes concatenated bin payloads into targets[] / positions[] (database order)
-std::string decode_blocks(const int64_t *longs, const uint64_t *bin_offsets, uint32_t n_bins, std::vector<uint64_t> &targets,
-                          std::vector<uint64_t> &positions);
+struct BodyFile {  // the memory-mapped BGZF body and its member directory
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    std::vector<Member> members;
+    uint64_t utotal = 0;
+    BodyFile() = default;
+    BodyFile(const BodyFile &) = delete;
+    BodyFile &operator=(const BodyFile &) = delete;
+    ~BodyFile();
+};
+
+struct IngestStats {
+    unsigned threads = 0;
+    uint64_t compressed_bytes = 0, raw_bytes = 0;
+};
+
+std::string open_body(const std::string &body_path, BodyFile &out);
+
+// where the payloads of bins [bin_begin, bin_end) lie: the byte range [need_lo, need_hi) of the uncompressed stream that
+// holds them, and per bin its offset (in longs, relative to need_lo) and length (in longs)
+std::string locate_bins(const BodyFile &bf, const DbHeader &h, uint32_t bin_begin, uint32_t bin_end, uint64_t &need_lo, uint64_t &need_hi,
+                        std::vector<uint64_t> &bin_off, std::vector<uint64_t> &bin_len);
+
+// inflates [need_lo, need_hi) of the uncompressed stream straight into device memory at d_raw
+std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats);
 
 }  // namespace ffh

@@ -156,7 +156,8 @@ std::vector<CRISPRSiteOT> readTabDelimited(const std::string &inputFile, const B
 struct ScanStats {
     uint64_t executedComparisons = 0;  // what the reference logs as Traverser.allComparisons (OffTargetDiscovery.scala:137)
     uint64_t targets = 0, positions = 0;
-    double loadMs = 0, scanMs = 0, finalizeMs = 0;
+    double createMs = 0, loadMs = 0, scanMs = 0, finalizeMs = 0;
+    ffh_load_stats load{};  // stages of loadMs on the first shard
     int gpus = 1;
 };
 class GpuTraverser {

@@ -114,6 +114,10 @@ int runDiscover(int argc, char **argv) {
     const ScanStats st = GpuTraverser::scan(db, guides, maxMismatch, maxOT, deviceList(o), positions);  // replaces :120-131
     std::fprintf(stderr, "Performed a total of %llu guide to target comparisons (%llu targets resident on %d GPU(s); load %.1f ms, scan %.1f ms, finalize %.1f ms)\n",
                  (unsigned long long)st.executedComparisons, (unsigned long long)st.targets, st.gpus, st.loadMs, st.scanMs, st.finalizeMs);
+    std::fprintf(stderr, "Database load: device set-up %.1f ms; header + member directory %.1f ms, inflate + copy %.1f ms (%u threads, %.1f MB -> %.1f MB), "
+                         "block decode %.1f ms, scan images %.1f ms\n",
+                 st.createMs, st.load.open_ms, st.load.inflate_ms, st.load.threads, st.load.compressed_bytes / 1e6, st.load.raw_bytes / 1e6, st.load.decode_ms,
+                 st.load.prepare_ms);
     std::fprintf(stderr, "Writing final output for %zu guides\n", guides.size());
     TabDelimitedOutput out(o.str("output"), bitCoder, posCoder, {}, true, positions);  // :141-146
     for (auto &g : guides) {

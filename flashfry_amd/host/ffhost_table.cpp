@@ -252,13 +252,17 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         for (auto &t : th) t.join();
         for (const auto &e : errs) if (!e.empty()) { cleanup(); throw Error(e); }
     };
-    auto t0 = clk::now();
+    auto tc = clk::now();
     parallel([&](size_t d) {
         ctx[d] = ffh_create(devices.empty() ? 0 : devices[d], 0);
-        if (!ctx[d]) { errs[d] = abiError(nullptr); return; }
+        if (!ctx[d]) errs[d] = abiError(nullptr);
+    });
+    auto t0 = clk::now();
+    parallel([&](size_t d) {
         if (ffh_db_open(ctx[d], binaryFile.c_str(), cut[d], cut[d + 1])) errs[d] = abiError(ctx[d]);
     });
     auto t1 = clk::now();
+    ffh_db_load_stats(ctx[0], &st.load);
     parallel([&](size_t d) {
         if (ffh_scan(ctx[d], longs.data(), (uint32_t)ng, maxMismatch)) { errs[d] = abiError(ctx[d]); return; }
         if (ffh_shard_totals(ctx[d], totals[d].data(), (uint32_t)std::max(maximumOffTargets, 0))) errs[d] = abiError(ctx[d]);
@@ -311,6 +315,7 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         st.targets += info.n_targets;
         st.positions += info.n_positions;
     }
+    st.createMs = std::chrono::duration<double, std::milli>(t0 - tc).count();
     st.loadMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
     st.scanMs = std::chrono::duration<double, std::milli>(t2 - t1).count();
     st.finalizeMs = std::chrono::duration<double, std::milli>(t3 - t2).count();

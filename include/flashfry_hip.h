@@ -103,6 +103,20 @@ typedef struct ffh_db_info {
     double prepare_ms;       /* device time spent building the scan images */
 } ffh_db_info;
 int ffh_db_info_get(const ffh_ctx *ctx, ffh_db_info *out);
+
+/* Where the time of the last ffh_db_open / ffh_db_load_blocks went (milliseconds of host wall time, stages in order). */
+typedef struct ffh_load_stats {
+    double open_ms;            /* header parse, mmap, BGZF member directory */
+    double inflate_ms;         /* parallel inflate into page-locked buffers with the copies to the device overlapped
+                                  (ffh_db_load_blocks: the host-to-device copy of the payload longs) */
+    double decode_ms;          /* bin payloads -> targets[] / positions[] on the device */
+    double prepare_ms;         /* scan images (= ffh_db_info.prepare_ms) */
+    uint64_t compressed_bytes; /* BGZF bytes inflated */
+    uint64_t raw_bytes;        /* payload bytes produced and copied to the device */
+    uint32_t threads;          /* host threads that inflated */
+    uint32_t reserved;
+} ffh_load_stats;
+int ffh_db_load_stats(const ffh_ctx *ctx, ffh_load_stats *out);
 /* contig names of the database header (1-based ids as in BitPosition.scala:38-49); NULL past the end */
 const char *ffh_db_contig(const ffh_ctx *ctx, uint32_t contig_id);
 

@@ -56,6 +56,58 @@ def test_blocks_loader_equals_soa_loader(capi, oracle):
     assert_same_scores(oracle, 2, g, a, ora)
 
 
+def test_device_block_decoder_refuses_malformed_payloads(capi, oracle):
+    """the bin payloads are decoded on the device (ffh_ingest.hpp); the checks of BlockManager.scala:72,85-87,160-170,232-236 hold there"""
+    odb, t, p, g = make_case(oracle, 20000, 50, enzyme=3, seed=5, max_linear=2)
+    longs, offs = odb.all_blocks()
+    with capi.Context(3) as ctx:
+        ctx.load_blocks(longs, offs)
+        info = ctx.info()
+        assert (info.n_targets, info.n_positions) == (len(t), len(p))
+        st = ctx.load_stats()
+        assert st.raw_bytes == 8 * len(longs) and st.decode_ms > 0
+    tgt = np.int64((int(oracle.encode("ACGTACGTACGTACGTACGTAGG")) & ((1 << 48) - 1)) | (2 << 48))
+    lin = np.array([1, tgt, 11, 12], dtype=np.int64)                         # one target with two positions
+    table = np.full(256, np.int64(-1) << np.int64(32), dtype=np.int64)       # pos = -1, size = 0 everywhere ...
+    table[27] = (0 << 32) | 3                                                # ... but sub-bin 27 holds the 3 payload longs
+    idx = np.concatenate([[2], table, lin[1:]]).astype(np.int64)
+
+    def load(blocks):
+        offs = np.zeros(len(blocks) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(b) for b in blocks])
+        with capi.Context(3) as ctx:
+            ctx.load_blocks(np.concatenate(blocks).astype(np.int64) if offs[-1] else np.zeros(1, np.int64), offs)
+            return ctx.info()
+
+    assert load([lin]).n_targets == 1 and load([lin]).n_positions == 2
+    assert load([idx, lin]).n_targets == 2 and load([idx, lin]).n_positions == 4
+    assert load([np.array([1], dtype=np.int64)]).n_targets == 0              # a bin without targets is a bare type long
+    cases = [
+        ([np.array([7, 1, 2], dtype=np.int64)], "Invalid bin type, unknown value: 7"),
+        ([np.zeros(0, dtype=np.int64)], "empty block for bin 0"),
+        ([lin, np.zeros(0, dtype=np.int64)], "empty block for bin 1"),
+        ([np.array([1, tgt & np.int64((1 << 48) - 1), 11], dtype=np.int64)], "Encoded position count should be greater than zero"),
+        ([lin[:3]], "exceeds the buffer size"),
+        ([idx[:100]], "shorter than its lookup table"),
+        ([idx[:-1]], "sub-bin slice out of range"),
+        ([np.concatenate([idx, [5]]).astype(np.int64)], "do not cover the payload"),
+        ([lin, lin[:3], np.array([9], dtype=np.int64)], "exceeds the buffer size"),    # the first bad bin in database order is reported
+        ([lin, np.array([9], dtype=np.int64), lin[:3]], "unknown value: 9"),
+    ]
+    two = table.copy()
+    two[27] = (0 << 32) | 2                                                  # the slice cuts the record in two
+    two[28] = (2 << 32) | 1
+    cases.append(([np.concatenate([[2], two, lin[1:]]).astype(np.int64)], "exceeds the buffer size"))
+    gap = table.copy()
+    gap[27] = (0 << 32) | 1
+    gap[28] = (1 << 32) | 1
+    gap[29] = (3 << 32) | 1                                                  # 1 + 1 != 3: compareIndexedBlock's contiguity assert (:167-168)
+    cases.append(([np.concatenate([[2], gap, lin[1:]]).astype(np.int64)], "not contiguous"))
+    for blocks, msg in cases:
+        with pytest.raises(capi.FlashFryHipError, match=msg):
+            load(blocks)
+
+
 @pytest.mark.parametrize("plan", [(8, 0), (8, 1), (8, 2), (8, 3), (8, 4), (10, 2), (11, 1), (12, 2), (9, 3)])
 def test_every_candidate_split_gives_the_same_hits(capi, oracle, plan):
     """the prefix/suffix ball split is an exact filter: any (width, radius) must reproduce the oracle's hit set"""
