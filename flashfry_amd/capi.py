@@ -18,7 +18,8 @@ FINALIZE_SUMMARIES_ONLY = 1
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
-    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
+    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
+    "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
@@ -47,6 +48,14 @@ class DbInfo(C.Structure):
 class LoadStats(C.Structure):
     _fields_ = [("open_ms", C.c_double), ("inflate_ms", C.c_double), ("decode_ms", C.c_double), ("prepare_ms", C.c_double),
                 ("compressed_bytes", C.c_uint64), ("raw_bytes", C.c_uint64), ("threads", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class IndexStats(C.Structure):
+    _fields_ = [("n_bases", C.c_uint64), ("n_sites", C.c_uint64), ("n_targets", C.c_uint64), ("n_positions", C.c_uint64),
+                ("n_contigs", C.c_uint32), ("reserved", C.c_uint32), ("scan_ms", C.c_double), ("sort_ms", C.c_double), ("write_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -102,6 +111,14 @@ def load_library(build=True):
     L.ffh_db_bin_bytes.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_db_info_get.argtypes = [C.c_void_p, C.POINTER(DbInfo)]
     L.ffh_db_load_stats.argtypes = [C.c_void_p, C.POINTER(LoadStats)]
+    L.ffh_indexer_create.restype = C.c_void_p
+    L.ffh_indexer_create.argtypes = [C.c_int, C.c_int]
+    L.ffh_indexer_destroy.argtypes = [C.c_void_p]
+    L.ffh_indexer_last_error.restype = C.c_char_p
+    L.ffh_indexer_last_error.argtypes = [C.c_void_p]
+    L.ffh_indexer_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64]
+    L.ffh_indexer_finish.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(IndexStats)]
+    L.ffh_db_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.ffh_db_contig.restype = C.c_char_p
     L.ffh_db_contig.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -184,6 +201,38 @@ class Result:
 
     def hsu2013(self):
         return (100.0 / (100.0 + self.summaries["hsu_sum"])) * 100.0
+
+
+def write_database(path, enzyme_index, targets, positions, contigs, bin_width=7):
+    """ffh_db_write: host arrays -> BGZF body + .header in the reference's format (no GPU involved)."""
+    L = load_library()
+    t = np.ascontiguousarray(targets).view(np.uint64)
+    p = np.ascontiguousarray(positions).view(np.uint64)
+    names = (C.c_char_p * max(len(contigs), 1))(*[c.encode() for c in contigs])
+    rc = L.ffh_db_write(str(path).encode(), enzyme_index, bin_width, names, len(contigs), t.ctypes.data, len(t), p.ctypes.data, len(p))
+    if rc:
+        raise FlashFryHipError(rc, L.ffh_last_error(None).decode())
+
+
+def index_contigs(path, enzyme_index, contigs, bin_width=7, device=0):
+    """ffh_indexer_*: [(name, sequence bytes/str)] -> database files; returns the IndexStats."""
+    L = load_library()
+    ix = L.ffh_indexer_create(device, enzyme_index)
+    if not ix:
+        raise FlashFryHipError(-7, L.ffh_last_error(None).decode())
+    try:
+        for name, seq in contigs:
+            b = seq.encode() if isinstance(seq, str) else bytes(seq)
+            rc = L.ffh_indexer_add_contig(ix, name.encode(), b, len(b))
+            if rc:
+                raise FlashFryHipError(rc, L.ffh_indexer_last_error(ix).decode())
+        st = IndexStats()
+        rc = L.ffh_indexer_finish(ix, str(path).encode(), bin_width, C.byref(st))
+        if rc:
+            raise FlashFryHipError(rc, L.ffh_indexer_last_error(ix).decode())
+        return st
+    finally:
+        L.ffh_indexer_destroy(ix)
 
 
 class Context:

@@ -26,6 +26,9 @@
 using namespace ffh;
 
 static std::string g_create_error;
+namespace ffh {
+void set_global_error(const std::string &m) { g_create_error = m; }
+}  // namespace ffh
 
 #define FFH_HIP(expr)                                                                                   \
     do {                                                                                                \
@@ -956,5 +959,181 @@ const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd; }
 const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { return r->pos_offsets; }
 const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions; }
 void ffh_result_free(ffh_result *r) { delete r; }
+
+}  // extern "C"
+
+// =====================================================================================================================
+// index on the device (ffh_index.hpp): sites -> sort -> unique targets + position lists -> ffh_db_write
+// =====================================================================================================================
+#include "ffh_index.hpp"
+
+struct ffh_indexer {
+    int device = 0, enzyme = 0;
+    hipStream_t st = nullptr;
+    SitePattern pat{};
+    std::string err;
+    std::vector<std::string> contigs;
+    DevBuf<uint8_t> seq;
+    DevBuf<uint32_t> blk_cnt;
+    DevBuf<uint64_t> blk_off, scan_tmp;
+    DevBuf<uint64_t> keys, pos;  // sites in discovery order
+    uint64_t n_sites = 0, n_bases = 0;
+    double scan_ms = 0;
+};
+
+static void site_pattern(int enzyme, SitePattern &p) {  // fwdRegex / revRegex, standards/StandardScanParameters.scala:104-211
+    const uint8_t A = 1, Cc = 2, G = 4, T = 8, N = 15;
+    const int L = enzyme == 1 ? 24 : (enzyme >= 5 ? 22 : 23);
+    p.len = L;
+    for (int k = 0; k < 24; ++k) { p.fwd[k] = 0; p.rev[k] = 0; }
+    for (int k = 0; k < L; ++k) { p.fwd[k] = N; p.rev[k] = N; }
+    switch (enzyme) {
+        case 1: p.fwd[0] = p.fwd[1] = p.fwd[2] = T; p.rev[L - 1] = p.rev[L - 2] = p.rev[L - 3] = A; break;      // TTTN...  /  ...NAAA (:209-211)
+        case 2: case 5: p.fwd[L - 2] = A | G; p.fwd[L - 1] = G; p.rev[0] = Cc; p.rev[1] = Cc | T; break;          // N[AG]G   /  C[CT]N (:104-106, :126-128)
+        case 3: case 6: p.fwd[L - 2] = G; p.fwd[L - 1] = G; p.rev[0] = Cc; p.rev[1] = Cc; break;                  // NGG      /  CCN   (:148-150, :170-172)
+        case 4: p.fwd[L - 2] = A; p.fwd[L - 1] = G; p.rev[0] = Cc; p.rev[1] = T; break;                            // NAG      /  CTN   (:192-194)
+    }
+}
+
+template <typename T>
+static hipError_t grow_keep(DevBuf<T> &b, size_t used, size_t need, hipStream_t st) {  // like reserve, but the first `used` elements survive
+    if (need <= b.cap) return hipSuccess;
+    DevBuf<T> nb;
+    hipError_t e = nb.reserve(std::max(need, b.cap + b.cap / 2));
+    if (e != hipSuccess) return e;
+    if (used) e = hipMemcpyAsync(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { nb.release(); return e; }
+    b.release();
+    b = nb;
+    return hipSuccess;
+}
+
+extern "C" {
+
+ffh_indexer *ffh_indexer_create(int device_id, int enzyme_index) {
+    if (enzyme_index < 1 || enzyme_index > 6) { g_create_error = "Unable to find the correct parameter pack for enzyme: " + std::to_string(enzyme_index); return nullptr; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device available (flashfry_hip has no CPU fallback)"; return nullptr; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return nullptr; }
+    ffh_indexer *ix = new (std::nothrow) ffh_indexer();
+    if (!ix) { g_create_error = "out of memory"; return nullptr; }
+    ix->device = device_id; ix->enzyme = enzyme_index;
+    site_pattern(enzyme_index, ix->pat);
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->st, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("HIP initialisation failed: ") + hipGetErrorString(e); delete ix; return nullptr; }
+    return ix;
+}
+
+void ffh_indexer_destroy(ffh_indexer *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->st) (void)hipStreamSynchronize(ix->st);
+    ix->seq.release(); ix->blk_cnt.release(); ix->blk_off.release(); ix->scan_tmp.release(); ix->keys.release(); ix->pos.release();
+    if (ix->st) (void)hipStreamDestroy(ix->st);
+    delete ix;
+}
+
+const char *ffh_indexer_last_error(const ffh_indexer *ix) { return ix ? ix->err.c_str() : g_create_error.c_str(); }
+
+int ffh_indexer_add_contig(ffh_indexer *ctx, const char *name, const char *sequence, uint64_t length) {
+    if (!ctx || !name || (length && !sequence)) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    if (length >= (1ull << 32)) { ctx->err = "contig longer than 2^32 bases: positions are 32-bit (BitPosition.scala:51-63)"; return FFH_E_ARG; }
+    if (ctx->contigs.size() >= (1u << 20) - 1) { ctx->err = "more than 2^20 contigs (BitPosition.scala:51-63)"; return FFH_E_ARG; }
+    ctx->contigs.emplace_back(name);
+    const uint32_t contig_id = (uint32_t)ctx->contigs.size();  // BitPosition.addReference: ids from 1 in order of appearance
+    ctx->n_bases += length;
+    if (length < (uint64_t)ctx->pat.len) return FFH_OK;
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t nb = (uint32_t)((length + kSiteTile - 1) / kSiteTile);
+    FFH_HIP(ctx->seq.reserve(length + 64));
+    FFH_HIP(ctx->blk_cnt.reserve(2 * (size_t)nb + 8));
+    FFH_HIP(ctx->blk_off.reserve(2 * (size_t)nb + 8));
+    FFH_HIP(ctx->scan_tmp.reserve(scan_scratch_elems_safe(2 * (uint64_t)nb)));
+    FFH_HIP(hipMemcpyAsync(ctx->seq.p, sequence, length, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_site_scan<false>, dim3(nb), dim3(kSiteThreads), 0, st, ctx->seq.p, length, ctx->pat, contig_id, nb, ctx->blk_cnt.p,
+                       (const uint64_t *)nullptr, 0ull, (uint64_t *)nullptr, (uint64_t *)nullptr);
+    exclusive_scan<uint32_t, uint64_t>(ctx->blk_cnt.p, 2 * (uint64_t)nb, ctx->blk_off.p, ctx->scan_tmp.p, st);
+    uint64_t found = 0;
+    FFH_HIP(hipMemcpyAsync(&found, ctx->blk_off.p + 2 * (size_t)nb, 8, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));
+    if (ctx->n_sites + found >= (1ull << 32) - 64) { ctx->err = "more than 2^32 target sites"; return FFH_E_ARG; }
+    if (found) {
+        FFH_HIP(grow_keep(ctx->keys, ctx->n_sites, ctx->n_sites + found, st));
+        FFH_HIP(grow_keep(ctx->pos, ctx->n_sites, ctx->n_sites + found, st));
+        hipLaunchKernelGGL(k_site_scan<true>, dim3(nb), dim3(kSiteThreads), 0, st, ctx->seq.p, length, ctx->pat, contig_id, nb, ctx->blk_cnt.p,
+                           (const uint64_t *)ctx->blk_off.p, ctx->n_sites, ctx->keys.p, ctx->pos.p);
+        FFH_HIP(hipGetLastError());
+        FFH_HIP(hipStreamSynchronize(st));
+        ctx->n_sites += found;
+    }
+    ctx->scan_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FFH_OK;
+}
+
+int ffh_indexer_finish(ffh_indexer *ctx, const char *db_path, int bin_width, ffh_index_stats *stats) {
+    if (!ctx || !db_path) { if (ctx) ctx->err = "null argument"; return FFH_E_ARG; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    const uint64_t S = ctx->n_sites;
+    const auto t0 = std::chrono::steady_clock::now();
+    DevBuf<uint64_t> alt_k, alt_v, d_targets, d_positions, d_posoff, scr64;
+    DevBuf<uint32_t> table, offs, scr32, head, rank, start, count;
+    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() {
+        alt_k.release(); alt_v.release(); d_targets.release(); d_positions.release(); d_posoff.release(); scr64.release();
+        table.release(); offs.release(); scr32.release(); head.release(); rank.release(); start.release(); count.release();
+    }};
+    std::vector<uint64_t> h_targets, h_positions;
+    uint64_t n_targets = 0, n_positions = 0;
+    if (S) {
+        // stable sort of (sequence, position) by sequence: CRISPRSite.compare = the bases (crispr/CRISPRSite.scala:44)
+        const uint32_t nb = sort_nblocks(S);
+        FFH_HIP(alt_k.reserve(S)); FFH_HIP(alt_v.reserve(S));
+        FFH_HIP(table.reserve((size_t)256 * nb + 8)); FFH_HIP(offs.reserve((size_t)256 * nb + 8));
+        FFH_HIP(scr32.reserve(scan_scratch_elems_safe(std::max<uint64_t>((uint64_t)256 * nb, S + 1))));
+        SortScratch ss;
+        ss.alt = alt_k.p; ss.val_alt = alt_v.p; ss.table = table.p; ss.offs = offs.p; ss.scan_tmp = scr32.p;
+        uint64_t *sk = nullptr, *sv = nullptr;
+        radix_sort_pairs(ctx->keys.p, ctx->pos.p, S, 0, 2 * ctx->pat.len, ss, st, sk, sv);
+        // runs of equal sequences -> one target with its (capped) count and position list
+        FFH_HIP(head.reserve(S + 8)); FFH_HIP(rank.reserve(S + 8));
+        hipLaunchKernelGGL(k_run_heads, dim3(blocks_for(S, 256)), dim3(256), 0, st, sk, S, head.p);
+        exclusive_scan<uint32_t, uint32_t>(head.p, S, rank.p, scr32.p, st);
+        uint32_t runs = 0;
+        FFH_HIP(hipMemcpyAsync(&runs, rank.p + S, 4, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        n_targets = runs;
+        FFH_HIP(start.reserve((size_t)runs + 8)); FFH_HIP(count.reserve((size_t)runs + 8));
+        FFH_HIP(d_targets.reserve((size_t)runs + 1)); FFH_HIP(d_posoff.reserve((size_t)runs + 2));
+        FFH_HIP(scr64.reserve(scan_scratch_elems_safe(runs)));
+        hipLaunchKernelGGL(k_run_starts, dim3(blocks_for(S, 256)), dim3(256), 0, st, head.p, rank.p, S, runs, start.p);
+        hipLaunchKernelGGL(k_run_targets, dim3(blocks_for(runs, 256)), dim3(256), 0, st, sk, start.p, runs, d_targets.p, count.p);
+        exclusive_scan<uint32_t, uint64_t>(count.p, runs, d_posoff.p, scr64.p, st);
+        FFH_HIP(hipMemcpyAsync(&n_positions, d_posoff.p + runs, 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        FFH_HIP(d_positions.reserve(n_positions + 1));
+        hipLaunchKernelGGL(k_run_positions, dim3(blocks_for(S, 256)), dim3(256), 0, st, sv, head.p, rank.p, start.p, d_posoff.p, S, d_positions.p);
+        FFH_HIP(hipGetLastError());
+        try { h_targets.resize(n_targets); h_positions.resize(n_positions); } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return FFH_E_NOMEM; }
+        FFH_HIP(hipMemcpyAsync(h_targets.data(), d_targets.p, n_targets * 8, hipMemcpyDeviceToHost, st));
+        if (n_positions) FFH_HIP(hipMemcpyAsync(h_positions.data(), d_positions.p, n_positions * 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<const char *> names;
+    for (const auto &c : ctx->contigs) names.push_back(c.c_str());
+    const int rc = ffh_db_write(db_path, ctx->enzyme, bin_width, names.data(), (uint32_t)names.size(), h_targets.data(), n_targets, h_positions.data(), n_positions);
+    if (rc) { ctx->err = g_create_error; return rc; }
+    if (stats) {
+        stats->n_bases = ctx->n_bases; stats->n_sites = S; stats->n_targets = n_targets; stats->n_positions = n_positions; stats->n_contigs = (uint32_t)ctx->contigs.size();
+        stats->scan_ms = ctx->scan_ms;
+        stats->sort_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats->write_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    }
+    return FFH_OK;
+}
 
 }  // extern "C"

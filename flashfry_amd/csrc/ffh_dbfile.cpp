@@ -4,6 +4,7 @@
 
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -11,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -142,8 +144,38 @@ std::string locate_bins(const BodyFile &bf, const DbHeader &h, uint32_t b0, uint
     return "";
 }
 
-// Members are independent deflate streams: every host thread inflates groups of consecutive members into its own
-// page-locked buffers and queues the copy to the device on its own stream, so inflate, PCIe and the next inflate overlap.
+// CPUs this process may actually use: hardware threads, the affinity mask and the cgroup CPU quota (a container with
+// `cpu.max = 1600000 100000` owns 16 CPUs however many the machine has; more inflate threads than that only add set-up)
+unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    auto quota = [&](const char *path, const char *period_path) {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return;
+        char a[64] = {0};
+        long long q = -1, per = 100000;
+        if (period_path) {  // cgroup v1: two files
+            if (std::fscanf(f, "%lld", &q) != 1) q = -1;
+            if (FILE *g = std::fopen(period_path, "r")) { if (std::fscanf(g, "%lld", &per) != 1) per = 100000; std::fclose(g); }
+        } else if (std::fscanf(f, "%63s %lld", a, &per) >= 1 && std::strcmp(a, "max") != 0) {
+            q = std::atoll(a);
+        }
+        std::fclose(f);
+        if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (q + per - 1) / per));
+    };
+    quota("/sys/fs/cgroup/cpu.max", nullptr);
+    quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (const char *e = std::getenv("FFH_LOAD_THREADS")) { const long v = std::atol(e); if (v > 0) n = (unsigned)v; }
+    return std::min(n, 128u);
+}
+
+// Members are independent deflate streams: every host thread inflates groups of consecutive members into its own slice
+// of one page-locked arena and queues the copy to the device on its own stream, so inflate, PCIe and the next inflate
+// overlap.  All HIP objects are created once by the calling thread (driver calls serialise; per-thread creation cost more
+// than the inflate at 128 threads).
 std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats) {
     const std::vector<Member> &ms = bf.members;
     stats.threads = 0; stats.compressed_bytes = 0; stats.raw_bytes = need_hi - need_lo;
@@ -157,69 +189,91 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
         while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff < need_hi) lo = mid + 1; else hi = mid; }
         m1 = lo;
     }
-    constexpr size_t kGroup = 64;                 // members per chunk: <= 4 MiB of payload
+    constexpr size_t kGroup = 32;                 // members per chunk: <= 2 MiB of payload
     constexpr size_t kChunkBytes = kGroup * 65536;
     const size_t nchunks = (m1 - m0 + kGroup - 1) / kGroup;
-    unsigned nthreads = std::thread::hardware_concurrency();
-    if (const char *e = std::getenv("FFH_LOAD_THREADS")) { const long v = std::atol(e); if (v > 0) nthreads = (unsigned)v; }
-    nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(nthreads ? nthreads : 1, 128u), nchunks));
+    const unsigned nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>(usable_cpus(), nchunks));
     stats.threads = nthreads;
     for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26;
+
+    struct Lane { hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; uint8_t *buf[2] = {nullptr, nullptr}; };
+    std::vector<Lane> lanes(nthreads);
+    uint8_t *arena = nullptr;
+    auto release = [&]() {
+        for (auto &l : lanes) { for (auto e : l.ev) if (e) (void)hipEventDestroy(e); if (l.st) (void)hipStreamDestroy(l.st); }
+        if (arena) (void)hipHostFree(arena);
+    };
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipHostMalloc((void **)&arena, (size_t)nthreads * 2 * kChunkBytes, hipHostMallocDefault);
+    for (unsigned t = 0; t < nthreads && he == hipSuccess; ++t) {
+        he = hipStreamCreateWithFlags(&lanes[t].st, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) {
+            lanes[t].buf[i] = arena + ((size_t)t * 2 + (size_t)i) * kChunkBytes;
+            he = hipEventCreateWithFlags(&lanes[t].ev[i], hipEventDisableTiming);
+        }
+    }
+    if (he != hipSuccess) { release(); return std::string("loader set-up failed: ") + hipGetErrorString(he); }
+
     std::atomic<size_t> next_chunk(0);
     std::atomic<int> failed(0);
     std::mutex err_mu;
     std::string err;
     auto fail = [&](const std::string &m) { std::lock_guard<std::mutex> g(err_mu); if (err.empty()) err = m; failed = 1; };
-    auto worker = [&]() {
+    const bool verbose = std::getenv("FFH_VERBOSE") != nullptr;
+    std::atomic<long long> us_inflate(0), us_wait(0);
+    auto now_us = []() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const long long t_start = now_us();
+    auto worker = [&](unsigned lane_id) {
+        Lane &ln = lanes[lane_id];
         if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed in a loader thread"); return; }
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        uint8_t *buf[2] = {nullptr, nullptr};
         bool used[2] = {false, false};
-        hipError_t he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && he == hipSuccess; ++i) {
-            he = hipHostMalloc((void **)&buf[i], kChunkBytes, hipHostMallocDefault);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-        }
         z_stream zs;
         std::memset(&zs, 0, sizeof zs);
-        const bool zok = inflateInit2(&zs, -15) == Z_OK;
-        if (he != hipSuccess || !zok) fail(std::string("loader thread set-up failed: ") + (zok ? hipGetErrorString(he) : "zlib"));
+        if (inflateInit2(&zs, -15) != Z_OK) { fail("zlib set-up failed"); return; }
         int slot = 0;
         while (!failed) {
             const size_t c = next_chunk.fetch_add(1);
             if (c >= nchunks) break;
-            if (used[slot] && hipEventSynchronize(ev[slot]) != hipSuccess) { fail("copy to the device failed"); break; }
+            const long long w1 = now_us();
+            if (used[slot] && hipEventSynchronize(ln.ev[slot]) != hipSuccess) { fail("copy to the device failed"); break; }
+            const long long w2 = now_us();
+            us_wait += w2 - w1;
             const size_t a = m0 + c * kGroup, b = std::min(m1, a + kGroup);
             const uint64_t u0 = ms[a].uoff, u1 = ms[b - 1].uoff + ms[b - 1].isize;
+            uint8_t *buf = ln.buf[slot];
             for (size_t i = a; i < b && !failed; ++i) {
                 const Member &m = ms[i];
                 if (m.isize == 0) continue;
                 inflateReset(&zs);
                 zs.next_in = const_cast<Bytef *>(bf.data + m.cdata_off); zs.avail_in = (uInt)m.cdata_len;
-                zs.next_out = buf[slot] + (m.uoff - u0); zs.avail_out = (uInt)m.isize;
+                zs.next_out = buf + (m.uoff - u0); zs.avail_out = (uInt)m.isize;
                 const int rc = inflate(&zs, Z_FINISH);
-                if (rc != Z_STREAM_END || zs.total_out != m.isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf[slot] + (m.uoff - u0), m.isize) != m.crc)
+                if (rc != Z_STREAM_END || zs.total_out != m.isize || (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf + (m.uoff - u0), m.isize) != m.crc)
                     fail("BGZF inflate / crc failure in the database body");
             }
             if (failed) break;
+            us_inflate += now_us() - w2;
             const uint64_t s = std::max(u0, need_lo), e = std::min(u1, need_hi);
             if (e > s) {
-                if (hipMemcpyAsync(d_raw + (s - need_lo), buf[slot] + (s - u0), (size_t)(e - s), hipMemcpyHostToDevice, st) != hipSuccess ||
-                    hipEventRecord(ev[slot], st) != hipSuccess) { fail("copy to the device failed"); break; }
+                if (hipMemcpyAsync(d_raw + (s - need_lo), buf + (s - u0), (size_t)(e - s), hipMemcpyHostToDevice, ln.st) != hipSuccess ||
+                    hipEventRecord(ln.ev[slot], ln.st) != hipSuccess) { fail("copy to the device failed"); break; }
                 used[slot] = true;
                 slot ^= 1;
             }
         }
-        if (st && hipStreamSynchronize(st) != hipSuccess) fail("copy to the device failed");
-        if (zok) inflateEnd(&zs);
-        for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (buf[i]) (void)hipHostFree(buf[i]); }
-        if (st) (void)hipStreamDestroy(st);
+        if (hipStreamSynchronize(ln.st) != hipSuccess) fail("copy to the device failed");
+        inflateEnd(&zs);
     };
+    const long long t_ready = now_us();
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    worker();
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    worker(0);
     for (auto &t : pool) t.join();
+    const long long t_done = now_us();
+    release();
+    if (verbose)
+        std::fprintf(stderr, "[ffh ingest] %u threads, %zu chunks: set-up %.1f ms, workers %.1f ms (per-thread mean: inflate %.1f ms, waiting for copies %.1f ms), teardown %.1f ms\n",
+                     nthreads, nchunks, (t_ready - t_start) / 1e3, (t_done - t_ready) / 1e3, us_inflate / 1e3 / nthreads, us_wait / 1e3 / nthreads, (now_us() - t_done) / 1e3);
     return failed ? err : "";
 }
 

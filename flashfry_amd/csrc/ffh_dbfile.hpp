@@ -48,6 +48,9 @@ struct IngestStats {
     uint64_t compressed_bytes = 0, raw_bytes = 0;
 };
 
+// hardware threads this process can really use (affinity mask, cgroup CPU quota, FFH_LOAD_THREADS override), <= 128
+unsigned usable_cpus();
+
 std::string open_body(const std::string &body_path, BodyFile &out);
 
 // where the payloads of bins [bin_begin, bin_end) lie: the byte range [need_lo, need_hi) of the uncompressed stream that

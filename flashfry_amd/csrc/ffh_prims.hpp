@@ -175,8 +175,11 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__re
     table[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// VALS: a u64 payload travels with every key (same stable permutation), staged through the same LDS buffer after the keys
+template <bool VALS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
-                                                                const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks) {
+                                                                const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks,
+                                                                const uint64_t *__restrict__ vals, uint64_t *__restrict__ vout) {
     __shared__ uint64_t staged[kSortChunk];      // the chunk, digit-ordered
     __shared__ uint32_t wave_cnt[4][256];        // per-wave digit counts -> per-wave start inside the digit's run
     __shared__ uint32_t dig_start[256];          // start of every digit's run inside the chunk
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
     const uint32_t here = (uint32_t)min((uint64_t)kSortChunk, n - base);
     // wave w owns keys [w*1024, w*1024 + 1024) of the chunk, 16 rows of 64
     uint64_t kreg[kSortRows];
+    uint16_t preg[VALS ? kSortRows : 1];  // where each of this thread's keys went inside the staged chunk
 #pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
         const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
@@ -237,18 +241,47 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (valid) staged[pos] = kreg[r];
+        if (VALS) preg[VALS ? r : 0] = (uint16_t)pos;
     }
     __syncthreads();
     // pass 3: contiguous copy-out; element i of the digit-ordered chunk goes to the digit's global run
-    for (uint32_t i = threadIdx.x; i < here; i += kSortThreads) {
-        const uint64_t key = staged[i];
-        const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
-        out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
+    if (!VALS) {
+        for (uint32_t i = threadIdx.x; i < here; i += kSortThreads) {
+            const uint64_t key = staged[i];
+            const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+            out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
+        }
+    } else {
+        uint32_t dest[kSortRows];
+#pragma unroll
+        for (int k = 0; k < kSortRows; ++k) {
+            const uint32_t i = threadIdx.x + k * kSortThreads;
+            dest[k] = 0;
+            if (i < here) {
+                const uint64_t key = staged[i];
+                const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+                dest[k] = dig_goff[d] + (i - dig_start[d]);
+                out[dest[k]] = key;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSortRows; ++r) {
+            const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+            if (i < here) staged[preg[VALS ? r : 0]] = vals[base + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortRows; ++k) {
+            const uint32_t i = threadIdx.x + k * kSortThreads;
+            if (i < here) vout[dest[k]] = staged[i];
+        }
     }
 }
 
 struct SortScratch {
     uint64_t *alt = nullptr;     // n keys
+    uint64_t *val_alt = nullptr; // n payloads (radix_sort_pairs only)
     uint32_t *table = nullptr;   // 256*nblocks + 1
     uint32_t *offs = nullptr;    // 256*nblocks + 1
     uint32_t *scan_tmp = nullptr;
@@ -267,10 +300,28 @@ inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, 
         for (int shift = ranges[rg][0]; shift < ranges[rg][1]; shift += 8) {
             hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
             exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
-            hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb);
+            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, (const uint64_t *)nullptr,
+                               (uint64_t *)nullptr);
             uint64_t *t = src; src = dst; dst = t;
         }
     return src;
+}
+
+// stable sort of (key, payload) pairs by bits [lo, hi) of the key; on return keys_out / vals_out name the buffers
+// (the caller's or the scratch ones) that hold the result
+inline void radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, int lo, int hi, SortScratch &s, hipStream_t st, uint64_t *&keys_out, uint64_t *&vals_out) {
+    keys_out = keys; vals_out = vals;
+    if (n == 0) return;
+    const uint32_t nb = sort_nblocks(n);
+    uint64_t *src = keys, *dst = s.alt, *vsrc = vals, *vdst = s.val_alt;
+    for (int shift = lo; shift < hi; shift += 8) {
+        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
+        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
+        hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, (const uint64_t *)vsrc, vdst);
+        uint64_t *t = src; src = dst; dst = t;
+        t = vsrc; vsrc = vdst; vdst = t;
+    }
+    keys_out = src; vals_out = vsrc;
 }
 
 }  // namespace ffh

@@ -175,8 +175,8 @@ struct HeaderInfo {
 };
 HeaderInfo readHeaderInfo(const std::string &databasePath);
 
-// modules/BuildOffTargetDatabase.scala:57-89 + reference/binary/DatabaseWriter.scala:58-111 (CPU)
-void buildOffTargetDatabase(const std::string &reference, const std::string &output, const ParameterPack &pack, int binSize);
+// modules/BuildOffTargetDatabase.scala:57-89: FASTA streamed into the library's GPU indexer (ffh_indexer_*), written by ffh_db_write
+void buildOffTargetDatabase(const std::string &reference, const std::string &output, const ParameterPack &pack, int binSize, int device = 0);
 
 // ---- CLI modules ---------------------------------------------------------------------------------------------
 int runIndex(int argc, char **argv);     // modules/BuildOffTargetDatabase.scala

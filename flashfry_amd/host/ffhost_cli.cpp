@@ -72,10 +72,10 @@ static std::vector<int> deviceList(const Options &o) {
 
 // ---- index: modules/BuildOffTargetDatabase.scala:57-89 --------------------------------------------------------------
 int runIndex(int argc, char **argv) {
-    const Options o = parse(argc, argv, {}, {"reference", "database", "tmpLocation", "enzyme", "binSize"});
-    require(o, {"reference", "database"});  // --tmpLocation is accepted and ignored: the sites are sorted in memory
+    const Options o = parse(argc, argv, {}, {"reference", "database", "tmpLocation", "enzyme", "binSize", "devices", "gpus"});
+    require(o, {"reference", "database"});  // --tmpLocation is accepted and ignored: the sites are sorted in device memory
     const ParameterPack &pack = ParameterPack::nameToParameterPack(o.str("enzyme", "spCas9ngg"));
-    buildOffTargetDatabase(o.str("reference"), o.str("database"), pack, o.num("binSize", 7));
+    buildOffTargetDatabase(o.str("reference"), o.str("database"), pack, o.num("binSize", 7), deviceList(o)[0]);
     return 0;
 }
 

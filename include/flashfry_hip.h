@@ -104,6 +104,37 @@ typedef struct ffh_db_info {
 } ffh_db_info;
 int ffh_db_info_get(const ffh_ctx *ctx, ffh_db_info *out);
 
+/* Writes a database in the reference's on-disk format: BGZF body bin by bin + text "<db_path>.header"
+ * (replaces DatabaseWriter.writeToBinnedFile reference/binary/DatabaseWriter.scala:58-111, BlockManager.createLinearBlock /
+ * createIndexedBlock blocks/BlockManager.scala:362-442 and BinaryHeader.writeHeader binary/BinaryHeader.scala:69-97).
+ * targets[]: unique target longs in sequence order with their occurrence count in bits 63:48 (what BlockReader.scala:138-159
+ * produces); positions[]: their position longs, count per target, same order; contigs[]: names, id = index + 1.
+ * Host memory in, files out; no GPU involved.  Errors are reported through ffh_last_error(NULL). */
+int ffh_db_write(const char *db_path, int enzyme_index, int bin_width, const char *const *contigs, uint32_t n_contigs, const uint64_t *targets,
+                 uint64_t n_targets, const uint64_t *positions, uint64_t n_positions);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * index: build a database from a reference genome on the GPU.  The host hands over one contig at a time
+ * (upper- or lower-case bases, anything that is not ACGT never matches); the device finds the target sites of both
+ * strands (SimpleSiteFinder, reference/ReferenceEncoder.scala:104-175), sorts them by sequence keeping discovery order
+ * inside equal sequences and merges duplicates into (sequence, count <= 32767, positions) (BinWriter.scala:58-100,
+ * BlockReader.scala:54-159); ffh_indexer_finish writes the result with ffh_db_write.
+ * Replaces modules/BuildOffTargetDatabase.scala:57-89.  Errors: ffh_indexer_last_error.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct ffh_indexer ffh_indexer;
+typedef struct ffh_index_stats {
+    uint64_t n_bases, n_sites, n_targets, n_positions;
+    uint32_t n_contigs, reserved;
+    double scan_ms;   /* copies of the contigs to the device + site discovery */
+    double sort_ms;   /* sort, merge of duplicates, copy of the result to the host */
+    double write_ms;  /* ffh_db_write: blocks, BGZF, header (host threads) */
+} ffh_index_stats;
+ffh_indexer *ffh_indexer_create(int device_id, int enzyme_index);
+void ffh_indexer_destroy(ffh_indexer *ix);
+const char *ffh_indexer_last_error(const ffh_indexer *ix);
+int ffh_indexer_add_contig(ffh_indexer *ix, const char *name, const char *sequence, uint64_t length);
+int ffh_indexer_finish(ffh_indexer *ix, const char *db_path, int bin_width, ffh_index_stats *stats);
+
 /* Where the time of the last ffh_db_open / ffh_db_load_blocks went (milliseconds of host wall time, stages in order). */
 typedef struct ffh_load_stats {
     double open_ms;            /* header parse, mmap, BGZF member directory */

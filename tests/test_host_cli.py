@@ -1,5 +1,5 @@
 """The C++ host CLI (flashfry-hip index | discover | score) against the oracle's restatement of the reference CLI.
-`index` is CPU code and is checked here without a GPU; discover/score need the GPU box."""
+Option handling is checked without a GPU; index, discover and score compute on the device and need the GPU box."""
 import os
 import subprocess
 
@@ -48,7 +48,8 @@ def guide_fasta(path, genome_path, n=40, seed=2, mutate=2):
             f.write(">random%s\n%s\n" % (w, w))
 
 
-@pytest.mark.parametrize("enzyme", ["spcas9ngg", "spcas9", "cpf1", "spcas9ngg19"])
+@pytest.mark.gpu
+@pytest.mark.parametrize("enzyme", ["spcas9ngg", "spcas9", "cpf1", "spcas9ngg19", "spcas9nag", "spcas919"])
 def test_index_matches_oracle(cli, oracle, tmp_path, enzyme):
     fa = str(tmp_path / "genome.fa")
     random_genome(fa, seed=len(enzyme))
@@ -71,6 +72,39 @@ def test_index_matches_oracle(cli, oracle, tmp_path, enzyme):
     assert kinds == ({1} if enzyme == "cpf1" else {1, 2}) or kinds == {1}
 
 
+@pytest.mark.gpu
+def test_index_edge_cases_match_oracle(cli, oracle, tmp_path):
+    """what the FASTA reader and the device site scan must get right: text before the first header is ignored, CRLF line
+    ends, no final newline, soft-masked bases, contigs shorter than a site, an empty record, sites cut by N, a tandem
+    repeat with more copies than Short.MaxValue (count and position list are capped at 32767, BlockReader.scala:147-153)"""
+    rng = np.random.default_rng(12)
+    unit = "ACGTTGCAAGCTTGACCATGAGG"                                        # one forward NGG site per copy
+    body = "".join(rng.choice(list("ACGT"), 30000))
+    recs = [("tiny", "ACGTACGTGG"), ("empty", ""), ("tandem repeat", unit * 33000), ("mixed\tcase", body[:9000].lower() + "N" + body[9000:20000] + "nnn" + body[20000:]),
+            ("palin", "CC" + "ACGTACGTACGTACGTACGTA" + "GG")]                # a window that is a forward AND a reverse site
+    fa = str(tmp_path / "edge.fa")
+    with open(fa, "w", newline="") as f:
+        f.write("ACGTACGTACGTACGTACGTAGG\r\n")                              # before any header: dropped (ReferenceEncoder.scala:116)
+        for i, (name, s) in enumerate(recs):
+            f.write(">%s\r\n" % name)
+            for k in range(0, len(s), 61):
+                last = i == len(recs) - 1 and k + 61 >= len(s)
+                f.write(s[k:k + 61] + ("" if last else "\r\n"))
+    a, b = str(tmp_path / "db_cli"), str(tmp_path / "db_oracle")
+    subprocess.check_call([cli, "index", "--reference", fa, "--database", a, "--enzyme", "spcas9ngg"], stderr=subprocess.DEVNULL)
+    assert oracle.lib.ffo_index_fasta(fa.encode(), b.encode(), b"spcas9ngg", 7) == 0, oracle.error()
+    da, db = oracle.db_read(a), oracle.db_read(b)
+    assert da.contigs() == db.contigs() == ["tiny", "empty", "tandem_repeat", "mixed_case", "palin"]
+    capped = 0
+    for bi in range(16384):
+        xa, na = da.bin(bi)
+        xb, nb = db.bin(bi)
+        assert na == nb and np.array_equal(xa, xb), bi
+        capped += int(np.sum((xa.view(np.uint64) >> np.uint64(48)) == 32767))
+    assert capped >= 1
+
+
+@pytest.mark.gpu
 def test_index_gz_and_bgzf_is_plain_gzip(cli, tmp_path):
     """BGZF is a series of gzip members: Python's gzip module must read the body the CLI wrote"""
     import gzip

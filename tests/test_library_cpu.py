@@ -50,3 +50,37 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"ff_oracle|oracle_lib|libff_oracle|from\s+oracle|import\s+oracle|oracle/", txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("enzyme,bin_width,n", [(3, 3, 60000), (3, 7, 30000), (1, 3, 20000), (5, 4, 140000)])
+def test_database_writer_matches_the_oracle_writer(oracle, tmp_path, enzyme, bin_width, n):
+    """ffh_db_write (DatabaseWriter.scala:58-111 + BlockManager.scala:362-442) against the oracle's restatement: the file
+    written by the library, read back by the oracle's BGZF/header reader, holds the oracle's own blocks bin by bin
+    (linear and indexed; 5' PAM enzymes regroup the targets and never index)."""
+    from flashfry_amd import capi, synth
+    from tests.helpers import make_case
+    import numpy as np
+    rng = np.random.default_rng(enzyme * 100 + bin_width)
+    bases = {1: 24, 3: 23, 5: 22}[enzyme]
+    seqs = np.unique(rng.integers(0, 1 << (2 * bases), n, dtype=np.uint64))  # sorted = sequence order
+    counts = np.where(rng.random(len(seqs)) < 0.9, 1, rng.integers(2, 6, len(seqs))).astype(np.uint64)
+    counts[0] = 32767  # Short.MaxValue, the cap of BlockReader.scala:147-153
+    targets = seqs | (counts << np.uint64(48))
+    positions = rng.integers(0, 1 << 60, int(counts.sum()), dtype=np.uint64)
+    contigs = ["chr%d" % (i + 1) for i in range(5)]
+    path = tmp_path / "db"
+    capi.write_database(path, enzyme, targets, positions, contigs, bin_width=bin_width)
+    back = oracle.db_read(str(path))
+    ref = oracle.db_from_sorted(enzyme, targets, positions, bin_width=bin_width, max_linear=500, contigs=contigs)
+    assert back.n_bins == ref.n_bins == 4 ** bin_width and back.contigs() == contigs and back.enzyme == enzyme
+    kinds = set()
+    for b in range(ref.n_bins):
+        a, na = back.bin(b)
+        e, ne = ref.bin(b)
+        assert na == ne and np.array_equal(a, e), "bin %d differs" % b
+        kinds.add(int(e[0]))
+    assert (2 in kinds) == (enzyme != 1 and bin_width < 7)
+    with pytest.raises(capi.FlashFryHipError, match="greater than zero"):
+        capi.write_database(path, enzyme, targets & np.uint64((1 << 48) - 1), positions, contigs, bin_width=bin_width)
+    with pytest.raises(capi.FlashFryHipError, match="sum of the target counts"):
+        capi.write_database(path, enzyme, targets, positions[:-1], contigs, bin_width=bin_width)
