@@ -25,11 +25,13 @@ def write_genome(path, mbases, contigs, seed):
     with open(path, "wb") as f:
         for c in range(contigs):
             n = int(mbases * 1e6 / contigs)
-            seq = lut[rng.integers(0, 4, n, dtype=np.uint8)]
             f.write(b">chrS%d synthetic\n" % (c + 1))
-            rows = seq[: n - n % 60].reshape(-1, 60)
-            f.write(b"\n".join(r.tobytes() for r in rows))
-            f.write(b"\n")
+            for a in range(0, n - n % 60, 60 << 20):  # 60-column lines, written in slabs
+                m = min(60 << 20, n - n % 60 - a)
+                rows = np.empty((m // 60, 61), dtype=np.uint8)
+                rows[:, :60] = lut[rng.integers(0, 4, m, dtype=np.uint8)].reshape(-1, 60)
+                rows[:, 60] = 10
+                f.write(rows.tobytes())
 
 
 def write_guides(path, n, seed):
@@ -50,14 +52,14 @@ def drop_caches():
         return False
 
 
-def timed(cmd):
+def timed(cmd, key="comparisons"):
     t0 = time.perf_counter()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     dt = time.perf_counter() - t0
     if p.returncode:
         raise SystemExit("FAILED %s\n%s" % (" ".join(cmd), p.stderr[-2000:]))
-    detail = [l for l in p.stderr.splitlines() if "comparisons" in l]
-    return dt, (detail[0] if detail else "")
+    detail = [l for l in p.stderr.splitlines() if key in l or "Database load" in l]
+    return dt, " | ".join(detail)
 
 
 def main():
@@ -75,7 +77,8 @@ def main():
         f.write(">EMX1\nGAGTCCGAGCAGAAGAAGAAGGG\n")
     write_guides(os.path.join(w, "g1000.fa"), 1000, 0x6D1DE5)
     rows = {}
-    rows["index_s"], _ = timed([CLI, "index", "--reference", fa, "--database", db, "--enzyme", "spcas9ngg", "--tmpLocation", w])
+    rows["genome_mbases"] = args.mbases
+    rows["index_s"], rows["index_detail"] = timed([CLI, "index", "--reference", fa, "--database", db, "--enzyme", "spcas9ngg", "--tmpLocation", w], key="Wrote")
     rows["database_bytes"] = os.path.getsize(db)
     for name, guides in (("C1_1_guide", "emx1.fa"), ("C2_1000_guides", "g1000.fa")):
         out = os.path.join(w, name + ".output")
