@@ -14,6 +14,7 @@ u32p = C.POINTER(C.c_uint32)
 i64p = C.POINTER(C.c_int64)
 
 FINALIZE_SUMMARIES_ONLY = 1
+FINALIZE_JOST = 2
 
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -30,13 +31,13 @@ SYMBOLS = [
 class GuideSummary(C.Structure):
     _fields_ = [("n_hits", C.c_uint32), ("ot_count", C.c_uint32), ("overflow", C.c_uint32), ("hist", C.c_uint32 * 5),
                 ("closest", C.c_uint32), ("closest_count", C.c_uint32), ("in_genome", C.c_uint32), ("n_scored", C.c_uint32),
-                ("cfd_max", C.c_double), ("cfd_sum", C.c_double), ("hsu_sum", C.c_double)]
+                ("cfd_max", C.c_double), ("cfd_sum", C.c_double), ("hsu_sum", C.c_double), ("jost_max", C.c_double), ("jost_sum", C.c_double)]
 
 
 SUMMARY_DTYPE = np.dtype([("n_hits", "<u4"), ("ot_count", "<u4"), ("overflow", "<u4"), ("hist", "<u4", (5,)),
                           ("closest", "<u4"), ("closest_count", "<u4"), ("in_genome", "<u4"), ("n_scored", "<u4"),
-                          ("cfd_max", "<f8"), ("cfd_sum", "<f8"), ("hsu_sum", "<f8")])
-assert SUMMARY_DTYPE.itemsize == C.sizeof(GuideSummary) == 72
+                          ("cfd_max", "<f8"), ("cfd_sum", "<f8"), ("hsu_sum", "<f8"), ("jost_max", "<f8"), ("jost_sum", "<f8")])
+assert SUMMARY_DTYPE.itemsize == C.sizeof(GuideSummary) == 88
 
 
 class DbInfo(C.Structure):
@@ -323,19 +324,19 @@ class Context:
         self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))
         return t[:self._n_guides]
 
-    def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False):
+    def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False, jost=False):
         out = C.c_void_p()
         pt = None
         if prior_totals is not None:
             pt = np.ascontiguousarray(prior_totals, dtype=np.uint32)
             assert len(pt) == self._n_guides
         self._check(self.L.ffh_finalize(self.h, pt.ctypes.data_as(u32p) if pt is not None else None, max_offtargets,
-                                        FINALIZE_SUMMARIES_ONLY if summaries_only else 0, C.byref(out)))
+                                        (FINALIZE_SUMMARIES_ONLY if summaries_only else 0) | (FINALIZE_JOST if jost else 0), C.byref(out)))
         return Result(self.L, out.value, lists=not summaries_only)
 
-    def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False):
+    def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False):
         self.scan(guides, max_mismatch)
-        return self.finalize(max_offtargets, None, summaries_only)
+        return self.finalize(max_offtargets, None, summaries_only, jost)
 
     def score_lists(self, guides, guide_offsets, hit_targets):
         """the `score` path: score caller-supplied hit lists (CSR) on the device"""

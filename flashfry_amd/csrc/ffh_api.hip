@@ -22,6 +22,7 @@
 #include "ffh_ingest.hpp"
 #include "ffh_kernels.hpp"
 #include "cfd_table.inc"
+#include "jost_table.inc"
 
 using namespace ffh;
 
@@ -183,7 +184,7 @@ struct ffh_ctx {
     DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals;
     DevBuf<uint64_t> ret_off, out_target, out_posoff, out_pos;
     DevBuf<uint8_t> out_mm;
-    DevBuf<double> out_cfd, out_hsu;
+    DevBuf<double> out_cfd, out_hsu, out_jost;
     DevBuf<GuideSummary> summ;
     ScoreTables *d_tab = nullptr;
 
@@ -412,6 +413,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
         static const double coeff[20] = {0.0, 0.0, 0.014, 0.0, 0.0, 0.395, 0.317, 0.0, 0.389, 0.079,   // CrisprMitEduOffTarget.scala:43-47
                                          0.445, 0.508, 0.613, 0.851, 0.732, 0.828, 0.615, 0.804, 0.685, 0.583};
         std::memcpy(h.hsu_coeff, coeff, sizeof coeff);
+        std::memcpy(h.jost, FFH_JOST, sizeof h.jost);
         e = hipMemcpy(ctx->d_tab, &h, sizeof h, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
@@ -435,7 +437,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     ctx->tiles.release(); ctx->sort_table.release(); ctx->sort_offs.release();
     ctx->n_ret.release(); ctx->ot_count.release(); ctx->full.release(); ctx->prior.release(); ctx->out_cnt.release(); ctx->out_tidx.release(); ctx->totals.release();
     ctx->ret_off.release(); ctx->out_target.release(); ctx->out_posoff.release(); ctx->out_pos.release(); ctx->out_mm.release();
-    ctx->out_cfd.release(); ctx->out_hsu.release(); ctx->summ.release();
+    ctx->out_cfd.release(); ctx->out_hsu.release(); ctx->out_jost.release(); ctx->summ.release();
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -831,16 +833,18 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     FFH_HIP(ctx->out_tidx.reserve(Hr + 1));
     FFH_HIP(ctx->out_cfd.reserve(Hr + 1));
     FFH_HIP(ctx->out_hsu.reserve(Hr + 1));
+    double *d_jost = nullptr;  // the CRISPRi aggregates are computed on request only: they cost a third per-hit array
+    if (flags & FFH_FINALIZE_JOST) { FFH_HIP(ctx->out_jost.reserve(Hr + 1)); d_jost = ctx->out_jost.p; }
     FFH_HIP(ctx->out_posoff.reserve(Hr + 2));
     if (ctx->n_raw)
         hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
                            ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
-                           ctx->out_hsu.p);
+                           ctx->out_hsu.p, d_jost);
     exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, Hr, ctx->out_posoff.p, ctx->scan_tmp64.p, st);
     uint64_t Pr = 0;
     FFH_HIP(hipMemcpyAsync(&Pr, ctx->out_posoff.p + Hr, 8, hipMemcpyDeviceToHost, st));
     if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
-                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
+                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)d_jost, G, ctx->summ.p);
     FFH_HIP(hipStreamSynchronize(st));
     const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY);
     if (want_lists) {
@@ -908,6 +912,7 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
     FFH_HIP(ctx->out_cnt.reserve(H + 1));
     FFH_HIP(ctx->out_cfd.reserve(H + 1));
     FFH_HIP(ctx->out_hsu.reserve(H + 1));
+    FFH_HIP(ctx->out_jost.reserve(H + 1));
     if (G) {
         FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)G * 8, hipMemcpyHostToDevice, st));
         FFH_HIP(hipMemcpyAsync(ctx->n_ret.p, n_ret.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
@@ -919,10 +924,10 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
         FFH_HIP(hipMemcpyAsync(ctx->out_target.p, hit_targets, H * 8, hipMemcpyHostToDevice, st));
         FFH_HIP(hipMemcpyAsync(ctx->out_tidx.p, hit_guide.data(), H * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_score_list, dim3(blocks_for(H, 256)), dim3(256), 0, st, ctx->out_target.p, ctx->out_tidx.p, H, ctx->guides.p, ctx->geo, ctx->d_tab,
-                           ctx->out_mm.p, ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p);
+                           ctx->out_mm.p, ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, ctx->out_jost.p);
     }
     if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
-                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, G, ctx->summ.p);
+                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)ctx->out_jost.p, G, ctx->summ.p);
     FFH_HIP(hipGetLastError());
     ffh_result *r = new (std::nothrow) ffh_result();
     if (!r || !r->allocate(ctx->pool, G, H, 0, true)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }

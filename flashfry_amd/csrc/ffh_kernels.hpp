@@ -583,6 +583,7 @@ struct ScoreTables {
     double cfd_mm[20 * 4 * 4];
     double cfd_pam[16];
     double hsu_coeff[20];
+    double jost[19 * 4 * 4];  // [position - 1][off-target base][guide base], 1.0 on the diagonal
 };
 
 // mismatches + pam*CFD (Doench2016CFDScore.scala:67-73,132-151) + Hsu2013 hit score (CrisprMitEduOffTarget.scala:107-148)
@@ -626,12 +627,28 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
     }
 }
 
+// Jost & Santos CRISPRi activity of one (guide, off-target) pair, JostAndSantosCRISPRi.calc_score :92-127: the product over
+// the mismatching positions 1..19 of the mean activity for (position, off-target base, complement of the guide base),
+// multiplied in ascending position.  20-mers (scan length 23) skip their first base, 19-mers (22) use all of theirs.
+// Defined for every Cas9 pack (:53-58); the caller skips pairs with no mismatch among the compared bases (:40).
+__device__ __forceinline__ double jost_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab) {
+    const int first = geo.scan_len == 23 ? 1 : 0;
+    double total = 1.0;
+#pragma unroll
+    for (int k = 0; k < 19; ++k) {
+        const int sh = 2 * (geo.scan_len - 1 - (first + k));
+        const uint32_t gb = (uint32_t)(gd >> sh) & 3u, ob = (uint32_t)(t >> sh) & 3u;
+        total *= tab->jost[k * 16 + ob * 4 + gb];  // 1.0 where the bases agree
+    }
+    return total;
+}
+
 // per retained hit of a discover scan: target long, mismatches, position count, database index and the two scores
 __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, int tbits, const uint32_t *__restrict__ seg_begin,
                              const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ st,
                              const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
                              uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
-                             double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
+                             double *__restrict__ out_cfd, double *__restrict__ out_hsu, double *__restrict__ out_jost /* may be null */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint64_t key = hits[i];
@@ -649,12 +666,13 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
     out_tidx[o] = ti;
     out_cfd[o] = cfd;
     out_hsu[o] = hsu;
+    if (out_jost) out_jost[o] = (geo.c0 == 3 && mm != 0) ? jost_pair(guides[g], t, geo, tab) : __builtin_nan("");
 }
 
 // the same for caller-supplied hit lists (the `score` path: hit lists re-read from a discover table)
 __global__ void k_score_list(const uint64_t *__restrict__ hit_targets, const uint32_t *__restrict__ hit_guide, uint64_t n_hits,
                              const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint8_t *__restrict__ out_mm,
-                             uint32_t *__restrict__ out_cnt, double *__restrict__ out_cfd, double *__restrict__ out_hsu) {
+                             uint32_t *__restrict__ out_cnt, double *__restrict__ out_cfd, double *__restrict__ out_hsu, double *__restrict__ out_jost) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint64_t t = hit_targets[i];
@@ -665,11 +683,12 @@ __global__ void k_score_list(const uint64_t *__restrict__ hit_targets, const uin
     out_cnt[i] = (uint32_t)(t >> 48);
     out_cfd[i] = cfd;
     out_hsu[i] = hsu;
+    if (out_jost) out_jost[i] = (geo.c0 == 3 && mm != 0) ? jost_pair(guides[hit_guide[i]], t, geo, tab) : __builtin_nan("");
 }
 
 struct GuideSummary {  // mirrors ffh_guide_summary
     uint32_t n_hits, ot_count, overflow, hist[5], closest, closest_count, in_genome, n_scored;
-    double cfd_max, cfd_sum, hsu_sum;
+    double cfd_max, cfd_sum, hsu_sum, jost_max, jost_sum;
 };
 
 // One wave per guide.  Integer aggregates are wave reductions (exact in any order); the two f64 sums are accumulated
@@ -678,13 +697,14 @@ struct GuideSummary {  // mirrors ffh_guide_summary
 __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restrict__ ret_off, const uint32_t *__restrict__ n_ret,
                                                          const uint32_t *__restrict__ ot_count, const uint32_t *__restrict__ full,
                                                          const uint8_t *__restrict__ mm, const uint32_t *__restrict__ cnt, const double *__restrict__ cfd,
-                                                         const double *__restrict__ hsu, uint32_t n_guides, GuideSummary *__restrict__ out) {
+                                                         const double *__restrict__ hsu, const double *__restrict__ jost /* may be null */,
+                                                         uint32_t n_guides, GuideSummary *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_guides) return;
     const uint32_t n = n_ret[g];
     const uint64_t b = ret_off[g];
     uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, n_scored = 0;
-    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0;
     for (uint32_t i = 0; i < n; i += 64) {  // pass 1: histogram, closest level, ordered f64 sums
         const bool in = i + lane < n;
         const uint32_t m = in ? mm[b + i + lane] : 0xFFu, c = in ? cnt[b + i + lane] : 0u;
@@ -701,6 +721,17 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
             hsu_sum += bcast_f64(h, l);
             cfd_max = fmax(cfd_max, bcast_f64(f, l));                              // scores are >= 0, the empty max is 0.0
             ++n_scored;
+        }
+        if (jost) {                                                                // JostAndSantosCRISPRi.scala:42-43, same walk
+            const double j = in ? jost[b + i + lane] : __builtin_nan("");
+            const double jc = j * (double)c;
+            uint64_t js = __ballot(in && j == j);
+            while (js) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(js);
+                js &= js - 1;
+                jost_sum += bcast_f64(jc, l);
+                jost_max = fmax(jost_max, bcast_f64(j, l));
+            }
         }
     }
     closest = wave_min_u32(closest);
@@ -719,6 +750,7 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
     s.closest_count = closest == 0xFFFFFFFFu ? 0u : wave_sum_u32(closest_count);
     s.in_genome = in_genome; s.n_scored = n_scored;
     s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
+    s.jost_max = jost_max; s.jost_sum = jost_sum;
     if (lane == 0) out[g] = s;
 }
 

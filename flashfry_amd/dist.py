@@ -54,7 +54,7 @@ def allreduce_summaries(summ, device=None, group=None):
     ints[:, 7] = summ["in_genome"]; ints[:, 8] = summ["n_scored"]
     ti = torch.as_tensor(ints, device=device)
     dist.all_reduce(ti, op=dist.ReduceOp.SUM, group=group)
-    mx = torch.as_tensor(np.stack([summ["overflow"].astype(np.float64), summ["cfd_max"]], 1), device=device)
+    mx = torch.as_tensor(np.stack([summ["overflow"].astype(np.float64), summ["cfd_max"], summ["jost_max"]], 1), device=device)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     closest = torch.as_tensor(summ["closest"].astype(np.int64), device=device)
     gmin = closest.clone()
@@ -64,7 +64,7 @@ def allreduce_summaries(summ, device=None, group=None):
     dist.all_reduce(cc, op=dist.ReduceOp.SUM, group=group)
     # f64 sums: gather and add in rank order (= database order of the shards) so the result does not depend on the
     # collective's internal reduction order
-    fl = torch.as_tensor(np.stack([summ["cfd_sum"], summ["hsu_sum"]], 1), device=device)
+    fl = torch.as_tensor(np.stack([summ["cfd_sum"], summ["hsu_sum"], summ["jost_sum"]], 1), device=device)
     parts = [torch.empty_like(fl) for _ in range(world)]
     dist.all_gather(parts, fl, group=group)
     acc = parts[0].clone()
@@ -73,7 +73,7 @@ def allreduce_summaries(summ, device=None, group=None):
     ti, mx, gmin, cc, acc = ti.cpu().numpy(), mx.cpu().numpy(), gmin.cpu().numpy(), cc.cpu().numpy(), acc.cpu().numpy()
     summ["n_hits"] = ti[:, 0]; summ["ot_count"] = ti[:, 1]; summ["hist"] = ti[:, 2:7]
     summ["in_genome"] = ti[:, 7]; summ["n_scored"] = ti[:, 8]
-    summ["overflow"] = mx[:, 0].astype(np.uint32); summ["cfd_max"] = mx[:, 1]
+    summ["overflow"] = mx[:, 0].astype(np.uint32); summ["cfd_max"] = mx[:, 1]; summ["jost_max"] = mx[:, 2]
     summ["closest"] = gmin.astype(np.uint32); summ["closest_count"] = cc
-    summ["cfd_sum"] = acc[:, 0]; summ["hsu_sum"] = acc[:, 1]
+    summ["cfd_sum"] = acc[:, 0]; summ["hsu_sum"] = acc[:, 1]; summ["jost_sum"] = acc[:, 2]
     return summ

@@ -12,7 +12,8 @@
 //   CRISPRHit / CRISPRSiteOT crispr/CRISPRHit.scala:39-104, crispr/CRISPRSiteOT.scala:31-64
 //   TabDelimitedOutput/Input targetio/TabDelimitedHandler.scala:38-335
 //   GpuTraverser             the Traverser.scan plug-in point, reference/traverser/Traverser.scala:38-61
-//   score columns            scoring/{Doench2016CFDScore,CrisprMitEduOffTarget,ClosestHit,DangerousSequences}.scala
+//   score columns            scoring/{Doench2016CFDScore,CrisprMitEduOffTarget,ClosestHit,DangerousSequences,
+//                            JostAndSantosCRISPRi,ReciprocalOffTargets}.scala
 //   DatabaseWriter / index   reference/binary/DatabaseWriter.scala:58-111, modules/BuildOffTargetDatabase.scala:57-89
 //
 // All comparisons, the cut-off and the scores are computed by the HIP library; this layer only moves text.
@@ -118,13 +119,14 @@ struct CRISPRSiteOT {  // crispr/CRISPRSiteOT.scala:31-64
     long currentTotal = 0;
     std::vector<CRISPRHit> offTargets;
     ffh_guide_summary summary{};                 // aggregates delivered by the HIP epilogue
+    std::vector<std::string> reciprocal;         // namedAnnotations("ReciprocalOffTargets"): bases of the other guides within reach
     bool full() const { return currentTotal >= overflow; }
 };
 
 std::string javaDoubleToString(double d);  // java.lang.Double.toString
 
 // ---- score columns (the reference's ScoreModel plug-ins that work on hit lists) ------------------------------
-enum class Metric { Hsu2013, Doench2016CFD, MinOT, Dangerous };
+enum class Metric { Hsu2013, Doench2016CFD, MinOT, Dangerous, JostAndSantos, Reciprocal };
 Metric metricByName(const std::string &name);                   // ScoreResults.getRegisteredScoringMetric :159-226
 bool metricValidOverEnzyme(Metric m, const ParameterPack &p);   // ScoreModel.validOverEnzyme
 std::vector<std::string> metricHeaderColumns(Metric m);         // ScoreModel.headerColumns

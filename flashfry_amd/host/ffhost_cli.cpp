@@ -183,6 +183,26 @@ int runScore(int argc, char **argv) {
         }
     }
     ffh_result_free(res);
+    if (std::find(models.begin(), models.end(), Metric::Reciprocal) != models.end() && !guides.empty()) {
+        // ReciprocalOffTargets.scoreGuides :54-62 is a guides x guides mismatch scan: the same device path with the guide
+        // list resident as the "database" (file order = database order, the file index rides along as the position)
+        const int maxRecip = o.num("maxReciprocalMismatch", 1);  // ScoreResults.scala:85-87
+        std::vector<uint64_t> asTargets(guides.size()), index(guides.size());
+        for (size_t g = 0; g < guides.size(); ++g) { asTargets[g] = (longs[g] & 0xFFFFFFFFFFFFULL) | (1ULL << 48); index[g] = g; }
+        ffh_result *rr = nullptr;
+        if (ffh_db_load_soa(ctx, asTargets.data(), asTargets.size(), index.data(), index.size(), 0) ||
+            ffh_discover(ctx, longs.data(), (uint32_t)guides.size(), std::max(maxRecip, 0), 0x7FFFFFFF, 0, &rr)) {
+            const std::string e = ffh_last_error(ctx);
+            ffh_destroy(ctx);
+            throw Error(e);
+        }
+        const uint64_t *go = ffh_result_guide_offsets(rr), *po = ffh_result_pos_offsets(rr), *pp = ffh_result_positions(rr);
+        const uint8_t *mm = ffh_result_hit_mismatches(rr);
+        for (size_t g = 0; g < guides.size(); ++g)
+            for (uint64_t h = go[g]; h < go[g + 1]; ++h)
+                if (mm[h] != 0) guides[g].reciprocal.push_back(guides[(size_t)pp[po[h]]].target.bases);  // :57-58
+        ffh_result_free(rr);
+    }
     ffh_destroy(ctx);
     std::stable_sort(guides.begin(), guides.end(), [](const CRISPRSiteOT &a, const CRISPRSiteOT &b) { return a.target.position < b.target.position; });  // :137
     TabDelimitedOutput out(o.str("output"), bitEnc, posEnc, models, o.has("includeOTs"), true, o.has("numericOutput"));  // :142-147
@@ -199,8 +219,9 @@ static void usage() {
                  "  index    --reference FILE --database FILE [--enzyme spcas9ngg] [--binSize 7] [--tmpLocation DIR]\n"
                  "  discover --database FILE --fasta FILE --output FILE [--positionOutput] [--maxMismatch 4] [--flankingSequence 6]\n"
                  "           [--maximumOffTargets 2000] [--minGC 0] [--maxGC 1] [--forceLinear] [--gpus N]\n"
-                 "  score    --input FILE --output FILE --scoringMetrics hsu2013,doench2016cfd,minot,dangerous --database FILE\n"
-                 "           [--maxMismatch N] [--includeOTs] [--numericOutput]\n");
+                 "  score    --input FILE --output FILE --database FILE\n"
+                 "           --scoringMetrics hsu2013,doench2016cfd,minot,dangerous,jostandsantos,reciprocalofftargets\n"
+                 "           [--maxMismatch N] [--includeOTs] [--numericOutput] [--maxReciprocalMismatch 1]\n");
 }
 
 int main(int argc, char **argv) {

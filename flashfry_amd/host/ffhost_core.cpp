@@ -235,10 +235,14 @@ Metric metricByName(const std::string &name) {
     if (l == "doench2016cfd") return Metric::Doench2016CFD;
     if (l == "minot") return Metric::MinOT;
     if (l == "dangerous") return Metric::Dangerous;
-    throw Error("Unknown scoring metric: " + name + " (this build scores hit lists on the GPU: hsu2013, doench2016cfd, minot, dangerous)");
+    if (l == "jostandsantos") return Metric::JostAndSantos;
+    if (l == "reciprocalofftargets") return Metric::Reciprocal;
+    throw Error("Unknown scoring metric: " + name +
+                " (this build scores hit lists on the GPU: hsu2013, doench2016cfd, minot, dangerous, jostandsantos, reciprocalofftargets)");
 }
 
 bool metricValidOverEnzyme(Metric m, const ParameterPack &p) {
+    if (m == Metric::JostAndSantos) return p.index != 1 && (p.totalScanLength == 23 || p.totalScanLength == 22);  // JostAndSantosCRISPRi.scala:53-58
     return (m == Metric::Hsu2013 || m == Metric::Doench2016CFD) ? p.cas9_23 : true;
 }
 
@@ -248,6 +252,8 @@ std::vector<std::string> metricHeaderColumns(Metric m) {
         case Metric::Doench2016CFD: return {"DoenchCFD_maxOT", "DoenchCFD_specificityscore"};
         case Metric::MinOT: return {"basesDiffToClosestHit", "closestHitCount", "0-1-2-3-4_mismatch"};
         case Metric::Dangerous: return {"dangerous_GC", "dangerous_polyT", "dangerous_in_genome"};
+        case Metric::JostAndSantos: return {"JostCRISPRi_maxOT", "JostCRISPRi_specificityscore"};  // JostAndSantosCRISPRi.scala:132-134
+        case Metric::Reciprocal: return {"ReciprocalOffTargets"};                                    // ReciprocalOffTargets.scala:98
     }
     return {};
 }
@@ -275,6 +281,14 @@ std::vector<std::string> metricColumns(Metric m, const CRISPRSiteOT &g, const Pa
             if (g.target.bases.substr((size_t)p.guideLo, (size_t)(p.guideHi - p.guideLo)).find("TTTT") != std::string::npos) prob[1] = numeric ? "1" : "PolyT";
             if (!g.offTargets.empty() && s.in_genome > 0) prob[2] = numeric ? std::to_string(s.in_genome) : "IN_GENOME=" + std::to_string(s.in_genome);
             return prob;
+        }
+        case Metric::JostAndSantos:  // JostAndSantosCRISPRi.scoreGuide :42-45 ("0.0" when nothing was scored)
+            return {javaDoubleToString(s.jost_max), javaDoubleToString(1.0 / (1.0 + s.jost_sum))};
+        case Metric::Reciprocal: {   // ReciprocalOffTargets.scoreGuides :54-62; a guide without partners keeps the missing annotation (TabDelimitedHandler.scala:142)
+            if (g.reciprocal.empty()) return {"NA"};
+            std::string joined;
+            for (const auto &b : g.reciprocal) joined += (joined.empty() ? "" : ",") + b;
+            return {joined};
         }
     }
     return {};

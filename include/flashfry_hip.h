@@ -169,6 +169,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mi
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t clamp);
 
 #define FFH_FINALIZE_SUMMARIES_ONLY 1u /* do not copy hit lists / positions to the host */
+#define FFH_FINALIZE_JOST 2u           /* also fill ffh_guide_summary.jost_max / jost_sum (Cas9 enzymes) */
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
                  unsigned flags, ffh_result **out);
 
@@ -197,6 +198,9 @@ typedef struct ffh_guide_summary {
     double cfd_max;          /* max over hits of pam*cfd, 0.0 if none (before the 0.023 print threshold) */
     double cfd_sum;          /* sum of pam*cfd*count in database order; specificity = 1/(1+cfd_sum) */
     double hsu_sum;          /* sum of Hsu2013 hit scores in database order; score = 100/(100+hsu_sum)*100 */
+    double jost_max;         /* JostAndSantosCRISPRi: max hit activity, 0.0 if none (scoring/JostAndSantosCRISPRi.scala:43) */
+    double jost_sum;         /* sum of activity*count in database order; specificity = 1/(1+jost_sum) (:42).  Both are 0
+                                unless FFH_FINALIZE_JOST was passed (ffh_score_lists always fills them) */
 } ffh_guide_summary;
 
 uint32_t ffh_result_n_guides(const ffh_result *r);

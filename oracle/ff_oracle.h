@@ -129,6 +129,7 @@ size_t      ffo_result_total_positions(const ffo_result *r);
 /* ---- scoring over a guide's retained hit list ---- */
 double ffo_cfd_score_pair(const char *guide20, const char *ot20);                       /* Doench2016CFDScore.scala:132-151 */
 double ffo_cfd_pam(const char *pam2);                                                   /* :211-214 */
+double ffo_jost_calc_score(const ffo_pack *p, const char *target, const char *off_target);  /* JostAndSantosCRISPRi.scala:92-127; NaN where it throws */
 double ffo_hsu_score_offtarget(const ffo_pack *p, const char *guide_bases, uint64_t ot);/* CrisprMitEduOffTarget.scala:107-148 */
 
 typedef struct ffo_guide_scores {
@@ -145,6 +146,10 @@ typedef struct ffo_guide_scores {
     int    hist[5];
     /* DangerousSequences :61-65 */
     int    in_genome;
+    /* JostAndSantosCRISPRi.scoreGuide :27-46 (valid for Cas9 20-mers and 19-mers, :53-58) */
+    int    jost_valid;
+    double jost_max;           /* 0.0 when no hit was scored (:43) */
+    double jost_spec;
 } ffo_guide_scores;
 /* per_hit_cfd (optional, n_hits doubles): pam*cfd for scored hits, NaN for hits skipped as on-target */
 int ffo_score_guide(const ffo_pack *p, uint64_t guide, const uint64_t *hit_targets, int n_hits,
@@ -165,7 +170,7 @@ int ffo_discover_fasta(const char *db_path, const char *fasta_path, const char *
                        int max_offtargets, int flank, int position_output, int force_linear,
                        double min_gc, double max_gc);                                                        /* modules/OffTargetDiscovery.scala:79-153 */
 int ffo_score_file(const char *db_path, const char *in_path, const char *out_path, const char *metrics_csv,
-                   int max_mismatch, int include_ots);                                                       /* modules/ScoreResults.scala:90-154 */
+                   int max_mismatch, int include_ots, int max_reciprocal_mismatch);                                                       /* modules/ScoreResults.scala:90-154 */
 
 #ifdef __cplusplus
 }

@@ -406,7 +406,8 @@ int ffo_index_fasta(const char *fasta, const char *db_path, const char *enzyme, 
  * ---------------------------------------------------------------------------------------------- */
 typedef struct score_cols { /* which models were requested, in order (ScoreResults.scala:101-121) */
     int n;
-    int kind[8]; /* 0 hsu2013, 1 doench2016cfd, 2 minot, 3 dangerous */
+    int kind[8]; /* 0 hsu2013, 1 doench2016cfd, 2 minot, 3 dangerous, 4 jostandsantos, 5 reciprocalofftargets */
+    int max_reciprocal; /* ReciprocalOffTargets.maxMismatch (ScoreResults.scala:85-87, default 1) */
 } score_cols;
 
 static double gc_content(const char *s) { /* utils/Utils.scala:46 */
@@ -449,6 +450,8 @@ static void write_table(FILE *f, const ffo_db *db, ffo_guide_ot *guides, const i
         case 1: fprintf(f, "\tDoenchCFD_maxOT\tDoenchCFD_specificityscore"); break;
         case 2: fprintf(f, "\tbasesDiffToClosestHit\tclosestHitCount\t0-1-2-3-4_mismatch"); break;
         case 3: fprintf(f, "\tdangerous_GC\tdangerous_polyT\tdangerous_in_genome"); break;
+        case 4: fprintf(f, "\tJostCRISPRi_maxOT\tJostCRISPRi_specificityscore"); break; /* JostAndSantosCRISPRi.scala:132-134 */
+        case 5: fprintf(f, "\tReciprocalOffTargets"); break;                              /* ReciprocalOffTargets.scala:98 */
     }
     fprintf(f, write_ots ? "\totCount\toffTargets\n" : "\totCount\n"); /* :122-125 */
     for (int r = 0; r < n; r++) {
@@ -483,6 +486,18 @@ static void write_table(FILE *f, const ffo_db *db, ffo_guide_ot *guides, const i
                     memcpy(guide, g->bases + p->guide_lo, (size_t)gl); guide[gl] = 0;
                     fprintf(f, strstr(guide, "TTTT") ? "PolyT\t" : "NONE\t");
                     if (g->n_hits > 0 && s.in_genome > 0) fprintf(f, "IN_GENOME=%d\t", s.in_genome); else fprintf(f, "NONE\t");
+                } break;
+                case 4: /* JostAndSantosCRISPRi.scoreGuide :42-45 (0.0.toString when nothing was scored) */
+                    ffo_java_double_to_string(s.jost_max, d); fprintf(f, "%s\t", d);
+                    ffo_java_double_to_string(s.jost_spec, d); fprintf(f, "%s\t", d);
+                    break;
+                case 5: { /* ReciprocalOffTargets.scoreGuides :54-62: every OTHER guide of the file, in file order, within maxMismatch */
+                    int any = 0;
+                    for (int o = 0; o < n; o++) {
+                        int mmr = ffo_mismatches(p, g->encoding, guides[o].encoding, FFO_STRING_MASK);
+                        if (mmr != 0 && mmr <= sc->max_reciprocal) { fprintf(f, "%s%s", any ? "," : "", guides[o].bases); any = 1; }
+                    }
+                    fprintf(f, any ? "\t" : "NA\t"); /* SingleGuideScoreModel.missingAnnotation, TabDelimitedHandler.scala:142 */
                 } break;
             }
         }
@@ -644,11 +659,11 @@ static int add_offtarget_token(const ffo_db *db, ffo_guide_ot *g, char *token, i
 }
 
 int ffo_score_file(const char *db_path, const char *in_path, const char *out_path, const char *metrics_csv, int max_mm,
-                   int include_ots) {
+                   int include_ots, int max_reciprocal) {
     ffo_db *db = db_read_impl(db_path, 0); /* header only, ScoreResults.scala:91 */
     if (!db) return -1;
     const ffo_pack *p = db->pack;
-    score_cols sc = {0, {0}};
+    score_cols sc = {0, {0}, max_reciprocal};
     int want_cfd = 0;
     {
         char *m = strdup(metrics_csv), *save = NULL;
@@ -658,8 +673,11 @@ int ffo_score_file(const char *db_path, const char *in_path, const char *out_pat
             else if (!strcasecmp(t, "doench2016cfd")) kind = 1;
             else if (!strcasecmp(t, "minot")) kind = 2;
             else if (!strcasecmp(t, "dangerous")) kind = 3;
+            else if (!strcasecmp(t, "jostandsantos")) kind = 4;
+            else if (!strcasecmp(t, "reciprocalofftargets")) kind = 5;
             else { ffo_set_error("Unknown scoring metric: %s", t); free(m); ffo_db_free(db); return -2; }
             if ((kind == 0 || kind == 1) && !p->cas9_23) continue; /* validOverEnzyme -> dropped :111-118 */
+            if (kind == 4 && !(p->index != 1 && (p->scan_len == 23 || p->scan_len == 22))) continue; /* JostAndSantosCRISPRi.scala:53-58 */
             if (kind == 1) want_cfd = 1;
             if (sc.n < 8) sc.kind[sc.n++] = kind;
         }

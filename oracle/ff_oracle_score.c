@@ -83,6 +83,37 @@ double ffo_hsu_score_offtarget(const ffo_pack *p, const char *guide_bases, uint6
     return total * adj; /* :147 */
 }
 
+/* ---- Jost & Santos CRISPRi: scoring/JostAndSantosCRISPRi.scala ---- */
+#include "jost_table.inc"
+
+static char jost_comp(char b) { return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : b; } /* utils/Utils.scala compBase */
+
+/* scoreMapping(ScoreLookup(position, baseA, baseB)): the entry (position, "r<baseA, T as U>:d<baseB>") (:385-389) */
+static double jost_lookup(int position, char base_a, char base_b) {
+    char key[8];
+    snprintf(key, sizeof key, "r%c:d%c", base_a == 'T' ? 'U' : base_a, base_b);
+    for (int i = 0; i < 228; i++)
+        if (FFO_JOST[i].pos == position && !strcmp(FFO_JOST[i].key, key)) return FFO_JOST[i].mean;
+    return NAN; /* NoSuchElementException in the reference; cannot happen for two different ACGT bases */
+}
+
+double ffo_jost_calc_score(const ffo_pack *p, const char *target, const char *off) { /* calc_score :92-127 */
+    double total = 1.0;
+    if ((int)strlen(target) != p->scan_len || (int)strlen(off) != p->scan_len) return NAN; /* asserts :94-95 */
+    if (p->scan_len == 23) {            /* cas9ScanLength20mer: the first base is skipped, positions 1..19 = string offsets 1..19 (:100-109) */
+        for (int index = 0; index < 19; index++) {
+            char base = off[index + 1];
+            if (target[index + 1] != base) total *= jost_lookup(index + 1, base, jost_comp(target[index + 1]));
+        }
+    } else if (p->scan_len == 22) {     /* cas9ScanLength19mer: positions 1..19 = string offsets 0..18 (:112-123) */
+        for (int index = 0; index < 19; index++) {
+            char base = off[index];
+            if (target[index] != base) total *= jost_lookup(index + 1, base, jost_comp(target[index]));
+        }
+    } else return NAN;                  /* IllegalStateException :125 */
+    return total;
+}
+
 int ffo_score_guide(const ffo_pack *p, uint64_t guide, const uint64_t *hits, int n, ffo_guide_scores *out,
                     double *per_hit_cfd) {
     char bases[32], ot[32];
@@ -135,6 +166,24 @@ int ffo_score_guide(const ffo_pack *p, uint64_t guide, const uint64_t *hits, int
     /* DangerousSequences :61-65 */
     for (int i = 0; i < n; i++)
         if (ffo_mismatches(p, hits[i], guide, FFO_STRING_MASK) == 0) out->in_genome += ffo_get_count(hits[i]);
+
+    /* JostAndSantosCRISPRi.scoreGuide :27-46 ; validOverEnzyme :53-58 */
+    out->jost_valid = p->index != 1 && (p->scan_len == 23 || p->scan_len == 22);
+    if (out->jost_valid) {
+        double sum = 0.0, mx = 0.0;
+        int any = 0;
+        for (int i = 0; i < n; i++) {
+            if (ffo_mismatches(p, hits[i], guide, FFO_STRING_MASK) > 0) {   /* filter :40 */
+                ffo_bit_decode(hits[i], p->scan_len, ot);
+                double sc = ffo_jost_calc_score(p, bases, ot);               /* :36 */
+                sum += sc * (double)ffo_get_count(hits[i]);                  /* :42 */
+                if (!any || sc > mx) mx = sc;                                /* :43 */
+                any = 1;
+            }
+        }
+        out->jost_spec = 1.0 / (1.0 + sum);
+        out->jost_max = any ? mx : 0.0;
+    }
     return 0;
 }
 

@@ -58,6 +58,7 @@ def main():
         m["cfd_max"] = float(scored.max()) if len(scored) else 0.0
         m["cfd_sum"] = float(1.0 / s.cfd_spec - 1.0) if len(scored) else 0.0
         m["hsu_sum"] = float(100.0 * 100.0 / s.hsu - 100.0)
+        m["jost_max"], m["jost_sum"] = s.jost_max, float(1.0 / s.jost_spec - 1.0)
     ffdist.allreduce_summaries(summ)
     gathered = [None] * world
     dist.all_gather_object(gathered, kept)
@@ -74,6 +75,7 @@ def main():
                               and int(summ["closest_count"][g]) == exp[g].closest_count for g in range(G)),
             "max_cfd_err": float(max(abs(1.0 / (1.0 + summ["cfd_sum"][g]) - exp[g].cfd_spec) for g in range(G))),
             "max_cfdmax_err": float(max(abs(summ["cfd_max"][g] - exp[g].cfd_max) for g in range(G))),
+            "max_jost_err": float(max(max(abs(summ["jost_max"][g] - exp[g].jost_max), abs(1.0 / (1.0 + summ["jost_sum"][g]) - exp[g].jost_spec)) for g in range(G))),
             "max_hsu_err": float(max(abs(100.0 / (100.0 + summ["hsu_sum"][g]) * 100.0 - exp[g].hsu) for g in range(G))),
             "n_overflowed": int(full.full.sum()), "n_guides": G,
             "crossing": int(sum(1 for g in range(G) if 0 < len(gathered[0][g]) and 0 < sum(len(gathered[r][g]) for r in range(1, world)))),

@@ -26,7 +26,7 @@ def assert_same_hits(gpu, ora, targets=None):
     assert np.array_equal(gpu.summaries["n_hits"].astype(np.uint64), np.diff(ora.guide_offsets))
 
 
-def assert_same_scores(oracle, enzyme, guides, gpu, ora, exact=True):
+def assert_same_scores(oracle, enzyme, guides, gpu, ora, exact=True, jost=False):
     """per-guide CFD / Hsu2013 / closest-hit / in-genome aggregates against the oracle's string-level restatement"""
     for g in range(ora.n_guides):
         s, per = oracle.score_guide(enzyme, int(guides[g]), ora.hits(g))
@@ -35,6 +35,11 @@ def assert_same_scores(oracle, enzyme, guides, gpu, ora, exact=True):
         assert int(m["closest"]) == (0xFFFFFFFF if s.closest == 2 ** 31 - 1 else s.closest)
         assert int(m["closest_count"]) == s.closest_count
         assert int(m["in_genome"]) == s.in_genome
+        if jost:  # JostAndSantosCRISPRi aggregates (requested with FFH_FINALIZE_JOST), bit-identical f64
+            if s.jost_valid:
+                assert float(m["jost_max"]) == s.jost_max and 1.0 / (1.0 + float(m["jost_sum"])) == s.jost_spec, (g, m, s.jost_max, s.jost_spec)
+            else:
+                assert float(m["jost_max"]) == 0.0 and float(m["jost_sum"]) == 0.0
         if s.cfd_valid:
             assert gpu.scores_valid
             a, b = int(gpu.guide_offsets[g]), int(gpu.guide_offsets[g + 1])

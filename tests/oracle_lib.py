@@ -21,7 +21,8 @@ class BinAndMask(C.Structure):
 class GuideScores(C.Structure):
     _fields_ = [("cfd_max", C.c_double), ("cfd_spec", C.c_double), ("cfd_valid", C.c_int),
                 ("hsu", C.c_double), ("hsu_valid", C.c_int),
-                ("closest", C.c_int), ("closest_count", C.c_int), ("hist", C.c_int * 5), ("in_genome", C.c_int)]
+                ("closest", C.c_int), ("closest_count", C.c_int), ("hist", C.c_int * 5), ("in_genome", C.c_int),
+                ("jost_valid", C.c_int), ("jost_max", C.c_double), ("jost_spec", C.c_double)]
 
 
 class Site(C.Structure):
@@ -105,7 +106,9 @@ class Oracle:
         L.ffo_find_sites.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Site), C.c_int]
         L.ffo_index_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.ffo_discover_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
-        L.ffo_score_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.ffo_score_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.ffo_jost_calc_score.restype = C.c_double
+        L.ffo_jost_calc_score.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
 
     # ---- helpers -------------------------------------------------------------------------------
     def pack(self, idx):

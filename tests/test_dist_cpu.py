@@ -32,7 +32,7 @@ def test_sharded_discover_over_gloo(tmp_path, world, max_ot):
     assert res["world"] == world
     for k in ("ok_hits", "ok_totals", "ok_overflow", "ok_hist", "ok_closest"):
         assert res[k], (k, res)
-    assert res["max_cfd_err"] <= 1e-9 and res["max_cfdmax_err"] == 0.0 and res["max_hsu_err"] <= 1e-9, res
+    assert res["max_cfd_err"] <= 1e-9 and res["max_cfdmax_err"] == 0.0 and res["max_hsu_err"] <= 1e-9 and res["max_jost_err"] <= 1e-9, res
     if max_ot == 40:
         assert 0 < res["n_overflowed"] < res["n_guides"] and res["crossing"] > 0  # the cut-off really crossed a shard boundary
 

@@ -29,7 +29,7 @@ def run_both(capi, oracle, odb, targets, positions, guides, enzyme, max_mm, max_
             ctx.load_blocks(longs, offs)
         if plan:
             ctx.set_plan(*plan)
-        gpu = ctx.discover(guides, max_mm, max_ot)
+        gpu = ctx.discover(guides, max_mm, max_ot, jost=True)
         tm = ctx.timings()
     ora = odb.discover(guides, max_mm, max_ot)
     return gpu, ora, tm
@@ -40,7 +40,7 @@ def test_hits_match_oracle_cas9(capi, oracle, max_mm):
     odb, t, p, g = make_case(oracle, 60000, 400, enzyme=3, seed=max_mm)
     gpu, ora, tm = run_both(capi, oracle, odb, t, p, g, 3, max_mm, 2000)
     assert_same_hits(gpu, ora)
-    assert_same_scores(oracle, 3, g, gpu, ora)
+    assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
     assert gpu.n_hits > 0
 
 
@@ -53,7 +53,7 @@ def test_blocks_loader_equals_soa_loader(capi, oracle):
     b, _, _ = run_both(capi, oracle, odb, t, p, g, 2, 4, 2000, via="soa")
     assert_same_hits(a, ora)
     assert_same_hits(b, ora)
-    assert_same_scores(oracle, 2, g, a, ora)
+    assert_same_scores(oracle, 2, g, a, ora, jost=True)
 
 
 def test_device_block_decoder_refuses_malformed_payloads(capi, oracle):
@@ -181,7 +181,7 @@ def test_other_enzymes(capi, oracle, enzyme):
     gpu, ora, _ = run_both(capi, oracle, odb, targets, positions, guides, enzyme, 3, 2000)
     assert_same_hits(gpu, ora)
     assert gpu.n_hits >= 50
-    assert_same_scores(oracle, enzyme, guides, gpu, ora)
+    assert_same_scores(oracle, enzyme, guides, gpu, ora, jost=True)
 
 
 @pytest.mark.parametrize("max_mm", [11, 12, 20, 25])

@@ -43,6 +43,10 @@ def guide_fasta(path, genome_path, n=40, seed=2, mutate=2):
             for p in rng.choice(20, size=int(rng.integers(0, mutate + 1)), replace=False):
                 w[p] = rng.choice(list("ACGT"))
             out.append("".join(w))
+            if len(out) % 5 == 1 and len(out) < n:  # a sibling one base away: reciprocal off-targets of each other
+                k = int(rng.integers(2, 20))
+                w[k] = "ACGT"[("ACGT".index(w[k]) + 1) % 4]
+                out.append("".join(w))
     with open(path, "w") as f:
         for w in out:
             f.write(">random%s\n%s\n" % (w, w))
@@ -165,16 +169,20 @@ def test_discover_and_score_tables_are_byte_identical(cli, oracle, tmp_path, enz
     assert open(out_sh).read() == open(out_cli).read()
     if not positions:
         return  # a discover table without positions cannot be re-read once it carries per-hit scores (reference quirk 15)
-    metrics = "hsu2013,doench2016cfd,minot,dangerous"
-    for include in (False, True):
+    metrics = "hsu2013,doench2016cfd,minot,dangerous,JostAndSantos,reciprocalofftargets"
+    for include, recip in ((False, 1), (True, 3)):
         s_cli, s_ora = str(tmp_path / "cli.scored"), str(tmp_path / "ora.scored")
-        subprocess.check_call([cli, "score", "--input", out_cli, "--output", s_cli, "--scoringMetrics", metrics, "--database", db] + (["--includeOTs"] if include else []),
-                              stderr=subprocess.DEVNULL)
-        assert oracle.lib.ffo_score_file(db.encode(), out_ora.encode(), s_ora.encode(), metrics.encode(), 2 ** 31 - 1, int(include)) == 0, oracle.error()
+        subprocess.check_call([cli, "score", "--input", out_cli, "--output", s_cli, "--scoringMetrics", metrics, "--database", db, "--maxReciprocalMismatch", str(recip)]
+                              + (["--includeOTs"] if include else []), stderr=subprocess.DEVNULL)
+        assert oracle.lib.ffo_score_file(db.encode(), out_ora.encode(), s_ora.encode(), metrics.encode(), 2 ** 31 - 1, int(include), recip) == 0, oracle.error()
         assert open(s_cli).read() == open(s_ora).read()
+        col = open(s_cli).readline().rstrip("\n").split("\t").index("ReciprocalOffTargets")
+        partners = [l.split("\t")[col] for l in open(s_cli).read().split("\n")[1:] if l]
+        assert enzyme == "cpf1" or (any(x != "NA" for x in partners) and any(x == "NA" for x in partners))
     hdr = open(s_cli).readline().rstrip("\n").split("\t")
     if enzyme == "cpf1":  # CFD / Hsu2013 are dropped for non-Cas9 enzymes (ScoreResults.scala:111-118)
         assert "Hsu2013" not in hdr and "basesDiffToClosestHit" in hdr
+        assert "JostCRISPRi_maxOT" not in hdr  # JostAndSantosCRISPRi.scala:53-58
     else:
-        assert hdr[7:10] == ["Hsu2013", "DoenchCFD_maxOT", "DoenchCFD_specificityscore"]
+        assert hdr[7:10] == ["Hsu2013", "DoenchCFD_maxOT", "DoenchCFD_specificityscore"] and "JostCRISPRi_specificityscore" in hdr
         assert "{Doench2016CFDScore=" in open(s_cli).read()

@@ -294,7 +294,7 @@ def test_fake_sites_roundtrip_and_mismatch_fields(oracle, golden_dir, tmp_path):
     db.write(dbp)
     out = str(tmp_path / "fake.sites_temp")
     # metrics "" is not allowed by the CLI; the reference test writes with no models -> use the reader+writer path
-    rc = oracle.lib.ffo_score_file(dbp.encode(), src.encode(), out.encode(), b"minot", 4, 1)
+    rc = oracle.lib.ffo_score_file(dbp.encode(), src.encode(), out.encode(), b"minot", 4, 1, 1)
     assert rc == 0, oracle.error()
     got = open(out).read().split("\n")
     exp = lines
@@ -314,3 +314,24 @@ def test_java_double_to_string(oracle):
              1.2e-5: "1.2E-5", 12345678.9: "1.23456789E7", 0.1: "0.1", 2.0 / 3.0: "0.6666666666666666", 1e21: "1.0E21"}
     for v, s in cases.items():
         assert oracle.java_double(v) == s
+
+
+def _product(factors):
+    x = 1.0
+    for f in factors:
+        x *= f
+    return x
+
+
+def test_jost_and_santos_known_answers(oracle, ka):
+    """JoistAndSantosCRISPRiTest.scala: the reference's own assertions are exact (`should be`), so are these"""
+    for enzyme, target, off, factors, src in ka["jost_pairs"]:
+        assert oracle.lib.ffo_jost_calc_score(oracle.pack(enzyme), target.encode(), off.encode()) == _product(factors), src
+    for enzyme, guide, hits, factors, src in ka["jost_guides"]:
+        s, _ = oracle.score_guide(enzyme, oracle.encode(guide), [oracle.encode(h) for h in hits])
+        assert s.jost_valid and s.jost_max == (_product(factors) if factors else 0.0), src
+        if factors:
+            assert s.jost_spec == 1.0 / (1.0 + _product(factors))
+    s, _ = oracle.score_guide(1, oracle.encode("TTTA" + "A" * 20), [])
+    assert not s.jost_valid                                       # Cpf1: JostAndSantosCRISPRi.scala:53-58
+    assert np.isnan(oracle.lib.ffo_jost_calc_score(oracle.pack(2), b"ACGT", b"ACGT"))  # the length asserts :94-95

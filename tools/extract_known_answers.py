@@ -79,6 +79,22 @@ def main():
         [1, 0, "TAATAATTTAAAAAACCCCCAAAAA", [["TTTTGGGGGTTTTTTAAATTATTA", 0, False, True], ["TTTTTGGGGGTTTTTTAAATTATT", 1, False, True]], "SimpleSiteFinderTest.scala:144-158"],
         [3, 1, "ATTTAAAAAACCCCCAAAAAGGG", [["ATTTAAAAAACCCCCAAAAAGGG", 0, True, False]], "SimpleSiteFinderTest.scala:161-173"],
     ]
+    # ---- scoring/JoistAndSantosCRISPRiTest.scala (exact equality in the reference's tests: `should be(...)`) ----
+    A20 = "A" * 20
+    ka["jost_pairs"] = [
+        # enzyme, target, off-target, expected factors (multiplied left to right), source
+        [2, A20 + "GGG", "T" + "A" * 19 + "GGG", [1.0], "JoistAndSantosCRISPRiTest.scala:18-22"],
+        [2, A20 + "GGG", "AT" + "A" * 18 + "GGG", [0.7952747759038213], "JoistAndSantosCRISPRiTest.scala:24-26"],
+        [2, A20 + "GGG", "AAAATAAAATAAAAGAAAAAGGG", [0.6947382165440157, 0.31016952886752025, 0.26865890093507167], "JoistAndSantosCRISPRiTest.scala:30-34"],
+        [2, A20 + "GGG", "ATAAAAAAAAAAAAAAAAATGGG", [0.7952747759038213, 0.03182081449682617], "JoistAndSantosCRISPRiTest.scala:36-38"],
+    ]
+    ka["jost_guides"] = [
+        # enzyme, guide, hits, expected maxOT factors (empty = "0.0": nothing scored), source
+        [2, A20 + "GGG", [A20 + "GGG"], [], "JoistAndSantosCRISPRiTest.scala:41-48"],
+        [2, A20 + "GGG", ["AAAATAAAATAAAAGAAAAAGGG"], [0.6947382165440157, 0.31016952886752025, 0.26865890093507167], "JoistAndSantosCRISPRiTest.scala:50-57"],
+        [2, A20 + "AGG", ["T" + "A" * 20 + "GG"], [1.0], "JoistAndSantosCRISPRiTest.scala:59-66"],
+        [5, "A" * 19 + "GGG", ["AAATAAAATAAAAGAAAAAGGG"], [0.6947382165440157, 0.31016952886752025, 0.26865890093507167], "JoistAndSantosCRISPRiTest.scala:68-84"],
+    ]
     OUT.write_text(json.dumps(ka, indent=1))
     print("wrote", OUT)
 
