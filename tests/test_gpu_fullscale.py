@@ -1,0 +1,128 @@
+"""The hot path at BASELINE.json's full size (3.0e8 targets, hg38 scale) checked through size-independent properties:
+an independent brute-force torch scan of all targets for a sample of guides, database order, the cut-off rule, planted
+copies at every mismatch level, invariance under the candidate split and under bin sharding.  No oracle here: it would
+need hours at this size (it is the checker at the small sizes in test_gpu_parity.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from flashfry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+T_FULL = int(3.0e8)
+G = 4000
+MAX_OT = 2000
+CMP_MASK = 0x3FFFFFFFFFC0          # StandardScanParameters.scala:143
+UPPER = 0xAAAAAAAAAAAA             # BitEncoding.scala:205
+
+
+def digest(res):
+    h = hashlib.sha256()
+    for a in (res.guide_offsets, res.hit_targets, res.hit_mismatches, res.pos_offsets, res.positions, res.summaries):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def torch_mismatches(torch, guide, targets):
+    """BitEncoding.mismatches :127-132 written with torch integer ops over the whole database"""
+    x = (targets ^ guide) & CMP_MASK
+    y = (x | (x << 1)) & UPPER
+    y = y - ((y >> 1) & 0x5555555555555555)
+    y = (y & 0x3333333333333333) + ((y >> 2) & 0x3333333333333333)
+    y = (y + (y >> 4)) & 0x0F0F0F0F0F0F0F0F
+    return (y * 0x0101010101010101) >> 56 & 0x7F
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    from flashfry_amd import capi
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    guides_dev = synth.make_guides(G, device=dev)
+    db = synth.make_database(T_FULL, seed=synth.DB_SEED, plant_guides=guides_dev, device=dev)
+    ctx = capi.Context(3)
+    torch.cuda.synchronize()
+    ctx.load_soa_device(db["targets"].data_ptr(), db["T"], db["positions"].data_ptr(), db["P"])
+    guides = guides_dev.cpu().numpy().view(np.uint64)
+    yield dict(torch=torch, capi=capi, ctx=ctx, db=db, guides=guides, guides_dev=guides_dev)
+    ctx.close()
+
+
+def test_every_hit_of_sampled_guides_matches_a_brute_force_torch_scan(world):
+    torch, ctx, db = world["torch"], world["ctx"], world["db"]
+    sample = list(range(0, G, 100))[:12] + [1, 2, 3]           # planted guides (every 100th) and plain ones
+    res = ctx.discover(world["guides"], 4, 2 ** 31 - 1)         # no cut-off: the complete hit sets
+    for g in sample:
+        mm = torch_mismatches(torch, int(world["guides"][g].astype(np.int64)), db["targets"])
+        idx = torch.nonzero(mm <= 4).flatten()
+        want = db["targets"][idx].cpu().numpy().view(np.uint64)   # database order = ascending index
+        got = res.hits(g)
+        assert np.array_equal(got, want), g
+        a, b = int(res.guide_offsets[g]), int(res.guide_offsets[g + 1])
+        assert np.array_equal(res.hit_mismatches[a:b], mm[idx].cpu().numpy().astype(np.uint8))
+        po = res.pos_offsets[a:b + 1]
+        src = db["pos_offsets"][idx].cpu().numpy()
+        for k in (0, len(idx) // 2, len(idx) - 1):                # positions of the first, middle and last hit
+            if len(idx):
+                n = int(po[k + 1] - po[k])
+                assert n == int(want[k] >> np.uint64(48))
+                assert np.array_equal(res.positions[int(po[k]):int(po[k + 1])], db["positions"][int(src[k]):int(src[k]) + n].cpu().numpy().view(np.uint64))
+
+
+def test_order_cutoff_and_planted_copies(world):
+    ctx = world["ctx"]
+    res = ctx.discover(world["guides"], 4, MAX_OT, jost=True)
+    s = res.summaries
+    seq = res.hit_targets & np.uint64((1 << 48) - 1)
+    cnt = (res.hit_targets >> np.uint64(48)).astype(np.int64)
+    off = res.guide_offsets.astype(np.int64)
+    gid = np.repeat(np.arange(G), np.diff(off))
+    assert np.all((seq[1:] > seq[:-1]) | (gid[1:] != gid[:-1]))   # strictly ascending sequences inside a guide = database order, no duplicates
+    assert res.hit_mismatches.max() <= 4
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    tot = csum[off[1:]] - csum[off[:-1]]
+    assert np.array_equal(tot, s["ot_count"].astype(np.int64))   # otCount = positions of the retained hits
+    assert np.array_equal(s["overflow"].astype(bool), tot >= MAX_OT)                  # CRISPRSiteOT.full
+    last = np.where(off[1:] > off[:-1], cnt[np.maximum(off[1:] - 1, 0)], 0)
+    assert np.all((tot - last)[s["overflow"].astype(bool)] < MAX_OT)                  # the hit that crossed the limit was the last one added
+    planted = s[::100]
+    ok = ~planted["overflow"].astype(bool)
+    assert ok.sum() >= 30 and np.all(planted["hist"][ok] >= 1)    # an exact copy and copies at 1..4 mismatches were planted
+    assert np.all(planted["in_genome"][ok] >= 1) and np.all(planted["closest"][ok] == 1)
+    scored = s["n_scored"] > 0
+    assert np.all((s["cfd_max"][scored] > 0) & (s["cfd_max"][scored] <= 1.0) & (s["cfd_sum"][scored] >= s["cfd_max"][scored]))
+    assert np.all((s["jost_max"][scored] > 0) & (s["jost_sum"][scored] >= s["jost_max"][scored] - 1e-12))
+    world["reference_digest"] = digest(res)
+
+
+def test_result_does_not_depend_on_the_candidate_split_or_on_sharding(world):
+    torch, capi, ctx, db = world["torch"], world["capi"], world["ctx"], world["db"]
+    if "reference_digest" not in world:
+        world["reference_digest"] = digest(ctx.discover(world["guides"], 4, MAX_OT, jost=True))
+    ctx.set_plan(10, 1)
+    try:
+        assert digest(ctx.discover(world["guides"], 4, MAX_OT, jost=True)) == world["reference_digest"]
+        tm = ctx.timings()
+        assert (tm.prefix_bases, tm.prefix_radius) == (10, 1)
+    finally:
+        ctx.set_plan(-1, -1)
+    # two shards at a target boundary, ordered cut-off continued across them
+    whole = ctx.discover(world["guides"], 4, MAX_OT)
+    cut = db["T"] // 2 + 12345
+    pcut = int(db["pos_offsets"][cut])
+    with capi.Context(3) as c0, capi.Context(3) as c1:
+        c0.load_soa_device(db["targets"].data_ptr(), cut, db["positions"].data_ptr(), pcut)
+        c1.load_soa_device(db["targets"][cut:].data_ptr(), db["T"] - cut, db["positions"][pcut:].data_ptr(), db["P"] - pcut)
+        c0.scan(world["guides"], 4)
+        c1.scan(world["guides"], 4)
+        r0 = c0.finalize(MAX_OT)
+        r1 = c1.finalize(MAX_OT, prior_totals=c0.shard_totals(MAX_OT))
+    n0, n1 = np.diff(r0.guide_offsets.astype(np.int64)), np.diff(r1.guide_offsets.astype(np.int64))
+    assert np.array_equal(n0 + n1, np.diff(whole.guide_offsets.astype(np.int64)))
+    merged = np.concatenate([np.concatenate([r0.hits(g), r1.hits(g)]) for g in range(0, G, 7)])
+    assert np.array_equal(merged, np.concatenate([whole.hits(g) for g in range(0, G, 7)]))
+    assert np.array_equal(r0.summaries["ot_count"] + r1.summaries["ot_count"], whole.summaries["ot_count"])
+    assert np.array_equal(r0.summaries["overflow"] | r1.summaries["overflow"], whole.summaries["overflow"])
