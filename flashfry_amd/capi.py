@@ -19,7 +19,7 @@ FINALIZE_JOST = 2
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
-    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
+    "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
@@ -48,7 +48,8 @@ class DbInfo(C.Structure):
 
 class LoadStats(C.Structure):
     _fields_ = [("open_ms", C.c_double), ("inflate_ms", C.c_double), ("decode_ms", C.c_double), ("prepare_ms", C.c_double),
-                ("compressed_bytes", C.c_uint64), ("raw_bytes", C.c_uint64), ("threads", C.c_uint32), ("reserved", C.c_uint32)]
+                ("compressed_bytes", C.c_uint64), ("raw_bytes", C.c_uint64), ("threads", C.c_uint32), ("reserved", C.c_uint32),
+                ("device_inflate_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

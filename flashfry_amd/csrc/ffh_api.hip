@@ -20,6 +20,7 @@
 #include "../../include/flashfry_hip.h"
 #include "ffh_dbfile.hpp"
 #include "ffh_ingest.hpp"
+#include "ffh_inflate.hpp"
 #include "ffh_kernels.hpp"
 #include "cfd_table.inc"
 #include "jost_table.inc"
@@ -155,6 +156,7 @@ struct ffh_ctx {
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
     double db_prepare_ms = 0;
     ffh_load_stats load{};
+    double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
@@ -597,12 +599,76 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
     if (!e.empty()) { ctx->err = e; return e.rfind("cannot open", 0) == 0 ? FFH_E_IO : FFH_E_FORMAT; }
     const auto t1 = std::chrono::steady_clock::now();
     DevBuf<int64_t> d_raw;
-    FFH_HIP(d_raw.reserve((need_hi - need_lo) / 8 + 1));
     IngestStats is;
-    e = inflate_to_device(body, need_lo, need_hi, (uint8_t *)d_raw.p, ctx->device, is);
-    if (!e.empty()) { d_raw.release(); ctx->err = e; return FFH_E_FORMAT; }
+    const int64_t *payload = nullptr;  // first long of bin_begin's payload
+    size_t m0 = 0, m1 = 0;
+    member_range(body, need_lo, need_hi, m0, m1);
+    const char *where = std::getenv("FFH_INFLATE");  // "host": inflate on the host threads instead of on the device
+    bool on_device = !(where && std::strcmp(where, "host") == 0) && m1 > m0;
+    if (on_device && (need_lo - body.members[m0].uoff) % 8) on_device = false;  // the payload must stay 8-byte aligned inside the members' output
+    ctx->load_device_inflate_ms = 0;
+    if (on_device) {
+        const Member &first = body.members[m0], &last = body.members[m1 - 1];
+        const uint64_t ubase = first.uoff, uspan = last.uoff + last.isize - ubase;
+        const size_t cspan = last.cdata_off + last.cdata_len + 8 - first.coff;
+        DevBuf<uint8_t> d_comp;
+        DevBuf<InflateMember> d_mem;
+        DevBuf<uint16_t> d_work;
+        DevBuf<uint32_t> d_crc;
+        struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() { d_comp.release(); d_mem.release(); d_work.release(); d_crc.release(); }};
+        FFH_HIP(d_comp.reserve(cspan + 64));
+        FFH_HIP(d_raw.reserve(uspan / 8 + 2));
+        e = inflate_to_device(body, need_lo, need_hi, d_comp.p, ctx->device, is, true);
+        if (!e.empty()) { d_raw.release(); ctx->err = e; return FFH_E_FORMAT; }
+        const auto td = std::chrono::steady_clock::now();
+        std::vector<InflateMember> hm;
+        hm.reserve(m1 - m0);
+        for (size_t i = m0; i < m1; ++i) {
+            const Member &m = body.members[i];
+            if (m.isize == 0) continue;
+            hm.push_back(InflateMember{m.cdata_off - first.coff, m.uoff - ubase, (uint32_t)m.cdata_len, m.isize, m.crc, 0u});
+        }
+        std::vector<uint32_t> crc_tab(8 * 256);
+        for (uint32_t v = 0; v < 256; ++v) {
+            uint32_t c = v;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            crc_tab[v] = c;
+        }
+        for (int k = 1; k < 8; ++k)
+            for (uint32_t v = 0; v < 256; ++v) crc_tab[(size_t)k * 256 + v] = (crc_tab[(size_t)(k - 1) * 256 + v] >> 8) ^ crc_tab[crc_tab[(size_t)(k - 1) * 256 + v] & 0xFF];
+        const uint32_t nm = (uint32_t)hm.size(), batch = std::min<uint32_t>(nm, 1u << 16);
+        FFH_HIP(d_mem.reserve(nm + 1));
+        FFH_HIP(d_work.reserve((size_t)batch * kInflateWorkU16 + 64));
+        FFH_HIP(d_crc.reserve(8 * 256));
+        unsigned long long *d_err = ctx->d_counters + 11;
+        FFH_HIP(hipMemcpyAsync(d_mem.p, hm.data(), (size_t)nm * sizeof(InflateMember), hipMemcpyHostToDevice, ctx->st));
+        FFH_HIP(hipMemcpyAsync(d_crc.p, crc_tab.data(), crc_tab.size() * 4, hipMemcpyHostToDevice, ctx->st));
+        FFH_HIP(hipMemsetAsync(d_err, 0xFF, 8, ctx->st));
+        for (uint32_t b0 = 0; b0 < nm; b0 += batch) {
+            const uint32_t nb = std::min(batch, nm - b0);
+            hipLaunchKernelGGL(k_inflate, dim3(blocks_for(nb, 64)), dim3(64), 0, ctx->st, (const uint8_t *)d_comp.p, (const InflateMember *)d_mem.p, b0, nb,
+                               (uint8_t *)d_raw.p, d_work.p, d_err);
+        }
+        if (nm) hipLaunchKernelGGL(k_crc32, dim3(blocks_for(nm, 64)), dim3(64), 0, ctx->st, (const uint8_t *)d_raw.p, (const InflateMember *)d_mem.p, nm,
+                                   (const uint32_t *)d_crc.p, d_err);
+        unsigned long long herr = ~0ull;
+        FFH_HIP(hipMemcpyAsync(&herr, d_err, 8, hipMemcpyDeviceToHost, ctx->st));
+        FFH_HIP(hipStreamSynchronize(ctx->st));
+        if (herr != ~0ull) {
+            d_raw.release();
+            ctx->err = "BGZF inflate / crc failure in the database body (member " + std::to_string((unsigned long long)(herr >> 8)) + ", code " + std::to_string((unsigned)(herr & 0xFF)) + ")";
+            return FFH_E_FORMAT;
+        }
+        ctx->load_device_inflate_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+        payload = d_raw.p + (need_lo - ubase) / 8;
+    } else {
+        FFH_HIP(d_raw.reserve((need_hi - need_lo) / 8 + 1));
+        e = inflate_to_device(body, need_lo, need_hi, (uint8_t *)d_raw.p, ctx->device, is, false);
+        if (!e.empty()) { d_raw.release(); ctx->err = e; return FFH_E_FORMAT; }
+        payload = d_raw.p;
+    }
     const auto t2 = std::chrono::steady_clock::now();
-    int rc = decode_blocks_on_device(ctx, d_raw.p, off, len);
+    int rc = decode_blocks_on_device(ctx, payload, off, len);
     d_raw.release();
     if (rc) return rc;
     const auto t3 = std::chrono::steady_clock::now();
@@ -615,6 +681,7 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
     ctx->load.compressed_bytes = is.compressed_bytes;
     ctx->load.raw_bytes = is.raw_bytes;
     ctx->load.threads = is.threads;
+    ctx->load.device_inflate_ms = ctx->load_device_inflate_ms;
     rc = prepare_database(ctx);
     ctx->n_bins = h.n_bins; ctx->bin_begin = bin_begin; ctx->bin_end = bin_end;
     return rc;

@@ -176,19 +176,24 @@ unsigned usable_cpus() {
 // of one page-locked arena and queues the copy to the device on its own stream, so inflate, PCIe and the next inflate
 // overlap.  All HIP objects are created once by the calling thread (driver calls serialise; per-thread creation cost more
 // than the inflate at 128 threads).
-std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats) {
+void member_range(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, size_t &m0, size_t &m1) {  // members overlapping [need_lo, need_hi)
+    const std::vector<Member> &ms = bf.members;
+    size_t lo = 0, hi = ms.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff + ms[mid].isize <= need_lo) lo = mid + 1; else hi = mid; }
+    m0 = lo;
+    lo = m0; hi = ms.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff < need_hi) lo = mid + 1; else hi = mid; }
+    m1 = lo;
+}
+
+std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats, bool raw_copy) {
     const std::vector<Member> &ms = bf.members;
     stats.threads = 0; stats.compressed_bytes = 0; stats.raw_bytes = need_hi - need_lo;
     if (need_hi <= need_lo) return "";
     size_t m0 = 0, m1 = ms.size();
-    {   // members overlapping [need_lo, need_hi)
-        size_t lo = 0, hi = ms.size();
-        while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff + ms[mid].isize <= need_lo) lo = mid + 1; else hi = mid; }
-        m0 = lo;
-        lo = m0; hi = ms.size();
-        while (lo < hi) { size_t mid = (lo + hi) / 2; if (ms[mid].uoff < need_hi) lo = mid + 1; else hi = mid; }
-        m1 = lo;
-    }
+    member_range(bf, need_lo, need_hi, m0, m1);
+    if (m1 <= m0) return "";
+    const size_t file_lo = ms[m0].coff;  // raw_copy: the members' file bytes go to d_raw + (file offset - file_lo), still compressed
     constexpr size_t kGroup = 32;                 // members per chunk: <= 2 MiB of payload
     constexpr size_t kChunkBytes = kGroup * 65536;
     const size_t nchunks = (m1 - m0 + kGroup - 1) / kGroup;
@@ -241,6 +246,16 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
             const size_t a = m0 + c * kGroup, b = std::min(m1, a + kGroup);
             const uint64_t u0 = ms[a].uoff, u1 = ms[b - 1].uoff + ms[b - 1].isize;
             uint8_t *buf = ln.buf[slot];
+            if (raw_copy) {  // no inflate here: the device decodes (ffh_inflate.hpp); the host only moves the file into page-locked memory
+                const size_t f0 = ms[a].coff, f1 = ms[b - 1].cdata_off + ms[b - 1].cdata_len + 8;
+                std::memcpy(buf, bf.data + f0, f1 - f0);
+                us_inflate += now_us() - w2;
+                if (hipMemcpyAsync(d_raw + (f0 - file_lo), buf, f1 - f0, hipMemcpyHostToDevice, ln.st) != hipSuccess ||
+                    hipEventRecord(ln.ev[slot], ln.st) != hipSuccess) { fail("copy to the device failed"); break; }
+                used[slot] = true;
+                slot ^= 1;
+                continue;
+            }
             for (size_t i = a; i < b && !failed; ++i) {
                 const Member &m = ms[i];
                 if (m.isize == 0) continue;
@@ -278,3 +293,5 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
 }
 
 }  // namespace ffh
+
+extern "C" int ffh_host_threads(void) { return (int)ffh::usable_cpus(); }

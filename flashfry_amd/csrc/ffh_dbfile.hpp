@@ -58,7 +58,12 @@ std::string open_body(const std::string &body_path, BodyFile &out);
 std::string locate_bins(const BodyFile &bf, const DbHeader &h, uint32_t bin_begin, uint32_t bin_end, uint64_t &need_lo, uint64_t &need_hi,
                         std::vector<uint64_t> &bin_off, std::vector<uint64_t> &bin_len);
 
-// inflates [need_lo, need_hi) of the uncompressed stream straight into device memory at d_raw
-std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats);
+// members [m0, m1) whose payload overlaps [need_lo, need_hi) of the uncompressed stream
+void member_range(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, size_t &m0, size_t &m1);
+
+// raw_copy == false: inflates [need_lo, need_hi) of the uncompressed stream on the host threads straight into device memory at d_raw.
+// raw_copy == true : copies the file bytes of the overlapping members, still compressed, to d_raw (d_raw[0] = first byte of member m0);
+//                    the device inflates them (ffh_inflate.hpp).  Same pipeline either way: page-locked slices, one stream per thread.
+std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats, bool raw_copy);
 
 }  // namespace ffh

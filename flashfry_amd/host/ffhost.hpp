@@ -139,9 +139,11 @@ public:
                        bool writeOTs, bool writePositions, bool numericOutput = false);  // :103-125
     ~TabDelimitedOutput();
     void write(const CRISPRSiteOT &guide);  // :131-153
+    void writeAll(const std::vector<CRISPRSiteOT> &guides);  // the same rows, formatted on all usable CPUs
     void close();
 
 private:
+    void format(const CRISPRSiteOT &guide, std::string &row) const;
     struct Sink;
     Sink *out;
     const BitEncoding &enc;
@@ -158,7 +160,7 @@ std::vector<CRISPRSiteOT> readTabDelimited(const std::string &inputFile, const B
 struct ScanStats {
     uint64_t executedComparisons = 0;  // what the reference logs as Traverser.allComparisons (OffTargetDiscovery.scala:137)
     uint64_t targets = 0, positions = 0;
-    double createMs = 0, loadMs = 0, scanMs = 0, finalizeMs = 0;
+    double createMs = 0, loadMs = 0, scanMs = 0, finalizeMs = 0, deliverMs = 0;
     ffh_load_stats load{};  // stages of loadMs on the first shard
     int gpus = 1;
 };

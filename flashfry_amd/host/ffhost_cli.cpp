@@ -88,6 +88,9 @@ int runDiscover(int argc, char **argv) {
     const double minGC = o.real("minGC", 0.0), maxGC = o.real("maxGC", 1.0);
     if (!(minGC >= 0 && minGC <= 1.0) || !(maxGC >= 0 && maxGC <= 1.0)) throw Error("minGC / maxGC must be within [0, 1]");  // :81-82
     const std::string db = o.str("database");
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
     std::fprintf(stderr, "Reading the header....\n");
     const HeaderInfo hdr = readHeaderInfo(db);  // :89
     const ParameterPack &pack = ParameterPack::indexToParameterPack(hdr.enzymeIndex);
@@ -111,6 +114,7 @@ int runDiscover(int argc, char **argv) {
     std::stable_sort(guides.begin(), guides.end(), [](const CRISPRSiteOT &a, const CRISPRSiteOT &b) { return a.target.position < b.target.position; });
     std::fprintf(stderr, "scanning against the known targets from the genome with %zu guides\n", guides.size());
     const bool positions = o.has("positionOutput");
+    const auto t1 = clk::now();
     const ScanStats st = GpuTraverser::scan(db, guides, maxMismatch, maxOT, deviceList(o), positions);  // replaces :120-131
     std::fprintf(stderr, "Performed a total of %llu guide to target comparisons (%llu targets resident on %d GPU(s); load %.1f ms, scan %.1f ms, finalize %.1f ms)\n",
                  (unsigned long long)st.executedComparisons, (unsigned long long)st.targets, st.gpus, st.loadMs, st.scanMs, st.finalizeMs);
@@ -119,12 +123,14 @@ int runDiscover(int argc, char **argv) {
                  st.createMs, st.load.open_ms, st.load.inflate_ms, st.load.threads, st.load.compressed_bytes / 1e6, st.load.raw_bytes / 1e6, st.load.decode_ms,
                  st.load.prepare_ms);
     std::fprintf(stderr, "Writing final output for %zu guides\n", guides.size());
+    const auto t2 = clk::now();
     TabDelimitedOutput out(o.str("output"), bitCoder, posCoder, {}, true, positions);  // :141-146
-    for (auto &g : guides) {
+    for (auto &g : guides)
         for (auto &h : g.offTargets) h.hasCfd = false;  // discover writes no per-hit scores (scoring models = [])
-        out.write(g);
-    }
+    out.writeAll(guides);
     out.close();
+    std::fprintf(stderr, "Host stages: guide discovery %.1f ms, traverser %.1f ms (of which hit delivery %.1f ms), table output %.1f ms\n", ms(t0, t1), ms(t1, t2),
+                 st.deliverMs, ms(t2, clk::now()));
     return 0;
 }
 
@@ -206,7 +212,7 @@ int runScore(int argc, char **argv) {
     ffh_destroy(ctx);
     std::stable_sort(guides.begin(), guides.end(), [](const CRISPRSiteOT &a, const CRISPRSiteOT &b) { return a.target.position < b.target.position; });  // :137
     TabDelimitedOutput out(o.str("output"), bitEnc, posEnc, models, o.has("includeOTs"), true, o.has("numericOutput"));  // :142-147
-    for (const auto &g : guides) out.write(g);
+    out.writeAll(guides);
     out.close();
     return 0;
 }

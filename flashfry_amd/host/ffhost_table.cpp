@@ -6,11 +6,41 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 #include "ffhost.hpp"
 
 namespace ffhost {
+
+// fn(begin, end) over [0, n) in dynamic chunks on the CPUs this process may use (ffh_host_threads: affinity + cgroup quota)
+static void parallelFor(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn) {
+    const size_t chunks = (n + grain - 1) / grain;
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ffh_host_threads()), chunks));
+    std::atomic<size_t> next(0);
+    std::exception_ptr failure;
+    std::mutex mu;
+    auto work = [&]() {
+        try {
+            for (;;) {
+                const size_t a = next.fetch_add(grain);
+                if (a >= n) break;
+                fn(a, std::min(n, a + grain));
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!failure) failure = std::current_exception();
+            next = n;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+}
 
 // ---- output sink: plain file, or gzip when the name ends in .gz (TabDelimitedHandler.scala:112-116) ---------
 struct TabDelimitedOutput::Sink {
@@ -74,10 +104,30 @@ static void appendHit(std::string &o, const CRISPRHit &hit, const CRISPRSiteOT &
     if (hit.hasCfd) o += "{Doench2016CFDScore=" + javaDoubleToString(hit.cfd) + "}";  // toOutputScores :93-104
 }
 
-void TabDelimitedOutput::write(const CRISPRSiteOT &g) {  // :131-153
-    const ParameterPack &p = enc.mParameterPack;
+void TabDelimitedOutput::write(const CRISPRSiteOT &g) {
     std::string o;
-    o.reserve(256 + g.offTargets.size() * 48);
+    format(g, o);
+    out->put(o);
+}
+
+// rows are independent: format slabs of guides on all usable CPUs, write the slabs in order
+void TabDelimitedOutput::writeAll(const std::vector<CRISPRSiteOT> &guides) {
+    const size_t slab = 512, wave = 64 * slab;
+    std::vector<std::string> text;
+    for (size_t base = 0; base < guides.size(); base += wave) {
+        const size_t n = std::min(wave, guides.size() - base);
+        text.assign((n + slab - 1) / slab, std::string());
+        parallelFor(n, slab, [&](size_t a, size_t b) {
+            std::string &o = text[a / slab];
+            for (size_t i = a; i < b; ++i) format(guides[base + i], o);
+        });
+        for (const auto &t : text) out->put(t);
+    }
+}
+
+void TabDelimitedOutput::format(const CRISPRSiteOT &g, std::string &o) const {  // :131-153
+    const ParameterPack &p = enc.mParameterPack;
+    o.reserve(o.size() + 256 + g.offTargets.size() * 48);
     o += g.target.contig + "\t" + std::to_string(g.target.position) + "\t" + std::to_string(g.target.position + (int)g.target.bases.size()) + "\t" + g.target.bases + "\t";
     o += (g.target.hasContext ? g.target.sequenceContext : std::string("NONE")) + "\t";
     o += ((g.full() || g.inheritedOverflow) ? "OVERFLOW" : "OK");
@@ -97,7 +147,6 @@ void TabDelimitedOutput::write(const CRISPRSiteOT &g) {  // :131-153
         }
     }
     o += '\n';
-    out->put(o);
 }
 
 // ---- TabDelimitedInput :169-335 ---------------------------------------------------------------------------------
@@ -170,28 +219,38 @@ std::vector<CRISPRSiteOT> readTabDelimited(const std::string &inputFile, const B
     const bool withOTs = header[nh - 2] == "otCount" && header[nh - 1] == "offTargets";
     if (!withOTs && header[nh - 1] != "otCount") { gzclose(f); throw Error("Unable to parse out the final columns in the header"); }
     const size_t nAnnot = nh - 7 - (withOTs ? 2 : 1);
-    std::vector<CRISPRSiteOT> guides;
-    while (readLine(f, line)) {
-        if (line.empty()) continue;
-        const std::vector<std::string> sp = splitJava(line, '\t');
-        if (sp.size() < 8 + nAnnot) { gzclose(f); throw Error("Unable to parse line: " + line.substr(0, 100)); }
-        CRISPRSiteOT ot;
-        ot.target.contig = sp[0];
-        ot.target.position = std::atoi(sp[1].c_str());
-        ot.target.bases = sp[3];
-        ot.target.hasContext = sp[4] != "NONE";
-        if (ot.target.hasContext) ot.target.sequenceContext = sp[4];
-        ot.target.forwardStrand = sp[6] == "FWD";
-        const bool isOverflowed = sp[5] != "OK";
-        const int otCount = std::atoi(sp[7 + nAnnot].c_str());
-        ot.overflow = isOverflowed ? otCount : otCount + 1;  // :241-245
-        ot.inheritedOverflow = isOverflowed;
-        ot.longEncoding = bitEncoding.bitEncodeString(sp[3]);
-        if (withOTs && sp.size() == nh)
-            for (const auto &tok : splitJava(sp.back(), ',')) addOffTarget(ot, tok, maximumMismatches, bitPosition, bitEncoding);
-        if (!filterOutOverflowedGuides || (!ot.inheritedOverflow && !ot.full())) guides.push_back(std::move(ot));  // :259-262
-    }
+    std::vector<std::string> lines;
+    while (readLine(f, line))
+        if (!line.empty()) lines.push_back(std::move(line));
     gzclose(f);
+    // rows are independent (extractCRISPRSiteOT :225-268): parse them on all usable CPUs, keep the file order
+    std::vector<CRISPRSiteOT> parsed(lines.size());
+    std::vector<uint8_t> keep(lines.size(), 0);
+    parallelFor(lines.size(), 256, [&](size_t a0, size_t b0) {
+        for (size_t li = a0; li < b0; ++li) {
+            const std::vector<std::string> sp = splitJava(lines[li], '\t');
+            if (sp.size() < 8 + nAnnot) throw Error("Unable to parse line: " + lines[li].substr(0, 100));
+            CRISPRSiteOT &ot = parsed[li];
+            ot.target.contig = sp[0];
+            ot.target.position = std::atoi(sp[1].c_str());
+            ot.target.bases = sp[3];
+            ot.target.hasContext = sp[4] != "NONE";
+            if (ot.target.hasContext) ot.target.sequenceContext = sp[4];
+            ot.target.forwardStrand = sp[6] == "FWD";
+            const bool isOverflowed = sp[5] != "OK";
+            const int otCount = std::atoi(sp[7 + nAnnot].c_str());
+            ot.overflow = isOverflowed ? otCount : otCount + 1;  // :241-245
+            ot.inheritedOverflow = isOverflowed;
+            ot.longEncoding = bitEncoding.bitEncodeString(sp[3]);
+            if (withOTs && sp.size() == nh)
+                for (const auto &tok : splitJava(sp.back(), ',')) addOffTarget(ot, tok, maximumMismatches, bitPosition, bitEncoding);
+            keep[li] = !filterOutOverflowedGuides || (!ot.inheritedOverflow && !ot.full());  // :259-262
+            std::string().swap(lines[li]);
+        }
+    });
+    std::vector<CRISPRSiteOT> guides;
+    for (size_t li = 0; li < parsed.size(); ++li)
+        if (keep[li]) guides.push_back(std::move(parsed[li]));
     return guides;
 }
 
@@ -277,7 +336,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     });
     auto t3 = clk::now();
     // deliver the hits in database order = shard order (what aggregator.updateOT would have received)
-    for (size_t g = 0; g < ng; ++g) {
+    parallelFor(ng, 256, [&](size_t g0, size_t g1) {
+    for (size_t g = g0; g < g1; ++g) {
         CRISPRSiteOT &ot = guides[g];
         ot.overflow = maximumOffTargets;
         ffh_guide_summary sum{};
@@ -306,6 +366,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         }
         ot.summary = sum;
     }
+    });
+    st.deliverMs = std::chrono::duration<double, std::milli>(clk::now() - t3).count();
     for (size_t d = 0; d < nd; ++d) {
         ffh_timings tm;
         ffh_get_timings(ctx[d], &tm);

@@ -135,17 +135,23 @@ const char *ffh_indexer_last_error(const ffh_indexer *ix);
 int ffh_indexer_add_contig(ffh_indexer *ix, const char *name, const char *sequence, uint64_t length);
 int ffh_indexer_finish(ffh_indexer *ix, const char *db_path, int bin_width, ffh_index_stats *stats);
 
+/* CPUs this process may really use (hardware threads, affinity mask, cgroup CPU quota; FFH_LOAD_THREADS overrides), <= 128:
+ * what the loader, the writer and the CLI's text formatting size their thread pools with. */
+int ffh_host_threads(void);
+
 /* Where the time of the last ffh_db_open / ffh_db_load_blocks went (milliseconds of host wall time, stages in order). */
 typedef struct ffh_load_stats {
     double open_ms;            /* header parse, mmap, BGZF member directory */
-    double inflate_ms;         /* parallel inflate into page-locked buffers with the copies to the device overlapped
-                                  (ffh_db_load_blocks: the host-to-device copy of the payload longs) */
+    double inflate_ms;         /* BGZF members -> payload longs in device memory: the file is staged through page-locked
+                                  buffers with overlapped copies and inflated on the device (FFH_INFLATE=host: inflated by
+                                  the host threads before the copy); ffh_db_load_blocks: the host-to-device copy */
     double decode_ms;          /* bin payloads -> targets[] / positions[] on the device */
     double prepare_ms;         /* scan images (= ffh_db_info.prepare_ms) */
     uint64_t compressed_bytes; /* BGZF bytes inflated */
     uint64_t raw_bytes;        /* payload bytes produced and copied to the device */
-    uint32_t threads;          /* host threads that inflated */
+    uint32_t threads;          /* host threads that staged (or inflated) */
     uint32_t reserved;
+    double device_inflate_ms;  /* part of inflate_ms spent in the device inflate + CRC kernels (0 with FFH_INFLATE=host) */
 } ffh_load_stats;
 int ffh_db_load_stats(const ffh_ctx *ctx, ffh_load_stats *out);
 /* contig names of the database header (1-based ids as in BitPosition.scala:38-49); NULL past the end */

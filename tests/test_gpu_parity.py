@@ -315,3 +315,70 @@ def test_database_file_roundtrip(capi, oracle, tmp_path):
         r1 = c1.finalize(2000, prior_totals=c0.shard_totals(2000))
     for gi in range(len(g)):
         assert np.array_equal(np.concatenate([r0.hits(gi), r1.hits(gi)]), ora.hits(gi))
+
+
+def _rewrite_bgzf(src, dst, member_bytes, level, strategy):
+    """the same database body re-compressed into BGZF members of `member_bytes` payload with the given zlib settings"""
+    import gzip
+    import zlib
+    raw = gzip.open(src).read()
+    hdr = open(src + ".header").read().split("\n")
+    nbins = int(hdr[3])
+    members, coff, off = [], [0], 0
+    for a in range(0, len(raw), member_bytes):
+        chunk = raw[a:a + member_bytes]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        data = co.compress(chunk) + co.flush()
+        total = 18 + len(data) + 8
+        assert total <= 65536
+        members.append(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + (total - 1).to_bytes(2, "little") + data +
+                       (zlib.crc32(chunk) & 0xFFFFFFFF).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
+        off += total
+        coff.append(off)
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    with open(dst, "wb") as f:
+        f.write(b"".join(members) + eof)
+    lin = 0
+    for b in range(nbins):
+        name, rest = hdr[4 + b].split("=")
+        _, nbytes, nt = rest.split(",")
+        hdr[4 + b] = "%s=%d,%s,%s" % (name, (coff[lin // member_bytes] << 16) | (lin % member_bytes), nbytes, nt)
+        lin += int(nbytes)
+    assert lin == len(raw)
+    with open(dst + ".header", "w") as f:
+        f.write("\n".join(hdr))
+
+
+@pytest.mark.parametrize("member_bytes,level,strategy", [(65280, 5, "default"), (65000, 0, "default"), (4096, 9, "default"), (32768, 6, "fixed"),
+                                                         (65280, 6, "huffman_only"), (8192, 1, "rle"), (65280, 9, "filtered")])
+def test_device_inflate_handles_every_deflate_block_type(capi, oracle, tmp_path, monkeypatch, member_bytes, level, strategy):
+    """the BGZF members are inflated on the device (ffh_inflate.hpp): stored, fixed-Huffman and dynamic-Huffman blocks, short and
+    long matches, small and full-size members; the host-thread inflate (FFH_INFLATE=host) must give the same database"""
+    import zlib
+    odb, t, p, g = make_case(oracle, 40000, 60, enzyme=3, seed=77, max_linear=500)
+    src, dst = str(tmp_path / "src_db"), str(tmp_path / "re_db")
+    odb.write(src)
+    strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED, "huffman_only": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE, "filtered": zlib.Z_FILTERED}[strategy]
+    _rewrite_bgzf(src, dst, member_bytes, level, strat)
+    ora = odb.discover(g, 4, 2000)
+    for where in ("device", "host"):
+        monkeypatch.setenv("FFH_INFLATE", where)
+        with capi.Context(3) as ctx:
+            ctx.open(dst)
+            st = ctx.load_stats()
+            assert (st.device_inflate_ms > 0) == (where == "device")
+            assert (ctx.info().n_targets, ctx.info().n_positions) == (len(t), len(p))
+            assert_same_hits(ctx.discover(g, 4, 2000), ora)
+            c2 = capi.Context(3)
+            c2.open(dst, 5000, 9000)                      # a bin range that starts and ends inside members
+            n_mid = c2.info().n_targets
+            c2.close()
+        assert 0 < n_mid < len(t)
+    # a flipped payload bit must be caught by the CRC check on the device
+    monkeypatch.setenv("FFH_INFLATE", "device")
+    blob = bytearray(open(dst, "rb").read())
+    blob[len(blob) // 2] ^= 0x10
+    open(dst, "wb").write(bytes(blob))
+    with capi.Context(3) as ctx:
+        with pytest.raises(capi.FlashFryHipError, match="inflate / crc failure|BGZF"):
+            ctx.open(dst)
