@@ -636,7 +636,7 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
         }
         for (int k = 1; k < 8; ++k)
             for (uint32_t v = 0; v < 256; ++v) crc_tab[(size_t)k * 256 + v] = (crc_tab[(size_t)(k - 1) * 256 + v] >> 8) ^ crc_tab[crc_tab[(size_t)(k - 1) * 256 + v] & 0xFF];
-        const uint32_t nm = (uint32_t)hm.size(), batch = std::min<uint32_t>(nm, 1u << 16);
+        const uint32_t nm = (uint32_t)hm.size(), batch = std::min<uint32_t>(nm, 1u << 18);  // one launch up to 4x hg38: the kernel is latency-bound per member
         FFH_HIP(d_mem.reserve(nm + 1));
         FFH_HIP(d_work.reserve((size_t)batch * kInflateWorkU16 + 64));
         FFH_HIP(d_crc.reserve(8 * 256));
@@ -646,7 +646,7 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
         FFH_HIP(hipMemsetAsync(d_err, 0xFF, 8, ctx->st));
         for (uint32_t b0 = 0; b0 < nm; b0 += batch) {
             const uint32_t nb = std::min(batch, nm - b0);
-            hipLaunchKernelGGL(k_inflate, dim3(blocks_for(nb, 64)), dim3(64), 0, ctx->st, (const uint8_t *)d_comp.p, (const InflateMember *)d_mem.p, b0, nb,
+            hipLaunchKernelGGL(k_inflate<64>, dim3(blocks_for(nb, 64)), dim3(64), 0, ctx->st, (const uint8_t *)d_comp.p, (const InflateMember *)d_mem.p, b0, nb,
                                (uint8_t *)d_raw.p, d_work.p, d_err);
         }
         if (nm) hipLaunchKernelGGL(k_crc32, dim3(blocks_for(nm, 64)), dim3(64), 0, ctx->st, (const uint8_t *)d_raw.p, (const InflateMember *)d_mem.p, nm,
