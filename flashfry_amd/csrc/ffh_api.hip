@@ -176,7 +176,7 @@ struct ffh_ctx {
     // per-pass scratch
     DevBuf<uint64_t> gkey;                                  // planar guide keys of the current batch (L2-resident)
     DevBuf<uint32_t> gbucket[2], patterns[2], tstart[2], istart[2];
-    DevBuf<uint32_t> icount, ifill, tcount, item_gid, part_fill, part_start, part_items, scan_tmp32;
+    DevBuf<uint32_t> icount, ifill, tcount, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint4> tiles;
     DevBuf<uint32_t> sort_table, sort_offs;
@@ -350,7 +350,10 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
     FFH_HIP(hipMemsetAsync(ctx->part_fill.p, 0, ((size_t)2 * ig.n_part + 2) * 4, st));
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
-    hipLaunchKernelGGL(k_item_partition<false>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
+    FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
+    FFH_HIP(hipMemsetAsync(ctx->part_hist.p, 0, ((size_t)ig.n_part + 1) * 4, st));
+    hipLaunchKernelGGL(k_guide_part_hist, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gbucket.p, ng, ig.low_bits, ctx->part_hist.p);
+    hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 256)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
     hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p);
@@ -434,7 +437,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     for (auto &im : ctx->img) { im.bstart.release(); im.keys.release(); im.tidx.release(); }
     ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->hit_t.release(); ctx->seg_begin.release(); ctx->seg_end.release();
     for (int w = 0; w < 2; ++w) { ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->tstart[w].release(); ctx->istart[w].release(); }
-    ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->item_gid.release(); ctx->part_fill.release(); ctx->part_start.release(); ctx->part_items.release();
+    ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->item_gid.release(); ctx->part_fill.release(); ctx->part_hist.release(); ctx->part_start.release(); ctx->part_items.release();
     ctx->tcount.release(); ctx->scan_tmp32.release(); ctx->scan_tmp64.release();
     ctx->tiles.release(); ctx->sort_table.release(); ctx->sort_offs.release();
     ctx->n_ret.release(); ctx->ot_count.release(); ctx->full.release(); ctx->prior.release(); ctx->out_cnt.release(); ctx->out_tidx.release(); ctx->totals.release();
@@ -888,6 +891,28 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (G) FFH_HIP(hipMemcpyAsync(ctx->prior.p, prior_totals, (size_t)G * 4, hipMemcpyHostToDevice, st));
         d_prior = ctx->prior.p;
     }
+    static_assert(sizeof(GuideSummary) == sizeof(ffh_guide_summary), "summary layouts must agree");
+    if (flags & FFH_FINALIZE_SUMMARIES_ONLY) {
+        // aggregates only: one fused pass per guide (cut-off, scores, ordered sums), no per-hit arrays, one synchronisation
+        ffh_result *r = new (std::nothrow) ffh_result();
+        if (!r || !r->allocate(ctx->pool, G, 0, 0, false)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+        r->scores_valid = ctx->geo.cas9_23;
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, ctx->guides.p, ctx->geo,
+                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p);
+        exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
+        hipError_t e = hipEventRecord(ctx->ev[1], st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
+        r->n_hits = r->guide_offsets[G];
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        ctx->tm.finalize_ms = ms;
+        *out = r;
+        return FFH_OK;
+    }
     if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
                               ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr);
     exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
@@ -924,7 +949,6 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     ffh_result *r = new (std::nothrow) ffh_result();
     if (!r || !r->allocate(ctx->pool, G, Hr, Pr, want_lists)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
     r->scores_valid = ctx->geo.cas9_23;
-    static_assert(sizeof(GuideSummary) == sizeof(ffh_guide_summary), "summary layouts must agree");
     hipError_t e = hipSuccess;
     if (G) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);

@@ -103,10 +103,9 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
 // capacity guess, so skewed guide sets (tiling libraries, repeats) cost nothing extra -- and without per-entry global
 // atomics (device-scope atomics on random addresses run at ~1.3e10/s on MI355X: 4 ms for the 5.6e7 entries of the
 // hg38-scale workload):
-//   A1 k_item_count_parts : a block histograms 64Ki entries over the partitions (= high bits of the bucket id) in LDS
-//                           and adds its counts to the global partition sizes (one atomic per partition and block);
-//      exclusive scan of the <= 4096 partition sizes;
-//   A2 k_item_partition   : same enumeration, each block reserves one run per partition (one atomic each) and writes
+//   A1 k_guide_part_hist + k_part_sizes : the partition (= high bits of the bucket id) sizes, computed without touching
+//                           the entries (XOR convolution of two histograms);  exclusive scan of the <= 4096 sizes;
+//   A2 k_item_partition   : a block enumerates 256Ki entries, reserves one run per partition (one atomic each) and writes
 //                           (low bucket bits, guide) records into the partition's exactly-sized staging range;
 //   B  k_item_bin         : one block per partition counts its records per bucket in LDS, scans the counts, writes
 //                           the CSR offsets of its buckets and scatters the guide ids into place (LDS atomics only).
@@ -145,6 +144,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
     __syncthreads();
     total = tot;
     return off + incl - v;
+}
+
+// Partition sizes without enumerating the entries: bucket = guide bucket ^ pattern acts bit by bit, so the number of
+// entries whose high bits equal q is  sum over patterns p of  #guides whose high bits equal q ^ high(p)  -- an XOR
+// convolution of the guides' partition histogram with the patterns' (<= 4096 x n_pat additions instead of one pass
+// over all n_guides x n_pat entries).
+__global__ void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t *__restrict__ ghist) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_guides) atomicAdd(&ghist[gbucket[g] >> low_bits], 1u);
+}
+__global__ void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t *__restrict__ part_count) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ig.n_part) return;
+    uint32_t n = 0;
+    for (uint32_t p = 0; p < ig.n_pat; ++p) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
+    part_count[q] = n;
 }
 
 template <bool WRITE>
@@ -589,6 +604,9 @@ struct ScoreTables {
 // mismatches + pam*CFD (Doench2016CFDScore.scala:67-73,132-151) + Hsu2013 hit score (CrisprMitEduOffTarget.scala:107-148)
 // of one (guide, target) pair; both scores are NaN for a 0-mismatch hit (the on-target itself) and for enzymes the
 // models are not defined over.  The multiplications run in the reference's order (position 0..19, PAM last).
+// UNROLL: the 20 positions as straight-line code (thread-per-hit kernels: every table load in flight at once) or as a loop
+// (the wave-per-guide epilogue keeps its tables in LDS and needs the registers for occupancy); same operations, same order.
+template <bool UNROLL = true>
 __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab, int &mm_out, double &cfd,
                                            double &hsu) {
     const uint64_t pg = planar_key(gd, geo.c0, geo.lc), pt = planar_key(t, geo.c0, geo.lc);
@@ -601,7 +619,8 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
         // base i (0 = 5' end) of a 23-mer sits at bits [2(22-i)+1 : 2(22-i)]
         double score = 1.0, part_one = 1.0;
         int first = -1, last = -1;
-#pragma unroll
+        constexpr int kUnroll = UNROLL ? 20 : 1;
+#pragma unroll kUnroll
         for (int b = 0; b < 20; ++b) {
             const int sh = 2 * (22 - b);
             const uint32_t gb = (uint32_t)(gd >> sh) & 3u, ob = (uint32_t)(t >> sh) & 3u;
@@ -631,10 +650,12 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
 // the mismatching positions 1..19 of the mean activity for (position, off-target base, complement of the guide base),
 // multiplied in ascending position.  20-mers (scan length 23) skip their first base, 19-mers (22) use all of theirs.
 // Defined for every Cas9 pack (:53-58); the caller skips pairs with no mismatch among the compared bases (:40).
+template <bool UNROLL = true>
 __device__ __forceinline__ double jost_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab) {
     const int first = geo.scan_len == 23 ? 1 : 0;
     double total = 1.0;
-#pragma unroll
+    constexpr int kUnroll = UNROLL ? 19 : 1;
+#pragma unroll kUnroll
     for (int k = 0; k < 19; ++k) {
         const int sh = 2 * (geo.scan_len - 1 - (first + k));
         const uint32_t gb = (uint32_t)(gd >> sh) & 3u, ob = (uint32_t)(t >> sh) & 3u;
@@ -752,6 +773,82 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
     s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
     s.jost_max = jost_max; s.jost_sum = jost_sum;
     if (lane == 0) out[g] = s;
+}
+
+// The epilogue of a discover call that only wants the per-guide aggregates (FFH_FINALIZE_SUMMARIES_ONLY), one wave per
+// guide and one pass over its hits: ordered cut-off (k_cutoff), per-hit scores (k_score_hits) and the aggregation
+// (k_guide_aggregate) without any per-hit array in between.  Same arithmetic in the same order, so the summaries are
+// bit-identical to the three-kernel path that also delivers the hit lists.
+__global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
+                                                        const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
+                                                        const ScoreTables *__restrict__ tab, uint32_t n_guides, uint32_t overflow, int want_jost,
+                                                        uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out) {
+    __shared__ ScoreTables lt;  // 4.6 KB: the coefficient tables, read with rolled loops (low register count -> 8 waves per SIMD)
+    {
+        const double *src = reinterpret_cast<const double *>(tab);
+        double *dst = reinterpret_cast<double *>(&lt);
+        for (uint32_t i = threadIdx.x; i < sizeof(ScoreTables) / sizeof(double); i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_guides) return;
+    const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
+    const uint64_t gd = guides[g];
+    uint32_t run = p0, kept = 0;
+    uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, closest_count = 0, n_scored = 0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0;
+    for (uint32_t i = b; i < e && run < overflow; i += 64) {
+        const bool in = i + lane < e;
+        const uint64_t t = in ? st[i + lane] : 0ull;
+        const uint32_t c = in ? (uint32_t)(t >> 48) : 0u;
+        const uint32_t incl = wave_inclusive_scan_u32(c, lane);
+        const bool keep = in && (run + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
+        const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
+        kept += nk;
+        if (nk) run += __shfl(incl, nk - 1, 64);
+        int mmi = 0xFF;
+        double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
+        if (keep) {
+            score_pair<false>(gd, t, geo, &lt, mmi, f, h);
+            if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair<false>(gd, t, geo, &lt);
+        }
+        const uint32_t m = keep ? (uint32_t)mmi : 0xFFu, ck = keep ? c : 0u;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) hist[k] += (m == (uint32_t)k) ? ck : 0u;  // ClosestHit.scala:57-59
+        const uint32_t cm = wave_min_u32((keep && m > 0) ? m : 0xFFFFFFFFu);  // :62-67, folded chunk by chunk
+        if (cm < closest) { closest = cm; closest_count = 0; }
+        if (cm != 0xFFFFFFFFu && cm == closest) closest_count += wave_sum_u32((m == closest) ? ck : 0u);
+        const double fc = f * (double)c;
+        uint64_t scored = __ballot(keep && f == f);
+        while (scored) {                                                       // wave-uniform walk in hit order
+            const uint32_t l = (uint32_t)__builtin_ctzll(scored);
+            scored &= scored - 1;
+            cfd_sum += bcast_f64(fc, l);
+            hsu_sum += bcast_f64(h, l);
+            cfd_max = fmax(cfd_max, bcast_f64(f, l));
+            ++n_scored;
+        }
+        if (want_jost) {
+            const double jc = j * (double)c;
+            uint64_t js = __ballot(keep && j == j);
+            while (js) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(js);
+                js &= js - 1;
+                jost_sum += bcast_f64(jc, l);
+                jost_max = fmax(jost_max, bcast_f64(j, l));
+            }
+        }
+    }
+    GuideSummary s;
+    s.n_hits = kept; s.ot_count = run - p0; s.overflow = run >= overflow;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s.hist[k] = wave_sum_u32(hist[k]);
+    s.closest = closest;
+    s.closest_count = closest == 0xFFFFFFFFu ? 0u : closest_count;
+    s.in_genome = s.hist[0]; s.n_scored = n_scored;
+    s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
+    s.jost_max = jost_max; s.jost_sum = jost_sum;
+    if (lane == 0) { out[g] = s; n_ret[g] = kept; }
 }
 
 __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ out_off,

@@ -31,6 +31,10 @@ def run_both(capi, oracle, odb, targets, positions, guides, enzyme, max_mm, max_
             ctx.set_plan(*plan)
         gpu = ctx.discover(guides, max_mm, max_ot, jost=True)
         tm = ctx.timings()
+        # the fused aggregates-only epilogue (what bench.py times) must agree with the list-delivering path bit for bit
+        only = ctx.finalize(max_ot, summaries_only=True, jost=True)
+        assert only.summaries.tobytes() == gpu.summaries.tobytes() and np.array_equal(only.guide_offsets, gpu.guide_offsets)
+        assert only.n_hits == gpu.n_hits
     ora = odb.discover(guides, max_mm, max_ot)
     return gpu, ora, tm
 
@@ -281,6 +285,8 @@ def test_two_shards_with_ordered_cutoff(capi, oracle):
         totals = [c.shard_totals(max_ot) for c in ctxs]
         prior = [np.zeros(len(g), np.uint32), totals[0]]
         res = [c.finalize(max_ot, prior_totals=pr) for c, pr in zip(ctxs, prior)]
+        only = [c.finalize(max_ot, prior_totals=pr, summaries_only=True) for c, pr in zip(ctxs, prior)]   # the fused epilogue continues the cut-off too
+        assert all(o.summaries.tobytes() == r.summaries.tobytes() for o, r in zip(only, res))
     finally:
         for c in ctxs:
             c.close()
