@@ -223,6 +223,8 @@ def test_edge_cases(capi, oracle):
         ctx.load_soa(t, p)
         r = ctx.discover(np.zeros(0, dtype=np.uint64), 4, 2000)           # no guides
         assert r.n_guides == 0 and r.n_hits == 0
+        r = ctx.discover(np.zeros(0, dtype=np.uint64), 4, 2000, summaries_only=True)
+        assert r.n_guides == 0 and r.n_hits == 0 and len(r.summaries) == 0
         far = np.array([oracle.encode("ACGT" * 5 + "AGG")], dtype=np.uint64)  # a guide without any hit
         r = ctx.discover(far, 0, 2000)
         assert r.n_guides == 1
