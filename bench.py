@@ -132,8 +132,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # FFH_BENCH_FORCE_EXCHANGE=1 runs the sharded step (device-resident exchange over RCCL) with a single rank: a way to
+    # exercise and time that code path on a 1-GPU box
+    sharded = world > 1 or os.environ.get("FFH_BENCH_FORCE_EXCHANGE") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     T_req, G = int(args.targets), args.guides
@@ -179,14 +185,17 @@ def main():
         del a, b
         torch.cuda.empty_cache()
 
+    exch = ffdist.DeviceExchange(G, dev) if sharded else None
+
     def step():
         ctx.scan(guides_np, args.max_mismatch)
-        prior = None
-        if world > 1:
-            prior = ffdist.prior_totals(ctx.shard_totals(args.max_offtargets), args.max_offtargets, device=dev)
-        res = ctx.finalize(args.max_offtargets, prior_totals=prior, summaries_only=True)
-        if world > 1:
-            ffdist.allreduce_summaries(res.summaries, dev)
+        if not sharded:
+            return ctx.finalize(args.max_offtargets, summaries_only=True)
+        # bin shards: shard totals -> all-gather -> ordered cut-off continued across shards -> reduce of the aggregates,
+        # all on device memory over RCCL; rank 0 takes the reduced aggregates to the host like the single-GPU step does
+        res = exch.step(ctx, args.max_offtargets)
+        if rank == 0:
+            res.reduced = exch.summaries_numpy()
         return res
 
     for _ in range(args.warmup):
@@ -219,7 +228,8 @@ def main():
         ms_step = dt / args.steps * 1e3
         cmp_ms = float(np.mean([t["compare_ms"] for t in tms]))
         raw_hits = int(np.mean([t["n_raw_hits"] for t in tms]))
-        kept_pos = int(res.summaries["ot_count"].sum())
+        final = res.reduced if sharded else res.summaries
+        kept_pos = int(final["ot_count"].sum())
         # algorithmic bytes of ONE compare launch: every resident target once (8 B), every guide once (8 B), one 8-byte record per hit
         b_alg = 8 * T + 8 * G + 8 * raw_hits
         b_survey = 8 * T + 8 * G + 16 * raw_hits + 8 * kept_pos  # SURVEY.md §8d formula for the whole discover
@@ -254,13 +264,21 @@ def main():
             "plan": {"prefix_bases": tms[-1]["prefix_bases"], "prefix_radius": tms[-1]["prefix_radius"], "suffix_bases": info.suffix_bases,
                      "suffix_radius": tms[-1]["suffix_radius"], "items": tms[-1]["items_prefix"] + tms[-1]["items_suffix"],
                      "tiles": tms[-1]["tiles_prefix"] + tms[-1]["tiles_suffix"]},
-            "hits": {"raw": raw_hits, "kept_positions": kept_pos, "overflowed_guides": int(res.summaries["overflow"].sum())},
+            "hits": {"raw": raw_hits, "kept_positions": kept_pos, "overflowed_guides": int(final["overflow"].sum())},
             "algorithmic_bytes_survey": b_survey,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     ctx.close()
-    if world > 1:
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # RCCL prints a version banner into the C stdio buffer of stdout: every rank gets it out first
+    sys.stdout.flush()
+    if sharded:
+        dist.barrier()
         dist.destroy_process_group()
+    if out is not None:  # the one JSON line is the last thing the job writes
+        print(json.dumps(out), flush=True)
+    os._exit(0)  # nothing (library destructors included) may write after the result line
 
 
 if __name__ == "__main__":

@@ -15,13 +15,14 @@ i64p = C.POINTER(C.c_int64)
 
 FINALIZE_SUMMARIES_ONLY = 1
 FINALIZE_JOST = 2
+FINALIZE_PRIOR_ON_DEVICE = 4
 
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
     "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
-    "ffh_shard_totals", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
@@ -93,6 +94,13 @@ def load_library(build=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64.  Whichever HIP runtime is loaded first serves the
+    # whole process (same SONAME); a second HSA runtime cannot open the GPU ("No HIP GPUs are available").  When torch is
+    # part of the process (tests, bench.py, torch.distributed) it therefore has to be loaded before this library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.build_hip_library() if build else _build.LIB
     if not os.path.exists(path):
         raise ImportError("libflashfry_hip.so is missing (%s): build it with `python -m flashfry_amd._build`; "
@@ -126,6 +134,8 @@ def load_library(build=True):
     L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ffh_scan.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int]
     L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
+    L.ffh_shard_totals_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ffh_summaries_to_device.argtypes = [C.c_void_p, C.c_void_p]
     L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_discover.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_score_lists.argtypes = [C.c_void_p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_void_p)]
@@ -324,6 +334,21 @@ class Context:
         t = np.zeros(max(self._n_guides, 1), dtype=np.uint32)
         self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))
         return t[:self._n_guides]
+
+    def shard_totals_device(self, device_ptr, clamp):
+        """per-guide position totals of this shard (saturated at clamp) written to a device buffer of n_guides uint32"""
+        self._check(self.L.ffh_shard_totals_device(self.h, C.c_void_p(device_ptr), clamp))
+
+    def summaries_to_device(self, device_ptr):
+        """the summaries of the last finalize copied to a device buffer of n_guides * SUMMARY_DTYPE.itemsize bytes"""
+        self._check(self.L.ffh_summaries_to_device(self.h, C.c_void_p(device_ptr)))
+
+    def finalize_device_prior(self, max_offtargets, prior_device_ptr, summaries_only=True, jost=False):
+        """finalize with the prior totals taken from device memory (n_guides uint32)"""
+        out = C.c_void_p()
+        flags = (FINALIZE_SUMMARIES_ONLY if summaries_only else 0) | (FINALIZE_JOST if jost else 0) | FINALIZE_PRIOR_ON_DEVICE
+        self._check(self.L.ffh_finalize(self.h, C.cast(C.c_void_p(prior_device_ptr), u32p), max_offtargets, flags, C.byref(out)))
+        return Result(self.L, out.value, lists=not summaries_only)
 
     def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False, jost=False):
         out = C.c_void_p()

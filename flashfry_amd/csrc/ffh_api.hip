@@ -872,6 +872,27 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     return FFH_OK;
 }
 
+int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals, uint32_t clamp) {
+    if (!ctx || !device_totals) return FFH_E_ARG;
+    if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    if (ctx->n_guides)
+        hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
+                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, device_totals);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
+
+int ffh_summaries_to_device(ffh_ctx *ctx, void *device_summaries) {
+    if (!ctx || !device_summaries) return FFH_E_ARG;
+    if (!ctx->scanned) { ctx->err = "no finalized scan"; return FFH_E_STATE; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    if (ctx->n_guides) FFH_HIP(hipMemcpyAsync(device_summaries, ctx->summ.p, (size_t)ctx->n_guides * sizeof(ffh_guide_summary), hipMemcpyDeviceToDevice, ctx->st));
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
+
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets, unsigned flags, ffh_result **out) {
     if (!ctx || !out || max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
@@ -888,7 +909,8 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     const uint32_t *d_prior = nullptr;
     if (prior_totals) {
         FFH_HIP(ctx->prior.reserve((size_t)G + 1));
-        if (G) FFH_HIP(hipMemcpyAsync(ctx->prior.p, prior_totals, (size_t)G * 4, hipMemcpyHostToDevice, st));
+        if (flags & FFH_FINALIZE_PRIOR_ON_DEVICE) FFH_HIP(hipDeviceSynchronize());  // the producer (an RCCL collective, a torch op) used another stream
+        if (G) FFH_HIP(hipMemcpyAsync(ctx->prior.p, prior_totals, (size_t)G * 4, (flags & FFH_FINALIZE_PRIOR_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         d_prior = ctx->prior.p;
     }
     static_assert(sizeof(GuideSummary) == sizeof(ffh_guide_summary), "summary layouts must agree");

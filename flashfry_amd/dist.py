@@ -77,3 +77,86 @@ def allreduce_summaries(summ, device=None, group=None):
     summ["closest"] = gmin.astype(np.uint32); summ["closest_count"] = cc
     summ["cfd_sum"] = acc[:, 0]; summ["hsu_sum"] = acc[:, 1]; summ["jost_sum"] = acc[:, 2]
     return summ
+
+
+class DeviceExchange:
+    """The two exchanges of a sharded discover on device memory (no host round trip): buffers are allocated once.
+
+    step(ctx, max_offtargets) runs after ctx.scan(...) on every rank: shard totals -> all-gather -> prior totals ->
+    ffh_finalize (aggregates only) -> reduction of the aggregates; returns the reduced summaries as a
+    uint8 [G, itemsize] device tensor (view it with summaries_numpy())."""
+
+    def __init__(self, n_guides, device, group=None, itemsize=88):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.device = torch, dist, group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.G, self.itemsize = n_guides, itemsize
+        assert itemsize == 88, "layout of ffh_guide_summary: 12 x u32 then 5 x f64"
+        self.totals = torch.zeros(n_guides, dtype=torch.int32, device=device)
+        self.all_totals = torch.zeros(self.world * n_guides, dtype=torch.int32, device=device)
+        self.prior = torch.zeros(n_guides, dtype=torch.int32, device=device)
+        self.summ = torch.zeros(n_guides * itemsize, dtype=torch.uint8, device=device)
+        self.fsum_all = torch.zeros(self.world * n_guides * 3, dtype=torch.float64, device=device)
+
+    def _all_gather(self, out_flat, inp):
+        # chunk views of one flat buffer: works with every backend (RCCL gathers in place, gloo copies)
+        self.dist.all_gather(list(out_flat.chunk(self.world)), inp, group=self.group)
+
+    def prior_totals(self, ctx, max_offtargets):
+        ctx.shard_totals_device(self.totals.data_ptr(), max_offtargets)
+        return self.prior_from_totals(max_offtargets)
+
+    def prior_from_totals(self, max_offtargets):
+        """self.totals (this shard's saturated per-guide totals) -> self.prior (saturated sum over the lower-ranked shards)"""
+        torch = self.torch
+        self._all_gather(self.all_totals, self.totals)
+        if self.rank:
+            lower = self.all_totals.view(self.world, self.G)[: self.rank].to(torch.int64).sum(0)
+            self.prior.copy_(torch.clamp(lower, max=int(max_offtargets)).to(torch.int32))
+        else:
+            self.prior.zero_()
+        return self.prior
+
+    def reduce_summaries(self):
+        """in place on self.summ: integer lanes by sum, maxima by max, closest hit by min + masked count, f64 sums gathered
+        and added in rank order (= database order of the shards: deterministic, like the host path)"""
+        torch, dist, G = self.torch, self.dist, self.G
+        i32 = self.summ.view(torch.int32).view(G, 22)
+        f64 = self.summ.view(torch.float64).view(G, 11)
+        sums = i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]].contiguous()       # n_hits, ot_count, hist[5], in_genome, n_scored
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        mx = torch.stack([i32[:, 2].to(torch.float64), f64[:, 6], f64[:, 9]], 1).contiguous()  # overflow, cfd_max, jost_max
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        closest = i32[:, 8].to(torch.int64) & 0xFFFFFFFF                 # 0xFFFFFFFF = none
+        gmin = closest.clone()
+        dist.all_reduce(gmin, op=dist.ReduceOp.MIN, group=self.group)
+        cc = torch.where(closest == gmin, i32[:, 9].to(torch.int64), torch.zeros_like(gmin))
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM, group=self.group)
+        fl = f64[:, [7, 8, 10]].contiguous().view(-1)                    # cfd_sum, hsu_sum, jost_sum
+        self._all_gather(self.fsum_all, fl)
+        parts = self.fsum_all.view(self.world, G, 3)
+        acc = parts[0].clone()
+        for r in range(1, self.world):
+            acc += parts[r]
+        i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]] = sums
+        i32[:, 2] = mx[:, 0].to(torch.int32)
+        f64[:, 6] = mx[:, 1]
+        f64[:, 9] = mx[:, 2]
+        i32[:, 8] = torch.where(gmin > 0x7FFFFFFF, gmin - (1 << 32), gmin).to(torch.int32)
+        i32[:, 9] = cc.to(torch.int32)
+        f64[:, 7] = acc[:, 0]
+        f64[:, 8] = acc[:, 1]
+        f64[:, 10] = acc[:, 2]
+        return self.summ
+
+    def step(self, ctx, max_offtargets, jost=False):
+        prior = self.prior_totals(ctx, max_offtargets)
+        res = ctx.finalize_device_prior(max_offtargets, prior.data_ptr(), summaries_only=True, jost=jost)
+        ctx.summaries_to_device(self.summ.data_ptr())
+        self.reduce_summaries()
+        return res
+
+    def summaries_numpy(self):
+        from . import capi
+        return self.summ.cpu().numpy().view(capi.SUMMARY_DTYPE)

@@ -176,11 +176,18 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t cla
 
 #define FFH_FINALIZE_SUMMARIES_ONLY 1u /* do not copy hit lists / positions to the host */
 #define FFH_FINALIZE_JOST 2u           /* also fill ffh_guide_summary.jost_max / jost_sum (Cas9 enzymes) */
+#define FFH_FINALIZE_PRIOR_ON_DEVICE 4u /* prior_totals is a device pointer (multi-GPU exchange without a host round trip) */
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
                  unsigned flags, ffh_result **out);
 
 int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets,
                  unsigned flags, ffh_result **out);
+
+/* Device-resident halves of the multi-GPU exchange (one process per GPU, RCCL): the shard totals are written to, and the
+ * summaries of the last ffh_finalize copied to, device buffers of the caller (n_guides x uint32 / n_guides x
+ * sizeof(ffh_guide_summary) bytes), so that the collectives run on device memory.  Both return after the copy completed. */
+int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals /* n_guides */, uint32_t clamp);
+int ffh_summaries_to_device(ffh_ctx *ctx, void *device_summaries);
 
 /* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
  * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the

@@ -59,7 +59,15 @@ def main():
         m["cfd_sum"] = float(1.0 / s.cfd_spec - 1.0) if len(scored) else 0.0
         m["hsu_sum"] = float(100.0 * 100.0 / s.hsu - 100.0)
         m["jost_max"], m["jost_sum"] = s.jost_max, float(1.0 / s.jost_spec - 1.0)
+    # the device-resident exchange used by bench.py (here on CPU tensors over gloo) must agree with the host path bit for bit
+    import torch
+    ex = ffdist.DeviceExchange(G, "cpu")
+    ex.totals.copy_(torch.from_numpy(totals.astype(np.int32)))
+    prior_dev = ex.prior_from_totals(max_ot).numpy().astype(np.uint32)
+    ex.summ.copy_(torch.from_numpy(summ.view(np.uint8).reshape(-1).copy()))
+    ex.reduce_summaries()
     ffdist.allreduce_summaries(summ)
+    same_exchange = bool(np.array_equal(prior_dev, prior)) and ex.summ.numpy().tobytes() == summ.tobytes()
     gathered = [None] * world
     dist.all_gather_object(gathered, kept)
     if rank == 0:
@@ -67,7 +75,7 @@ def main():
         ok_hits = all(sum((gathered[r][g] for r in range(world)), []) == [int(x) for x in full.hits(g)] for g in range(G))
         exp = [oracle.score_guide(3, int(guides[g]), full.hits(g))[0] for g in range(G)]
         res = {
-            "world": world, "ok_hits": bool(ok_hits),
+            "world": world, "ok_hits": bool(ok_hits), "ok_device_exchange": same_exchange,
             "ok_totals": bool(np.array_equal(summ["ot_count"].astype(np.int64), full.current_total)),
             "ok_overflow": bool(np.array_equal(summ["overflow"].astype(bool), full.full)),
             "ok_hist": all(list(summ["hist"][g]) == list(exp[g].hist) for g in range(G)),

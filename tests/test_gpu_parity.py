@@ -390,3 +390,48 @@ def test_device_inflate_handles_every_deflate_block_type(capi, oracle, tmp_path,
     with capi.Context(3) as ctx:
         with pytest.raises(capi.FlashFryHipError, match="inflate / crc failure|BGZF"):
             ctx.open(dst)
+
+
+def test_device_resident_exchange_entry_points(capi, oracle):
+    """ffh_shard_totals_device / FFH_FINALIZE_PRIOR_ON_DEVICE / ffh_summaries_to_device (what bench.py uses for N > 1) against the
+    host-pointer forms, with two shards on the one GPU; then flashfry_amd.dist.DeviceExchange over a 1-rank RCCL group"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from flashfry_amd import dist as ffdist
+    odb, t, p, g = dense_case(oracle, seed=12)
+    cut = len(t) // 2
+    counts = (t >> np.uint64(48)).astype(np.int64)
+    pcut = int(counts[:cut].sum())
+    dev = torch.device("cuda", 0)
+    max_ot = 60
+    with capi.Context(3) as c0, capi.Context(3) as c1:
+        c0.load_soa(t[:cut], p[:pcut])
+        c1.load_soa(t[cut:], p[pcut:])
+        c0.scan(g, 5)
+        c1.scan(g, 5)
+        tot_dev = torch.zeros(len(g), dtype=torch.int32, device=dev)
+        c0.shard_totals_device(tot_dev.data_ptr(), max_ot)
+        host_tot = c0.shard_totals(max_ot)
+        assert np.array_equal(tot_dev.cpu().numpy().astype(np.uint32), host_tot)
+        a = c1.finalize(max_ot, prior_totals=host_tot, summaries_only=True)
+        b = c1.finalize_device_prior(max_ot, tot_dev.data_ptr(), summaries_only=True)
+        assert a.summaries.tobytes() == b.summaries.tobytes() and a.summaries["overflow"].any()
+        buf = torch.zeros(len(g) * capi.SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        c1.summaries_to_device(buf.data_ptr())
+        assert buf.cpu().numpy().tobytes() == b.summaries.tobytes()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=dev)
+    try:
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            ctx.scan(g, 5)
+            want = ctx.finalize(max_ot, summaries_only=True, jost=True).summaries.copy()
+            ex = ffdist.DeviceExchange(len(g), dev)
+            ex.step(ctx, max_ot, jost=True)
+            assert ex.summaries_numpy().tobytes() == want.tobytes()
+    finally:
+        dist.destroy_process_group()
