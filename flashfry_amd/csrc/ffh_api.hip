@@ -44,9 +44,18 @@ void set_global_error(const std::string &m) { g_create_error = m; }
 namespace {
 
 template <typename T>
-struct DevBuf {
+struct DevBuf {  // device allocation that grows on demand and frees itself (on the device that is current: the entry points set it)
     T *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     hipError_t reserve(size_t n) {  // contents are NOT preserved
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -433,21 +442,11 @@ void ffh_destroy(ffh_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-    ctx->targets.release(); ctx->positions.release(); ctx->pos_off.release();
-    for (auto &im : ctx->img) { im.bstart.release(); im.keys.release(); im.tidx.release(); }
-    ctx->guides.release(); ctx->hits.release(); ctx->hits_alt.release(); ctx->hit_t.release(); ctx->seg_begin.release(); ctx->seg_end.release();
-    for (int w = 0; w < 2; ++w) { ctx->gbucket[w].release(); ctx->patterns[w].release(); ctx->tstart[w].release(); ctx->istart[w].release(); }
-    ctx->gkey.release(); ctx->icount.release(); ctx->ifill.release(); ctx->item_gid.release(); ctx->part_fill.release(); ctx->part_hist.release(); ctx->part_start.release(); ctx->part_items.release();
-    ctx->tcount.release(); ctx->scan_tmp32.release(); ctx->scan_tmp64.release();
-    ctx->tiles.release(); ctx->sort_table.release(); ctx->sort_offs.release();
-    ctx->n_ret.release(); ctx->ot_count.release(); ctx->full.release(); ctx->prior.release(); ctx->out_cnt.release(); ctx->out_tidx.release(); ctx->totals.release();
-    ctx->ret_off.release(); ctx->out_target.release(); ctx->out_posoff.release(); ctx->out_pos.release(); ctx->out_mm.release();
-    ctx->out_cfd.release(); ctx->out_hsu.release(); ctx->out_jost.release(); ctx->summ.release();
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->st) (void)hipStreamDestroy(ctx->st);
-    delete ctx;
+    delete ctx;  // the device buffers free themselves
 }
 
 int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius) {
@@ -485,10 +484,6 @@ static int decode_blocks_on_device(ffh_ctx *ctx, const int64_t *d_raw, const std
     hipStream_t st = ctx->st;
     DevBuf<uint64_t> d_off, d_pbase, d_scr64;
     DevBuf<uint32_t> d_hdr, d_plen, d_marks, d_rank, d_scr32;
-    struct Guard {
-        std::function<void()> f;
-        ~Guard() { f(); }
-    } guard{[&]() { d_off.release(); d_pbase.release(); d_scr64.release(); d_hdr.release(); d_plen.release(); d_marks.release(); d_rank.release(); d_scr32.release(); }};
     std::vector<uint64_t> ends(nb + 1, 0);  // the kernels take off[b] .. off[b + 1]: the bins must lie back to back, as DatabaseWriter.scala:75-92 writes them
     for (uint32_t b = 0; b < nb; ++b) {
         ends[b] = bin_off[b];
@@ -618,7 +613,6 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
         DevBuf<InflateMember> d_mem;
         DevBuf<uint16_t> d_work;
         DevBuf<uint32_t> d_crc;
-        struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() { d_comp.release(); d_mem.release(); d_work.release(); d_crc.release(); }};
         FFH_HIP(d_comp.reserve(cspan + 64));
         FFH_HIP(d_raw.reserve(uspan / 8 + 2));
         e = inflate_to_device(body, need_lo, need_hi, d_comp.p, ctx->device, is, true);
@@ -1122,8 +1116,7 @@ static hipError_t grow_keep(DevBuf<T> &b, size_t used, size_t need, hipStream_t 
     if (used) e = hipMemcpyAsync(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { nb.release(); return e; }
-    b.release();
-    b = nb;
+    b = std::move(nb);
     return hipSuccess;
 }
 
@@ -1148,7 +1141,6 @@ void ffh_indexer_destroy(ffh_indexer *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->st) (void)hipStreamSynchronize(ix->st);
-    ix->seq.release(); ix->blk_cnt.release(); ix->blk_off.release(); ix->scan_tmp.release(); ix->keys.release(); ix->pos.release();
     if (ix->st) (void)hipStreamDestroy(ix->st);
     delete ix;
 }
@@ -1200,10 +1192,6 @@ int ffh_indexer_finish(ffh_indexer *ctx, const char *db_path, int bin_width, ffh
     const auto t0 = std::chrono::steady_clock::now();
     DevBuf<uint64_t> alt_k, alt_v, d_targets, d_positions, d_posoff, scr64;
     DevBuf<uint32_t> table, offs, scr32, head, rank, start, count;
-    struct Guard { std::function<void()> f; ~Guard() { f(); } } guard{[&]() {
-        alt_k.release(); alt_v.release(); d_targets.release(); d_positions.release(); d_posoff.release(); scr64.release();
-        table.release(); offs.release(); scr32.release(); head.release(); rank.release(); start.release(); count.release();
-    }};
     std::vector<uint64_t> h_targets, h_positions;
     uint64_t n_targets = 0, n_positions = 0;
     if (S) {
