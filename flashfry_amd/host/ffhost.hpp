@@ -105,7 +105,8 @@ double gcContent(const std::string &s);  // utils/Utils.scala:46
 // ---- hits ---------------------------------------------------------------------------------------------------
 struct CRISPRHit {  // crispr/CRISPRHit.scala:39-43
     uint64_t sequence = 0;
-    std::vector<uint64_t> coordinates;
+    std::vector<uint64_t> coordinates;     // the encoded positions; left empty when they are neither known nor printed
+    uint32_t nCoordinates = 0;             // coordinates.size of the reference's object (an all-zero array there, crispr/CRISPRHit.scala:39-43)
     bool validOffTargetCoordinates = true;
     bool hasCfd = false;  // scores(Doench2016CFDScore), CRISPRHit.addScore
     double cfd = 0;

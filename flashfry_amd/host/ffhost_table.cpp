@@ -137,7 +137,7 @@ void TabDelimitedOutput::format(const CRISPRSiteOT &g, std::string &o) const {  
     for (Metric m : models)
         for (const auto &c : metricColumns(m, g, p, numeric)) o += c + "\t";
     long total = 0;
-    for (const auto &h : g.offTargets) total += (long)h.coordinates.size();
+    for (const auto &h : g.offTargets) total += (long)h.nCoordinates;
     o += std::to_string(total);
     if (writeOTs) {
         o += '\t';
@@ -195,12 +195,13 @@ static void addOffTarget(CRISPRSiteOT &ot, const std::string &token, int maximum
             if (colon == std::string::npos || caret == std::string::npos) throw Error("Unable to parse position: " + pe);
             hit.coordinates.push_back(bitPosition.encode(pe.substr(0, colon), (uint32_t)std::atol(pe.c_str() + colon + 1), (int)seq.size(), pe.substr(caret + 1) == "F"));
         }
+        hit.nCoordinates = (uint32_t)hit.coordinates.size();
     } else {  // zero-filled coordinates, :310-316
-        hit.coordinates.assign((size_t)count, 0);
+        hit.nCoordinates = (uint32_t)count;  // the reference allocates `count` zeros here; only their number is ever used
         hit.validOffTargetCoordinates = false;
     }
     if (!ot.full()) {  // :305-306 -> CRISPRSiteOT.addOT
-        ot.currentTotal += (long)hit.coordinates.size();
+        ot.currentTotal += (long)hit.nCoordinates;
         ot.offTargets.push_back(std::move(hit));
     }
 }
@@ -342,6 +343,9 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         ot.overflow = maximumOffTargets;
         ffh_guide_summary sum{};
         sum.closest = 0xFFFFFFFFu;
+        size_t nHits = 0;
+        for (size_t d = 0; d < nd; ++d) nHits += (size_t)(ffh_result_guide_offsets(res[d])[g + 1] - ffh_result_guide_offsets(res[d])[g]);
+        ot.offTargets.reserve(nHits);
         for (size_t d = 0; d < nd; ++d) {
             const ffh_result *r = res[d];
             const ffh_guide_summary &s = ffh_result_summaries(r)[g];
@@ -350,8 +354,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
             for (uint64_t h = go[g]; h < go[g + 1]; ++h) {
                 CRISPRHit hit;
                 hit.sequence = ht[h];
+                hit.nCoordinates = (uint32_t)(po[h + 1] - po[h]);
                 if (wantPositions) hit.coordinates.assign(pp + po[h], pp + po[h + 1]);
-                else hit.coordinates.assign((size_t)(po[h + 1] - po[h]), 0);
                 hit.hasCfd = cfd[h] == cfd[h];
                 hit.cfd = cfd[h];
                 ot.currentTotal += (long)(po[h + 1] - po[h]);
