@@ -22,7 +22,9 @@ SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
     "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
-    "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
+    "ffh_bulge_result_hit_targets", "ffh_bulge_result_hit_mismatches", "ffh_bulge_result_hit_bulge_type", "ffh_bulge_result_hit_bulge_position",
+    "ffh_bulge_result_free", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
@@ -134,6 +136,14 @@ def load_library(build=True):
     L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ffh_scan.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int]
     L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
+    L.ffh_discover_bulge.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.ffh_bulge_result_n_guides.restype = C.c_uint32
+    L.ffh_bulge_result_n_hits.restype = C.c_uint64
+    for name, ty in (("guide_offsets", u64p), ("hit_targets", u64p), ("hit_mismatches", C.POINTER(C.c_uint8)), ("hit_bulge_type", C.POINTER(C.c_uint8)),
+                     ("hit_bulge_position", C.POINTER(C.c_uint8))):
+        getattr(L, "ffh_bulge_result_" + name).restype = ty
+    for name in ("n_guides", "n_hits", "guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position", "free"):
+        getattr(L, "ffh_bulge_result_" + name).argtypes = [C.c_void_p]
     L.ffh_shard_totals_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.ffh_summaries_to_device.argtypes = [C.c_void_p, C.c_void_p]
     L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
@@ -247,6 +257,21 @@ def index_contigs(path, enzyme_index, contigs, bin_width=7, device=0):
         L.ffh_indexer_destroy(ix)
 
 
+class BulgeResult:
+    """ffh_bulge_result copied into numpy arrays: per guide (CSR) the hit targets in database order with the mismatch count, the
+    bulge type (0 none, 1 RNA, 2 DNA) and the bulge position of the best alignment"""
+
+    def __init__(self, L, h):
+        n, H = L.ffh_bulge_result_n_guides(h), L.ffh_bulge_result_n_hits(h)
+        cp = lambda ptr, cnt, dt: np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True) if cnt else np.zeros(0, dtype=dt)
+        self.n_guides, self.n_hits = n, H
+        self.guide_offsets = cp(L.ffh_bulge_result_guide_offsets(h), n + 1, np.uint64)
+        self.hit_targets = cp(L.ffh_bulge_result_hit_targets(h), H, np.uint64)
+        self.hit_mismatches = cp(L.ffh_bulge_result_hit_mismatches(h), H, np.uint8)
+        self.hit_bulge_type = cp(L.ffh_bulge_result_hit_bulge_type(h), H, np.uint8)
+        self.hit_bulge_position = cp(L.ffh_bulge_result_hit_bulge_position(h), H, np.uint8)
+
+
 class Context:
     """One GPU, one HIP stream, one resident database shard."""
 
@@ -334,6 +359,16 @@ class Context:
         t = np.zeros(max(self._n_guides, 1), dtype=np.uint32)
         self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))
         return t[:self._n_guides]
+
+    def discover_bulge(self, guides, max_mismatch=3, max_bulge=1, tttv=False):
+        """config C5 (Cas12a): hits with <= max_mismatch mismatches and <= max_bulge one-base bulges; returns a BulgeResult (copies)"""
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        out = C.c_void_p()
+        self._check(self.L.ffh_discover_bulge(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_bulge, 1 if tttv else 0, C.byref(out)))
+        try:
+            return BulgeResult(self.L, out.value)
+        finally:
+            self.L.ffh_bulge_result_free(out)
 
     def shard_totals_device(self, device_ptr, clamp):
         """per-guide position totals of this shard (saturated at clamp) written to a device buffer of n_guides uint32"""

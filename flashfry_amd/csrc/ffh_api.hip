@@ -1243,3 +1243,96 @@ int ffh_indexer_finish(ffh_indexer *ctx, const char *db_path, int bin_width, ffh
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// config C5: mismatches + one bulge, Cas12a (ffh_bulge.hpp)
+// =====================================================================================================================
+#include "ffh_bulge.hpp"
+
+struct ffh_bulge_result {
+    uint32_t n_guides = 0;
+    std::vector<uint64_t> guide_offsets, hit_targets;
+    std::vector<uint8_t> hit_mm, hit_type, hit_pos;
+};
+
+extern "C" {
+
+int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_bulge, unsigned flags, ffh_bulge_result **out) {
+    if (!ctx || !out || (n_guides && !guides) || max_mismatch < 0 || max_bulge < 0 || max_bulge > 1) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    if (ctx->img[0].width < 0) { ctx->err = "no database loaded"; return FFH_E_STATE; }
+    if (ctx->enzyme != 1) { ctx->err = "the bulge search is specified for Cas12a / Cpf1 (enzyme index 1) only"; return FFH_E_ARG; }
+    if (n_guides >= (1u << 24)) { ctx->err = "too many guides for one bulge search"; return FFH_E_ARG; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->st;
+    std::unique_ptr<ffh_bulge_result> r(new (std::nothrow) ffh_bulge_result());
+    if (!r) { ctx->err = "out of memory"; return FFH_E_NOMEM; }
+    r->n_guides = n_guides;
+    r->guide_offsets.assign((size_t)n_guides + 1, 0);
+    const uint64_t T = ctx->T;
+    int tbits = 1;
+    while (tbits < 32 && (1ull << tbits) < std::max<uint64_t>(T, 2)) ++tbits;
+    int gbits = 1;
+    while ((1u << gbits) < std::max<uint32_t>(n_guides, 2)) ++gbits;
+    uint64_t n_hits = 0;
+    DevBuf<uint64_t> d_guides, key, val, alt_k, alt_v, d_target;
+    DevBuf<uint32_t> table, offs, scr32;
+    DevBuf<uint8_t> d_mm, d_type, d_pos;
+    if (n_guides && T) {
+        FFH_HIP(d_guides.reserve(n_guides));
+        FFH_HIP(hipMemcpyAsync(d_guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
+        unsigned long long *cursor = ctx->d_counters + 12;
+        size_t cap = std::max<size_t>(1u << 20, (size_t)n_guides * 1024);
+        for (;;) {
+            FFH_HIP(key.reserve(cap)); FFH_HIP(val.reserve(cap));
+            cap = std::min(key.cap, val.cap);
+            FFH_HIP(hipMemsetAsync(cursor, 0, 8, st));
+            hipLaunchKernelGGL(k_bulge_scan, dim3(blocks_for(T, 256)), dim3(256), 0, st, ctx->targets.p, T, d_guides.p, n_guides, ctx->geo, max_mismatch, max_bulge,
+                               (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
+            FFH_HIP(hipGetLastError());
+            unsigned long long found = 0;
+            FFH_HIP(hipMemcpyAsync(&found, cursor, 8, hipMemcpyDeviceToHost, st));
+            FFH_HIP(hipStreamSynchronize(st));
+            if (found <= cap) { n_hits = found; break; }
+            cap = (size_t)(found + found / 8);  // the buffer was too small: grow to what the scan found and run it again
+        }
+    }
+    if (n_hits) {
+        if (n_hits >= (1ull << 32) - 64) { ctx->err = "more than 2^32 bulge hits"; return FFH_E_ARG; }
+        const uint32_t nb = sort_nblocks(n_hits);
+        FFH_HIP(alt_k.reserve(n_hits)); FFH_HIP(alt_v.reserve(n_hits));
+        FFH_HIP(table.reserve((size_t)256 * nb + 8)); FFH_HIP(offs.reserve((size_t)256 * nb + 8));
+        FFH_HIP(scr32.reserve(scan_scratch_elems_safe((uint64_t)256 * nb)));
+        SortScratch ss;
+        ss.alt = alt_k.p; ss.val_alt = alt_v.p; ss.table = table.p; ss.offs = offs.p; ss.scan_tmp = scr32.p;
+        uint64_t *sk = nullptr, *sv = nullptr;
+        radix_sort_pairs(key.p, val.p, n_hits, 0, tbits + gbits, ss, st, sk, sv);  // (guide, database order)
+        FFH_HIP(d_target.reserve(n_hits)); FFH_HIP(d_mm.reserve(n_hits)); FFH_HIP(d_type.reserve(n_hits)); FFH_HIP(d_pos.reserve(n_hits));
+        hipLaunchKernelGGL(k_bulge_unpack, dim3(blocks_for(n_hits, 256)), dim3(256), 0, st, sk, sv, n_hits, tbits, ctx->targets.p, d_target.p, d_mm.p, d_type.p, d_pos.p);
+        FFH_HIP(hipGetLastError());
+        std::vector<uint64_t> keys(n_hits);
+        try {
+            r->hit_targets.resize(n_hits); r->hit_mm.resize(n_hits); r->hit_type.resize(n_hits); r->hit_pos.resize(n_hits);
+        } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return FFH_E_NOMEM; }
+        FFH_HIP(hipMemcpyAsync(keys.data(), sk, n_hits * 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_targets.data(), d_target.p, n_hits * 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_mm.data(), d_mm.p, n_hits, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_type.data(), d_type.p, n_hits, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_pos.data(), d_pos.p, n_hits, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < n_hits; ++i) ++r->guide_offsets[(size_t)(keys[i] >> tbits) + 1];
+        for (uint32_t g = 0; g < n_guides; ++g) r->guide_offsets[g + 1] += r->guide_offsets[g];
+    }
+    *out = r.release();
+    return FFH_OK;
+}
+
+uint32_t ffh_bulge_result_n_guides(const ffh_bulge_result *r) { return r ? r->n_guides : 0; }
+uint64_t ffh_bulge_result_n_hits(const ffh_bulge_result *r) { return r ? (uint64_t)r->hit_targets.size() : 0; }
+const uint64_t *ffh_bulge_result_guide_offsets(const ffh_bulge_result *r) { return r ? r->guide_offsets.data() : nullptr; }
+const uint64_t *ffh_bulge_result_hit_targets(const ffh_bulge_result *r) { return r ? r->hit_targets.data() : nullptr; }
+const uint8_t *ffh_bulge_result_hit_mismatches(const ffh_bulge_result *r) { return r ? r->hit_mm.data() : nullptr; }
+const uint8_t *ffh_bulge_result_hit_bulge_type(const ffh_bulge_result *r) { return r ? r->hit_type.data() : nullptr; }
+const uint8_t *ffh_bulge_result_hit_bulge_position(const ffh_bulge_result *r) { return r ? r->hit_pos.data() : nullptr; }
+void ffh_bulge_result_free(ffh_bulge_result *r) { delete r; }
+
+}  // extern "C"

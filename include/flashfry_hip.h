@@ -183,6 +183,31 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shar
 int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets,
                  unsigned flags, ffh_result **out);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Config C5 of BASELINE.json: Cas12a (Cpf1, enzyme index 1) off-targets with up to max_mismatch mismatches AND up to
+ * max_bulge (0 or 1) bulges of one base.  The reference has no bulge search; the specification is DESIGN.md section 8
+ * ("f4") and csrc/ffh_bulge.hpp: alignments none / RNA bulge at guide position k / DNA bulge at target position k
+ * (1 <= k <= 18, position 0 next to the PAM), best = fewest mismatches, ties none < RNA < DNA then smallest k.
+ * Brute force over the resident shard, every guide against every target; no cut-off, no scores (CFD / Hsu2013 are not
+ * defined for Cas12a).  Hits per guide in database order.  FFH_BULGE_PAM_TTTV keeps only targets whose fourth PAM base is
+ * not T (TTTV sites inside a TTTN database).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct ffh_bulge_result ffh_bulge_result;
+#define FFH_BULGE_PAM_TTTV 1u
+#define FFH_BULGE_NONE 0
+#define FFH_BULGE_RNA 1
+#define FFH_BULGE_DNA 2
+int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_bulge, unsigned flags,
+                       ffh_bulge_result **out);
+uint32_t ffh_bulge_result_n_guides(const ffh_bulge_result *r);
+uint64_t ffh_bulge_result_n_hits(const ffh_bulge_result *r);
+const uint64_t *ffh_bulge_result_guide_offsets(const ffh_bulge_result *r);      /* n_guides + 1 */
+const uint64_t *ffh_bulge_result_hit_targets(const ffh_bulge_result *r);
+const uint8_t *ffh_bulge_result_hit_mismatches(const ffh_bulge_result *r);
+const uint8_t *ffh_bulge_result_hit_bulge_type(const ffh_bulge_result *r);      /* FFH_BULGE_* */
+const uint8_t *ffh_bulge_result_hit_bulge_position(const ffh_bulge_result *r);  /* k, 0 for FFH_BULGE_NONE */
+void ffh_bulge_result_free(ffh_bulge_result *r);
+
 /* Device-resident halves of the multi-GPU exchange (one process per GPU, RCCL): the shard totals are written to, and the
  * summaries of the last ffh_finalize copied to, device buffers of the caller (n_guides x uint32 / n_guides x
  * sizeof(ffh_guide_summary) bytes), so that the collectives run on device memory.  Both return after the copy completed. */

@@ -156,6 +156,11 @@ int ffo_score_guide(const ffo_pack *p, uint64_t guide, const uint64_t *hit_targe
                     ffo_guide_scores *out, double *per_hit_cfd);
 int ffo_result_score_guide(const ffo_result *r, const ffo_db *db, int guide, ffo_guide_scores *out, double *per_hit_cfd);
 
+/* ---- config C5 (no reference counterpart; specification: DESIGN.md section 8 "f4"): best alignment of a Cas12a guide with a
+ * target allowing one bulge of one base.  Returns the mismatch count of the best alignment (fewest mismatches; ties none <
+ * RNA bulge < DNA bulge, then the smallest position); *type = 0 none / 1 RNA / 2 DNA, *pos = bulge position k (1..18) or 0. */
+int ffo_bulge_align(const ffo_pack *p, uint64_t guide, uint64_t target, int max_bulge, int *type, int *pos);
+
 /* java.lang.Double.toString semantics (shortest repr that round-trips; sci notation <1e-3 or >=1e7) */
 int ffo_java_double_to_string(double d, char *out /* >= 32 bytes */);
 

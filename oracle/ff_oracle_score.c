@@ -243,3 +243,32 @@ int ffo_java_double_to_string(double d, char *out) {
     }
     return (int)(w - out);
 }
+
+
+/* ---- config C5: mismatches + one bulge (this repository's specification, see ff_oracle.h) ------------------------------
+ * Plain strings, one loop per alignment: g = the 20 guide bases after the PAM, t = the 20 target bases after the PAM,
+ * position 0 next to the PAM.
+ *   RNA bulge k: guide base k unpaired      -> g[i] ~ t[i] (i < k),  g[i] ~ t[i-1] (i > k)
+ *   DNA bulge k: target base k unpaired     -> g[i] ~ t[i] (i < k),  g[i] ~ t[i+1] (k <= i <= 18); g[19] has no stored partner */
+int ffo_bulge_align(const ffo_pack *p, uint64_t guide, uint64_t target, int max_bulge, int *type, int *pos) {
+    char gs[32], ts[32];
+    ffo_bit_decode(guide, p->scan_len, gs);
+    ffo_bit_decode(target, p->scan_len, ts);
+    const int n = p->guide_hi - p->guide_lo; /* 20 */
+    const char *g = gs + p->guide_lo, *t = ts + p->guide_lo;
+    int best = 0, bt = 0, bp = 0;
+    for (int i = 0; i < n; i++) best += g[i] != t[i];
+    if (max_bulge > 0) {
+        for (int kind = 1; kind <= 2; kind++)       /* RNA first: it wins ties against DNA */
+            for (int k = 1; k <= n - 2; k++) {
+                int mm = 0;
+                for (int i = 0; i < k; i++) mm += g[i] != t[i];
+                if (kind == 1) { for (int i = k + 1; i < n; i++) mm += g[i] != t[i - 1]; }
+                else           { for (int i = k; i <= n - 2; i++) mm += g[i] != t[i + 1]; }
+                if (mm < best) { best = mm; bt = kind; bp = k; }
+            }
+    }
+    if (type) *type = bt;
+    if (pos) *pos = bp;
+    return best;
+}

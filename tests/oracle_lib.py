@@ -107,6 +107,7 @@ class Oracle:
         L.ffo_index_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.ffo_discover_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.ffo_score_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.ffo_bulge_align.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ffo_jost_calc_score.restype = C.c_double
         L.ffo_jost_calc_score.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
 

@@ -435,3 +435,65 @@ def test_device_resident_exchange_entry_points(capi, oracle):
             assert ex.summaries_numpy().tobytes() == want.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def test_cas12a_bulge_search_matches_the_brute_force_specification(capi, oracle):
+    """config C5 (Cas12a TTTV, mismatches + one bulge; the reference has no bulge search: parity is against this repository's own
+    specification, restated with strings in the oracle): every (guide, target) pair of a small database, all three alignment kinds"""
+    rng = np.random.default_rng(99)
+    L = 24
+    pam = int(oracle.encode("TTTA" + "A" * 20)) >> 40 << 40                     # TTTA....: the PAM bits of a 24-mer
+    raw = np.unique(rng.integers(0, 1 << 40, size=12000, dtype=np.uint64))
+    pam_n = rng.integers(0, 4, size=len(raw)).astype(np.uint64)                 # TTTN: the fourth PAM base varies
+    seq = (np.uint64(0b111111) << np.uint64(42)) | (pam_n << np.uint64(40)) | raw
+    guides = []
+    planted = []
+    for k in range(42):                                                          # guides whose bulged / mismatched copies are planted
+        g = int(rng.integers(0, 1 << 40))
+        guides.append(g | (0b11111100 << 40) | (1 << 48))
+        bases = [(g >> (2 * (19 - i))) & 3 for i in range(20)]
+        kind, pos = k % 3, int(rng.integers(1, 19))
+        if kind == 1:    # RNA bulge: the target lacks guide base `pos`; its last base is free
+            tb = bases[:pos] + bases[pos + 1:] + [int(rng.integers(0, 4))]
+        elif kind == 2:  # DNA bulge: the target has an extra base at `pos`
+            tb = (bases[:pos] + [int(rng.integers(0, 4))] + bases[pos:])[:20]
+        else:
+            tb = list(bases)
+        for _ in range(int(rng.integers(0, 4))):                                 # up to 3 mismatches on top
+            tb[int(rng.integers(0, 20))] = int(rng.integers(0, 4))
+        v = 0
+        for b in tb:
+            v = (v << 2) | b
+        planted.append(v | (0b111111 << 42) | (int(rng.integers(0, 4)) << 40))
+    seq = np.unique(np.concatenate([seq, np.array(planted, dtype=np.uint64)]))
+    binkey = (seq >> np.uint64(2 * (24 - 11))) & np.uint64(0x3FFF)                # database order of a 5'-PAM enzyme
+    seq = seq[np.lexsort((seq, binkey))]
+    counts = rng.integers(1, 3, size=len(seq)).astype(np.uint64)
+    targets = seq | (counts << np.uint64(48))
+    positions = rng.integers(0, 1 << 27, size=int(counts.sum()), dtype=np.uint64)
+    guides = np.array(guides, dtype=np.uint64)
+    pk = oracle.pack(1)
+    ty, ps = capi.C.c_int(), capi.C.c_int()
+    for max_mm, max_bulge, tttv in ((3, 1, False), (2, 1, True), (3, 0, False)):
+        with capi.Context(1) as ctx:
+            ctx.load_soa(targets, positions)
+            res = ctx.discover_bulge(guides, max_mm, max_bulge, tttv=tttv)
+        want = []
+        for gi, g in enumerate(guides):
+            for t in targets:
+                if tttv and ((int(t) >> 40) & 3) == 3:
+                    continue
+                mm = oracle.lib.ffo_bulge_align(pk, int(g), int(t), max_bulge, capi.C.byref(ty), capi.C.byref(ps))
+                if mm <= max_mm:
+                    want.append((gi, int(t), mm, ty.value, ps.value))
+        got = []
+        for gi in range(len(guides)):
+            a, b = int(res.guide_offsets[gi]), int(res.guide_offsets[gi + 1])
+            got += [(gi, int(res.hit_targets[h]), int(res.hit_mismatches[h]), int(res.hit_bulge_type[h]), int(res.hit_bulge_position[h])) for h in range(a, b)]
+        assert got == want, (max_mm, max_bulge, tttv, len(got), len(want))
+        kinds = {w[3] for w in want}
+        assert kinds == ({0, 1, 2} if max_bulge else {0}) and len(want) >= (30 if max_bulge and not tttv else 10)
+    with capi.Context(3) as ctx:                                                  # specified for Cas12a only
+        ctx.load_soa(np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+        with pytest.raises(capi.FlashFryHipError, match="Cas12a"):
+            ctx.discover_bulge(guides, 3, 1)
