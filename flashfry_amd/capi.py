@@ -24,7 +24,7 @@ SYMBOLS = [
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
     "ffh_bulge_result_hit_targets", "ffh_bulge_result_hit_mismatches", "ffh_bulge_result_hit_bulge_type", "ffh_bulge_result_hit_bulge_position",
-    "ffh_bulge_result_free", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_bulge_result_free", "ffh_exchange_pack", "ffh_exchange_mask", "ffh_exchange_unpack", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
@@ -146,6 +146,9 @@ def load_library(build=True):
         getattr(L, "ffh_bulge_result_" + name).argtypes = [C.c_void_p]
     L.ffh_shard_totals_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.ffh_summaries_to_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.ffh_exchange_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ffh_exchange_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.ffh_exchange_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_discover.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_score_lists.argtypes = [C.c_void_p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_void_p)]
@@ -377,6 +380,15 @@ class Context:
     def summaries_to_device(self, device_ptr):
         """the summaries of the last finalize copied to a device buffer of n_guides * SUMMARY_DTYPE.itemsize bytes"""
         self._check(self.L.ffh_summaries_to_device(self.h, C.c_void_p(device_ptr)))
+
+    def exchange_pack(self, summ_ptr, n, max_ptr, sum_ptr, fsum_ptr):
+        self._check(self.L.ffh_exchange_pack(self.h, summ_ptr, n, max_ptr, sum_ptr, fsum_ptr))
+
+    def exchange_mask(self, summ_ptr, n, max_ptr, sum_ptr):
+        self._check(self.L.ffh_exchange_mask(self.h, summ_ptr, n, max_ptr, sum_ptr))
+
+    def exchange_unpack(self, summ_ptr, n, max_ptr, sum_ptr, fsum_all_ptr, world):
+        self._check(self.L.ffh_exchange_unpack(self.h, summ_ptr, n, max_ptr, sum_ptr, fsum_all_ptr, world))
 
     def finalize_device_prior(self, max_offtargets, prior_device_ptr, summaries_only=True, jost=False):
         """finalize with the prior totals taken from device memory (n_guides uint32)"""

@@ -870,6 +870,7 @@ int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals, uint32_t clam
     if (!ctx || !device_totals) return FFH_E_ARG;
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipDeviceSynchronize());  // the caller's buffer may still be written by another stream (its allocation's fill, a collective)
     if (ctx->n_guides)
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
                            ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, device_totals);
@@ -882,6 +883,7 @@ int ffh_summaries_to_device(ffh_ctx *ctx, void *device_summaries) {
     if (!ctx || !device_summaries) return FFH_E_ARG;
     if (!ctx->scanned) { ctx->err = "no finalized scan"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipDeviceSynchronize());
     if (ctx->n_guides) FFH_HIP(hipMemcpyAsync(device_summaries, ctx->summ.p, (size_t)ctx->n_guides * sizeof(ffh_guide_summary), hipMemcpyDeviceToDevice, ctx->st));
     FFH_HIP(hipStreamSynchronize(ctx->st));
     return FFH_OK;
@@ -1334,5 +1336,85 @@ const uint8_t *ffh_bulge_result_hit_mismatches(const ffh_bulge_result *r) { retu
 const uint8_t *ffh_bulge_result_hit_bulge_type(const ffh_bulge_result *r) { return r ? r->hit_type.data() : nullptr; }
 const uint8_t *ffh_bulge_result_hit_bulge_position(const ffh_bulge_result *r) { return r ? r->hit_pos.data() : nullptr; }
 void ffh_bulge_result_free(ffh_bulge_result *r) { delete r; }
+
+}  // extern "C"
+
+// =====================================================================================================================
+// multi-GPU reduction of the per-guide aggregates: pack / mask / unpack around the three collectives (dist.py)
+// =====================================================================================================================
+namespace ffh {
+
+// lanes of the MAX collective: overflow, cfd_max, jost_max, -closest (so that the MAX delivers the MIN); lanes of the SUM
+// collective: n_hits, ot_count, hist[5], in_genome, n_scored, closest_count (filled by k_exchange_mask); f64 sums gathered apart
+__global__ void k_exchange_pack(const GuideSummary *__restrict__ s, uint32_t n, double *__restrict__ mx, int32_t *__restrict__ sums, double *__restrict__ fsum) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const GuideSummary v = s[g];
+    mx[4 * g + 0] = (double)v.overflow; mx[4 * g + 1] = v.cfd_max; mx[4 * g + 2] = v.jost_max; mx[4 * g + 3] = -(double)v.closest;
+    int32_t *o = sums + 10 * (size_t)g;
+    o[0] = (int32_t)v.n_hits; o[1] = (int32_t)v.ot_count;
+    for (int k = 0; k < 5; ++k) o[2 + k] = (int32_t)v.hist[k];
+    o[7] = (int32_t)v.in_genome; o[8] = (int32_t)v.n_scored; o[9] = 0;
+    fsum[3 * (size_t)g + 0] = v.cfd_sum; fsum[3 * (size_t)g + 1] = v.hsu_sum; fsum[3 * (size_t)g + 2] = v.jost_sum;
+}
+// after the MAX collective: only the ranks that hold the globally closest level contribute their count (ClosestHit.scala:62-67)
+__global__ void k_exchange_mask(const GuideSummary *__restrict__ s, uint32_t n, const double *__restrict__ mx, int32_t *__restrict__ sums) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    sums[10 * (size_t)g + 9] = ((double)s[g].closest == -mx[4 * g + 3]) ? (int32_t)s[g].closest_count : 0;
+}
+// fsum_all = [world][n][3]: added in rank order = database order of the shards (deterministic)
+__global__ void k_exchange_unpack(GuideSummary *__restrict__ s, uint32_t n, const double *__restrict__ mx, const int32_t *__restrict__ sums,
+                                  const double *__restrict__ fsum_all, uint32_t world) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    GuideSummary v;
+    const int32_t *o = sums + 10 * (size_t)g;
+    v.n_hits = (uint32_t)o[0]; v.ot_count = (uint32_t)o[1];
+    for (int k = 0; k < 5; ++k) v.hist[k] = (uint32_t)o[2 + k];
+    v.in_genome = (uint32_t)o[7]; v.n_scored = (uint32_t)o[8]; v.closest_count = (uint32_t)o[9];
+    v.overflow = (uint32_t)mx[4 * g + 0]; v.cfd_max = mx[4 * g + 1]; v.jost_max = mx[4 * g + 2];
+    v.closest = (uint32_t)(-mx[4 * g + 3]);
+    double a = 0, b = 0, c = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const double *f = fsum_all + ((size_t)r * n + g) * 3;
+        if (r == 0) { a = f[0]; b = f[1]; c = f[2]; } else { a += f[0]; b += f[1]; c += f[2]; }
+    }
+    v.cfd_sum = a; v.hsu_sum = b; v.jost_sum = c;
+    s[g] = v;
+}
+
+}  // namespace ffh
+
+extern "C" {
+
+int ffh_exchange_pack(ffh_ctx *ctx, const void *d_summaries, uint32_t n, double *d_max, int32_t *d_sum, double *d_fsum) {
+    if (!ctx || !d_summaries || !d_max || !d_sum || !d_fsum) return FFH_E_ARG;
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipDeviceSynchronize());
+    if (n) hipLaunchKernelGGL(k_exchange_pack, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (const GuideSummary *)d_summaries, n, d_max, d_sum, d_fsum);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
+int ffh_exchange_mask(ffh_ctx *ctx, const void *d_summaries, uint32_t n, const double *d_max_reduced, int32_t *d_sum) {
+    if (!ctx || !d_summaries || !d_max_reduced || !d_sum) return FFH_E_ARG;
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipDeviceSynchronize());  // the collective ran on another stream
+    if (n) hipLaunchKernelGGL(k_exchange_mask, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (const GuideSummary *)d_summaries, n, d_max_reduced, d_sum);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
+int ffh_exchange_unpack(ffh_ctx *ctx, void *d_summaries, uint32_t n, const double *d_max_reduced, const int32_t *d_sum_reduced, const double *d_fsum_all,
+                        uint32_t world) {
+    if (!ctx || !d_summaries || !d_max_reduced || !d_sum_reduced || !d_fsum_all || !world) return FFH_E_ARG;
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipDeviceSynchronize());
+    if (n) hipLaunchKernelGGL(k_exchange_unpack, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (GuideSummary *)d_summaries, n, d_max_reduced, d_sum_reduced, d_fsum_all, world);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(ctx->st));
+    return FFH_OK;
+}
 
 }  // extern "C"

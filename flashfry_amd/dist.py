@@ -98,6 +98,9 @@ class DeviceExchange:
         self.prior = torch.zeros(n_guides, dtype=torch.int32, device=device)
         self.summ = torch.zeros(n_guides * itemsize, dtype=torch.uint8, device=device)
         self.fsum_all = torch.zeros(self.world * n_guides * 3, dtype=torch.float64, device=device)
+        self.mx = torch.zeros(n_guides * 4, dtype=torch.float64, device=device)
+        self.sums = torch.zeros(n_guides * 10, dtype=torch.int32, device=device)
+        self.fsum = torch.zeros(n_guides * 3, dtype=torch.float64, device=device)
 
     def _all_gather(self, out_flat, inp):
         # chunk views of one flat buffer: works with every backend (RCCL gathers in place, gloo copies)
@@ -119,44 +122,62 @@ class DeviceExchange:
         return self.prior
 
     def reduce_summaries(self):
-        """in place on self.summ: integer lanes by sum, maxima by max, closest hit by min + masked count, f64 sums gathered
-        and added in rank order (= database order of the shards: deterministic, like the host path)"""
+        """in place on self.summ, three collectives: (1) MAX over [overflow, cfd_max, jost_max, -closest] (the min of the closest
+        level rides along negated; every value is exact in f64), (2) SUM over the integer lanes plus the closest-hit count masked
+        to the winning level, (3) all-gather of the three f64 sums, added in rank order (= database order of the shards:
+        deterministic, like the host path)"""
         torch, dist, G = self.torch, self.dist, self.G
         i32 = self.summ.view(torch.int32).view(G, 22)
         f64 = self.summ.view(torch.float64).view(G, 11)
-        sums = i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]].contiguous()       # n_hits, ot_count, hist[5], in_genome, n_scored
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        mx = torch.stack([i32[:, 2].to(torch.float64), f64[:, 6], f64[:, 9]], 1).contiguous()  # overflow, cfd_max, jost_max
+        closest = (i32[:, 8].to(torch.int64) & 0xFFFFFFFF).to(torch.float64)          # 0xFFFFFFFF = none
+        mx = torch.stack([i32[:, 2].to(torch.float64), f64[:, 6], f64[:, 9], -closest], 1).contiguous()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        closest = i32[:, 8].to(torch.int64) & 0xFFFFFFFF                 # 0xFFFFFFFF = none
-        gmin = closest.clone()
-        dist.all_reduce(gmin, op=dist.ReduceOp.MIN, group=self.group)
-        cc = torch.where(closest == gmin, i32[:, 9].to(torch.int64), torch.zeros_like(gmin))
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM, group=self.group)
-        fl = f64[:, [7, 8, 10]].contiguous().view(-1)                    # cfd_sum, hsu_sum, jost_sum
+        gmin = -mx[:, 3]
+        cc = torch.where(closest == gmin, i32[:, 9], torch.zeros_like(i32[:, 9]))
+        sums = torch.cat([i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]], cc.unsqueeze(1)], 1).contiguous()  # n_hits, ot_count, hist[5], in_genome, n_scored, closest_count
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        fl = f64[:, [7, 8, 10]].contiguous().view(-1)                                  # cfd_sum, hsu_sum, jost_sum
         self._all_gather(self.fsum_all, fl)
         parts = self.fsum_all.view(self.world, G, 3)
         acc = parts[0].clone()
         for r in range(1, self.world):
             acc += parts[r]
-        i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]] = sums
+        i32[:, [0, 1, 3, 4, 5, 6, 7, 10, 11]] = sums[:, :9]
+        i32[:, 9] = sums[:, 9]
         i32[:, 2] = mx[:, 0].to(torch.int32)
         f64[:, 6] = mx[:, 1]
         f64[:, 9] = mx[:, 2]
-        i32[:, 8] = torch.where(gmin > 0x7FFFFFFF, gmin - (1 << 32), gmin).to(torch.int32)
-        i32[:, 9] = cc.to(torch.int32)
-        f64[:, 7] = acc[:, 0]
-        f64[:, 8] = acc[:, 1]
-        f64[:, 10] = acc[:, 2]
+        gm = gmin.to(torch.int64)
+        i32[:, 8] = torch.where(gm > 0x7FFFFFFF, gm - (1 << 32), gm).to(torch.int32)
+        f64[:, [7, 8, 10]] = acc
+        return self.summ
+
+    def reduce_summaries_fused(self, ctx):
+        """reduce_summaries with the packing, masking and unpacking done by three library kernels (the torch form costs ~20 small
+        launches): same three collectives, same arithmetic"""
+        dist, G = self.dist, self.G
+        ctx.exchange_pack(self.summ.data_ptr(), G, self.mx.data_ptr(), self.sums.data_ptr(), self.fsum.data_ptr())
+        dist.all_reduce(self.mx, op=dist.ReduceOp.MAX, group=self.group)
+        ctx.exchange_mask(self.summ.data_ptr(), G, self.mx.data_ptr(), self.sums.data_ptr())
+        dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_gather(self.fsum_all, self.fsum)
+        ctx.exchange_unpack(self.summ.data_ptr(), G, self.mx.data_ptr(), self.sums.data_ptr(), self.fsum_all.data_ptr(), self.world)
         return self.summ
 
     def step(self, ctx, max_offtargets, jost=False):
         prior = self.prior_totals(ctx, max_offtargets)
         res = ctx.finalize_device_prior(max_offtargets, prior.data_ptr(), summaries_only=True, jost=jost)
         ctx.summaries_to_device(self.summ.data_ptr())
-        self.reduce_summaries()
+        self.reduce_summaries_fused(ctx)
         return res
 
     def summaries_numpy(self):
+        """the reduced summaries on the host (through a page-locked staging tensor when the buffers live on a GPU)"""
         from . import capi
-        return self.summ.cpu().numpy().view(capi.SUMMARY_DTYPE)
+        if self.summ.is_cuda:
+            if getattr(self, "_host", None) is None:
+                self._host = self.torch.empty(self.summ.shape, dtype=self.torch.uint8, pin_memory=True)
+            self._host.copy_(self.summ, non_blocking=True)
+            self.torch.cuda.current_stream().synchronize()
+            return self._host.numpy().view(capi.SUMMARY_DTYPE)
+        return self.summ.numpy().view(capi.SUMMARY_DTYPE)

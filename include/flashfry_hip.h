@@ -213,6 +213,16 @@ void ffh_bulge_result_free(ffh_bulge_result *r);
  * sizeof(ffh_guide_summary) bytes), so that the collectives run on device memory.  Both return after the copy completed. */
 int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals /* n_guides */, uint32_t clamp);
 int ffh_summaries_to_device(ffh_ctx *ctx, void *device_summaries);
+/* The reduction of the aggregates over the shards is three collectives on device buffers of the caller:
+ *   ffh_exchange_pack   summaries -> max[n][4] f64 (overflow, cfd_max, jost_max, -closest), sum[n][10] i32 (n_hits, ot_count, hist[5],
+ *                       in_genome, n_scored, 0), fsum[n][3] f64 (cfd_sum, hsu_sum, jost_sum);            then all-reduce MAX of max
+ *   ffh_exchange_mask   sum[.][9] = closest_count where this shard holds the globally closest level;       then all-reduce SUM of sum,
+ *                                                                                                          all-gather of fsum
+ *   ffh_exchange_unpack reduced lanes + the gathered f64 sums added in rank order (= database order) -> summaries, in place */
+int ffh_exchange_pack(ffh_ctx *ctx, const void *device_summaries, uint32_t n_guides, double *device_max, int32_t *device_sum, double *device_fsum);
+int ffh_exchange_mask(ffh_ctx *ctx, const void *device_summaries, uint32_t n_guides, const double *device_max_reduced, int32_t *device_sum);
+int ffh_exchange_unpack(ffh_ctx *ctx, void *device_summaries, uint32_t n_guides, const double *device_max_reduced, const int32_t *device_sum_reduced,
+                        const double *device_fsum_all /* [world][n_guides][3] */, uint32_t world);
 
 /* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
  * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the

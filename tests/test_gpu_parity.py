@@ -420,6 +420,41 @@ def test_device_resident_exchange_entry_points(capi, oracle):
         buf = torch.zeros(len(g) * capi.SUMMARY_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         c1.summaries_to_device(buf.data_ptr())
         assert buf.cpu().numpy().tobytes() == b.summaries.tobytes()
+    # the pack / mask / unpack kernels around the three collectives, with the collectives of a 2-rank group done by hand
+    with capi.Context(3) as c0, capi.Context(3) as c1:
+        c0.load_soa(t[:cut], p[:pcut])
+        c1.load_soa(t[cut:], p[pcut:])
+        c0.scan(g, 5)
+        c1.scan(g, 5)
+        s0 = c0.finalize(max_ot, summaries_only=True, jost=True).summaries.copy()
+        s1 = c1.finalize(max_ot, prior_totals=c0.shard_totals(max_ot), summaries_only=True, jost=True).summaries.copy()
+        n, isz = len(g), capi.SUMMARY_DTYPE.itemsize
+        bufs, mxs, sums, fsums = [], [], [], []
+        for c in (c0, c1):
+            b = torch.zeros(n * isz, dtype=torch.uint8, device=dev)
+            c.summaries_to_device(b.data_ptr())
+            mx, sm, fs = torch.zeros(n * 4, dtype=torch.float64, device=dev), torch.zeros(n * 10, dtype=torch.int32, device=dev), torch.zeros(n * 3, dtype=torch.float64, device=dev)
+            c.exchange_pack(b.data_ptr(), n, mx.data_ptr(), sm.data_ptr(), fs.data_ptr())
+            bufs.append(b); mxs.append(mx); sums.append(sm); fsums.append(fs)
+        mx = torch.maximum(mxs[0], mxs[1])                                   # all-reduce MAX
+        for c, b, sm in zip((c0, c1), bufs, sums):
+            c.exchange_mask(b.data_ptr(), n, mx.data_ptr(), sm.data_ptr())
+        total = sums[0] + sums[1]                                            # all-reduce SUM
+        gathered = torch.cat(fsums)                                          # all-gather, rank order
+        c0.exchange_unpack(bufs[0].data_ptr(), n, mx.data_ptr(), total.data_ptr(), gathered.data_ptr(), 2)
+        got = bufs[0].cpu().numpy().view(capi.SUMMARY_DTYPE)
+    want = s0.copy()
+    for f in ("n_hits", "ot_count", "hist", "in_genome", "n_scored"):
+        want[f] = s0[f] + s1[f]
+    for f in ("overflow", "cfd_max", "jost_max"):
+        want[f] = np.maximum(s0[f], s1[f])
+    want["closest"] = np.minimum(s0["closest"], s1["closest"])
+    want["closest_count"] = np.where(s0["closest"] == want["closest"], s0["closest_count"], 0) + np.where(s1["closest"] == want["closest"], s1["closest_count"], 0)
+    for f in ("cfd_sum", "hsu_sum", "jost_sum"):
+        want[f] = s0[f] + s1[f]
+    bad = [i for i in range(n) if got[i].tobytes() != want[i].tobytes()]
+    assert not bad, (bad[:3], got[bad[0]], want[bad[0]], s0[bad[0]], s1[bad[0]])
+    assert (want["closest"] != 0xFFFFFFFF).any() and (s1["n_hits"] > 0).any()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
