@@ -27,7 +27,7 @@
 
 using namespace ffh;
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;  // what ffh_last_error(NULL) returns: per thread, contexts are created from several threads
 namespace ffh {
 void set_global_error(const std::string &m) { g_create_error = m; }
 }  // namespace ffh

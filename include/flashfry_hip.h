@@ -59,7 +59,7 @@ int ffh_device_count(void);
 /* enzyme_index as stored in the database header: 1 Cpf1, 2 spCas9, 3 spCas9-NGG, 4 spCas9-NAG, 5 spCas9 19-mer,
  * 6 spCas9-NGG 19-mer (ParameterPack.indexToParameterPack, standards/StandardScanParameters.scala:61-69).
  * enzyme_index 0 defers the choice to the header of the database opened later (BinaryHeader.scala:127).
- * Returns NULL on failure; ffh_last_error(NULL) then tells why. */
+ * Returns NULL on failure; ffh_last_error(NULL) then tells why (the context-less message is kept per calling thread). */
 ffh_ctx *ffh_create(int device_id, int enzyme_index);
 void ffh_destroy(ffh_ctx *ctx);
 const char *ffh_last_error(const ffh_ctx *ctx);
