@@ -278,7 +278,8 @@ def main():
         dist.destroy_process_group()
     if out is not None:  # the one JSON line is the last thing the job writes
         print(json.dumps(out), flush=True)
-    os._exit(0)  # nothing (library destructors included) may write after the result line
+    if sharded:
+        os._exit(0)  # RCCL / torch.distributed teardown may not write after the result line (a profiler needs the normal exit at N = 1)
 
 
 if __name__ == "__main__":
