@@ -130,6 +130,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("FFH_BENCH_SAME_GPU") == "1":
+        local = 0  # test aid: all ranks share GPU 0 (with FFH_BENCH_BACKEND=gloo), to run the multi-rank path on a 1-GPU box
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # FFH_BENCH_FORCE_EXCHANGE=1 runs the sharded step (device-resident exchange over RCCL) with a single rank: a way to
@@ -140,7 +142,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FFH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     T_req, G = int(args.targets), args.guides
     # ---- synthetic inputs, generated on the device (same generator as the tests) ----
