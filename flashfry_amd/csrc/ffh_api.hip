@@ -353,6 +353,7 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     if (part_bits > (uint32_t)kMaxPartBits || ig.low_bits > (uint32_t)kMaxLowBits) { ctx->err = "bucket width too large for the candidate binning"; return FFH_E_ARG; }
     ig.n_part = 1u << part_bits;
     ig.item_base = item_base;
+    ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
     FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
     FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
     FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
