@@ -186,3 +186,25 @@ def test_discover_and_score_tables_are_byte_identical(cli, oracle, tmp_path, enz
     else:
         assert hdr[7:10] == ["Hsu2013", "DoenchCFD_maxOT", "DoenchCFD_specificityscore"] and "JostCRISPRi_specificityscore" in hdr
         assert "{Doench2016CFDScore=" in open(s_cli).read()
+
+
+@pytest.mark.gpu
+def test_empty_inputs_through_the_cli(cli, oracle, tmp_path):
+    """a genome without a single target site and a guide file without a single guide: valid (empty) database, header-only tables"""
+    fa, gfa = str(tmp_path / "empty.fa"), str(tmp_path / "guides.fa")
+    with open(fa, "w") as f:
+        f.write(">chrE\n" + "AT" * 500 + "\n")                      # no NGG / CCN anywhere
+    with open(gfa, "w") as f:
+        f.write(">g1\nGACTTGCATCCGAAGCCGGTGGG\n")
+    db = str(tmp_path / "db")
+    subprocess.check_call([cli, "index", "--reference", fa, "--database", db, "--enzyme", "spcas9ngg"], stderr=subprocess.DEVNULL)
+    odb = oracle.db_read(db)
+    assert odb.n_bins == 16384 and all(len(odb.bin(b)[0]) == 1 for b in range(0, 16384, 257))
+    out = str(tmp_path / "out.sites")
+    subprocess.check_call([cli, "discover", "--database", db, "--fasta", gfa, "--output", out], stderr=subprocess.DEVNULL)
+    rows = open(out).read().split("\n")
+    assert rows[0].startswith("contig\tstart") and rows[1].split("\t")[:4] == ["g1", "0", "23", "GACTTGCATCCGAAGCCGGTGGG"] and rows[1].split("\t")[-2:] == ["0", ""]
+    with open(gfa, "w") as f:
+        f.write(">nothing\nATATATATATATATATATATATATAT\n")          # no guide in here
+    subprocess.check_call([cli, "discover", "--database", db, "--fasta", gfa, "--output", out], stderr=subprocess.DEVNULL)
+    assert open(out).read().count("\n") == 1
