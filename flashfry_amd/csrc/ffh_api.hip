@@ -776,6 +776,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ca.slots = ctx->item_gid.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
         ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
         ca.r1 = plan.r1; ca.hits = ctx->hits.p; ca.cursor = ctx->d_counters; ca.cap = (uint64_t)ctx->hits.cap;
+        ca.guide_base = g0; ca.tbits = ctx->tbits;
         // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
         // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
         const unsigned cmp_grid = ctx->compare_grid;
@@ -806,11 +807,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
         ctx->tm.compare_launches++;
-        // (batch-local guide, image position) -> sort key (global guide << tbits) | database index
-        if (cursor > cursor_before)
-            hipLaunchKernelGGL(k_resolve_hits, dim3(blocks_for(cursor - cursor_before, 256)), dim3(256), 0, st, ctx->hits.p + cursor_before,
-                               (uint64_t)(cursor - cursor_before), ctx->img[0].tidx.p, ctx->img[1].tidx.p, g0, ctx->tbits);
-        cursor_before = cursor;
+        cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
         g0 += ng;
     }
     ctx->n_raw = cursor_before;

@@ -322,6 +322,8 @@ struct CompareArgs {
     uint64_t *hits;
     unsigned long long *cursor;  // [0] hit cursor, [1] pairs (prefix image), [2] pairs (suffix image)
     uint64_t cap;
+    uint32_t guide_base;         // first guide of this batch
+    int tbits;                   // hit key = (global guide << tbits) | database index
 };
 
 struct HitStage {
@@ -331,6 +333,9 @@ struct HitStage {
     uint64_t *hits;
     unsigned long long *cursor;
     uint64_t cap;
+    const uint32_t *tidx_p, *tidx_s;
+    uint32_t guide_base;
+    int tbits;
 
     __device__ __forceinline__ void flush() {
         unsigned long long base = 0;
@@ -339,8 +344,15 @@ struct HitStage {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // staged record = (batch-local guide << 32) | side << 31 | position in that side's image; it leaves as the sort key
+        // (global guide << tbits) | database index -- the lookup rides on the flush instead of a pass of its own over all hits
         for (uint32_t i = lane; i < fill; i += 64)
-            if (base + i < cap) hits[base + i] = my[i];
+            if (base + i < cap) {
+                const uint64_t h = my[i];
+                const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
+                const uint32_t ti = (lo >> 31) ? tidx_s[pos] : tidx_p[pos];
+                hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         fill = 0;
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restr
     const uint32_t n_tiles = *a.n_tiles_a + *a.n_tiles_b;
     if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
     __syncthreads();
-    HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap};
+    HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap, a.tidx[0], a.tidx[1], a.guide_base, a.tbits};
     unsigned long long pairs[2] = {0, 0};
     // padding candidate: the 12 unused high bits of both planes set, the 20 used ones clear.  It differs from every real
     // key in those 12 bits and from the all-ones key of an idle lane in the 20 low ones: never within max_mm < 12
@@ -518,18 +530,6 @@ done:
     }
     __syncthreads();
     if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(a.cursor + 1 + threadIdx.x, blk_pairs[threadIdx.x]);
-}
-
-// hit records leave the compare kernel as (guide << 32) | side << 31 | position in that side's scan image; rewrite them
-// as the sort key (global guide << tbits) | database index (tbits = bits needed for a database index)
-__global__ void k_resolve_hits(uint64_t *__restrict__ hits, uint64_t n, const uint32_t *__restrict__ tidx_p, const uint32_t *__restrict__ tidx_s,
-                               uint32_t guide_base, int tbits) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t h = hits[i];
-    const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
-    const uint32_t ti = (lo >> 31) ? tidx_s[pos] : tidx_p[pos];
-    hits[i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
 }
 
 // ---------------------------------------------------------------------------------------------------------
