@@ -299,10 +299,10 @@ __global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t 
 //     v_cmp -- no readlane, no memory wait;
 //   * short chunks (the <= 32 / 16 / 8 target tail of a bucket) are replicated 2 / 4 / 8 times across the wave and
 //     tested against 2 / 4 / 8 different guides per step, so the tail does not waste the lanes;
-//   * a hit is recorded as (guide, side, position in the image); the database index is looked up afterwards by
-//     k_resolve_hits, so the hot loop never waits on memory even when it hits;
+//   * a hit is staged as (guide, side, position in the image), so the hot loop never waits on memory even when it hits;
 //   * hits are compacted with ballot + mbcnt into a per-wave LDS staging buffer and flushed with ONE global atomic
-//     per ~200 hits (a single global cursor saturates far below the hit rate).
+//     per ~200 hits (a single global cursor saturates far below the hit rate); the flush looks the database index up and
+//     writes the final sort key (guide << tbits) | index.
 //   Suffix-image items: the same pair can only also be found through the prefix image when its prefix part has
 //   <= r1 mismatches, so it is emitted from a suffix item only if the prefix part has MORE than r1.
 // ---------------------------------------------------------------------------------------------------------
