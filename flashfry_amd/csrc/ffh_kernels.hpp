@@ -168,6 +168,12 @@ __global__ void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t 
     part_count[q] = n;
 }
 
+// LDS counter index of partition / bucket x.  A wave's 64 entries are 64 patterns of one guide: their partitions differ from the
+// guide's only in the few bits the patterns set, very often not in the five bits that select the LDS bank, and the counters of
+// one wave then sit in one bank (SQ_LDS_BANK_CONFLICT = 96 % of the LDS cycles).  Folding the higher bits into the bank bits is a
+// bijection on every power-of-two range >= 32 and spreads them.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) & 31u) ^ ((x >> 10) & 31u); }
+
 template <bool WRITE>
 __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
                                                                  const uint32_t *__restrict__ part_start, uint32_t *__restrict__ part_fill,
@@ -184,20 +190,20 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig);
         const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat];
-        atomicAdd(&cur[b >> ig.low_bits], 1u);
+        atomicAdd(&cur[lds_slot(b >> ig.low_bits)], 1u);
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
-        const uint32_t c = cur[d];
-        if (!WRITE) { if (c) atomicAdd(&part_fill[d], c); }                    // A1: partition sizes
-        else cur[d] = c ? part_start[d] + atomicAdd(&part_fill[d], c) : 0u;  // A2: start of this block's run
+        const uint32_t c = cur[lds_slot(d)];
+        if (!WRITE) { if (c) atomicAdd(&part_fill[d], c); }                              // A1: partition sizes
+        else cur[lds_slot(d)] = c ? part_start[d] + atomicAdd(&part_fill[d], c) : 0u;  // A2: start of this block's run
     }
     if (!WRITE) return;
     __syncthreads();
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig), g = g_first + q;
         const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat];
-        const uint32_t pos = atomicAdd(&cur[b >> ig.low_bits], 1u);
+        const uint32_t pos = atomicAdd(&cur[lds_slot(b >> ig.low_bits)], 1u);
         part_items[pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
     }
 }
@@ -221,22 +227,22 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
 #pragma unroll
         for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[r[u] >> kGidBits], 1u);
+        for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
     }
     __syncthreads();
     // exclusive scan of the nlow counters: every thread owns nlow / 1024 consecutive ones (at most 2)
     const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
     uint32_t mine = 0;
     for (uint32_t k = 0; k < per; ++k)
-        if (l0 + k < nlow) mine += cnt[l0 + k];
+        if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
     uint32_t tot;
     uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
     const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
     for (uint32_t k = 0; k < per; ++k)
         if (l0 + k < nlow) {
-            const uint32_t c = cnt[l0 + k];
+            const uint32_t c = cnt[lds_slot(l0 + k)];
             istart[((uint64_t)d << ig.low_bits) + l0 + k] = gbase + off;
-            cnt[l0 + k] = off;  // becomes the scatter cursor
+            cnt[lds_slot(l0 + k)] = off;  // becomes the scatter cursor
             off += c;
         }
     if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
 #pragma unroll
         for (int u = 0; u < kU; ++u)
             if (k0 + u * kPartThreads + threadIdx.x < n) {
-                const uint32_t pos = atomicAdd(&cnt[r[u] >> kGidBits], 1u);
+                const uint32_t pos = atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
                 const uint32_t gid = r[u] & ((1u << kGidBits) - 1u);
                 if (staged) stage[pos] = gid;
                 else item_gid[gbase + pos] = gid;
