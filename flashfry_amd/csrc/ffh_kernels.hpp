@@ -110,7 +110,7 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
 //   B  k_item_bin         : one block per partition counts its records per bucket in LDS, scans the counts, writes
 //                           the CSR offsets of its buckets and scatters the guide ids into place (LDS atomics only).
 constexpr int kPartThreads = 1024;
-constexpr int kPartItemsPerBlock = 262144;
+constexpr int kPartItemsPerBlock = 32768;
 constexpr int kMaxPartBits = 12;   // <= 4096 partitions
 constexpr int kMaxLowBits = 12;    // <= 4096 buckets per partition (11 bits preferred: see prepare_side)
 constexpr int kBinStage = 26624;   // candidate ids staged in LDS per partition (104 KB); larger partitions scatter to memory
