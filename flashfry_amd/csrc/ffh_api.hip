@@ -361,8 +361,7 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     FFH_HIP(hipMemsetAsync(ctx->part_fill.p, 0, ((size_t)2 * ig.n_part + 2) * 4, st));
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
-    FFH_HIP(hipMemsetAsync(ctx->part_hist.p, 0, ((size_t)ig.n_part + 1) * 4, st));
-    hipLaunchKernelGGL(k_guide_part_hist, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gbucket.p, ng, ig.low_bits, ctx->part_hist.p);
+    hipLaunchKernelGGL(k_guide_part_hist, dim3(1), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p);
     hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 256)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);

@@ -152,13 +152,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
     return off + incl - v;
 }
 
+// LDS counter index of partition / bucket x.  A wave's 64 entries are 64 patterns of one guide: their partitions differ from the
+// guide's only in the few bits the patterns set, very often not in the five bits that select the LDS bank, and the counters of
+// one wave then sit in one bank (SQ_LDS_BANK_CONFLICT = 96 % of the LDS cycles).  Folding the higher bits into the bank bits is a
+// bijection on every power-of-two range >= 32 and spreads them.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) & 31u) ^ ((x >> 10) & 31u); }
+
 // Partition sizes without enumerating the entries: bucket = guide bucket ^ pattern acts bit by bit, so the number of
 // entries whose high bits equal q is  sum over patterns p of  #guides whose high bits equal q ^ high(p)  -- an XOR
 // convolution of the guides' partition histogram with the patterns' (<= 4096 x n_pat additions instead of one pass
 // over all n_guides x n_pat entries).
-__global__ void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t *__restrict__ ghist) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_guides) atomicAdd(&ghist[gbucket[g] >> low_bits], 1u);
+// one block: LDS atomics only (100 000 device-scope atomics on 2048 counters took 47 us, this takes a few)
+__global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
+                                                          uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t h[1 << kMaxPartBits];
+    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) h[d] = 0;
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_guides; g += blockDim.x) atomicAdd(&h[lds_slot(gbucket[g] >> low_bits)], 1u);
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) ghist[d] = h[lds_slot(d)];
 }
 __global__ void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t *__restrict__ part_count) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,12 +179,6 @@ __global__ void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t 
     for (uint32_t p = 0; p < ig.n_pat; ++p) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
     part_count[q] = n;
 }
-
-// LDS counter index of partition / bucket x.  A wave's 64 entries are 64 patterns of one guide: their partitions differ from the
-// guide's only in the few bits the patterns set, very often not in the five bits that select the LDS bank, and the counters of
-// one wave then sit in one bank (SQ_LDS_BANK_CONFLICT = 96 % of the LDS cycles).  Folding the higher bits into the bank bits is a
-// bijection on every power-of-two range >= 32 and spreads them.
-__device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) & 31u) ^ ((x >> 10) & 31u); }
 
 template <bool WRITE>
 __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,

@@ -81,10 +81,24 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const TIn *__restr
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-template <typename TIn, typename TOut>
+// SUMS: `boff` holds the raw block sums and every block adds up the ones before it itself (<= kScanInlineBlocks of them): the
+// scans here are short and launch-bound, two launches instead of a recursion of five
+constexpr uint64_t kScanInlineBlocks = 4096;
+template <typename TIn, typename TOut, bool SUMS>
 __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn *__restrict__ in, uint64_t n, const TOut *__restrict__ boff,
                                                               TOut *__restrict__ out) {
     __shared__ TOut lds[8];
+    TOut before = 0;
+    if (SUMS) {
+        TOut part = 0;
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kScanThreads) part += boff[j];
+        TOut dummy;
+        const TOut excl = block_exclusive_scan<TOut>(part, lds, dummy);
+        (void)excl;
+        before = dummy;  // block_exclusive_scan returns the block total through its last argument
+    } else {
+        before = boff[blockIdx.x];
+    }
     const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
     TOut v[kScanItems];
     scan_load_items<TIn, TOut>(in, n, base, v);
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn *__restri
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) s += v[k];
     TOut tot;
-    TOut off = block_exclusive_scan<TOut>(s, lds, tot) + boff[blockIdx.x];
+    TOut off = block_exclusive_scan<TOut>(s, lds, tot) + before;
     if (base + kScanItems <= n) {
         constexpr int kPer = 16 / sizeof(TOut);
         struct alignas(16) Pack { TOut e[kPer]; };
@@ -123,16 +137,18 @@ inline void exclusive_scan(const TIn *in, uint64_t n, TOut *out, TOut *scratch, 
     const uint64_t nb_pad = (nb + 1 + 7) & ~7ull;  // keep every sub-buffer 16-byte aligned for the vector loads
     TOut *bsum = scratch;            // nb entries (+1 for the recursive total)
     TOut *next = scratch + nb_pad;   // scratch of the next level
+    if (nb == 1) {  // one block: nothing before it
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut, true>), dim3(1), dim3(kScanThreads), 0, st, in, n, (const TOut *)bsum, out);
+        return;
+    }
     hipLaunchKernelGGL((k_scan_reduce<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, bsum);
-    if (nb > 1) {
-        // scan block sums in place-ish: bsum -> boff (stored in `next` region's head), recursive
+    if (nb <= kScanInlineBlocks) {
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut, true>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, (const TOut *)bsum, out);
+    } else {
+        // scan the block sums: bsum -> boff (stored in `next` region's head), recursive
         TOut *boff = next;
         exclusive_scan<TOut, TOut>(bsum, nb, boff, next + nb_pad, st);
-        hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, boff, out);
-    } else {
-        // single block: offset 0
-        (void)hipMemsetAsync(next, 0, sizeof(TOut), st);
-        hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3(1), dim3(kScanThreads), 0, st, in, n, next, out);
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut, false>), dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, n, (const TOut *)boff, out);
     }
 }
 

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 for P in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM"; do
   N=$(echo $P | cut -d" " -f1)
   rm -rf /tmp/pmc_$N
-  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "k_item_partition|k_item_bin|k_guide_epilogue" --output-format csv -d /tmp/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic > /tmp/pmc_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "${KREGEX:-k_item_partition|k_item_bin|k_guide_epilogue}" --output-format csv -d /tmp/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic > /tmp/pmc_$N.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections
