@@ -346,9 +346,9 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
     ig.n_guides = ng; ig.n_pat = np;
-    // 2048 buckets per partition keep a partition's candidate ids (~26k at hg38 scale) inside the LDS stage of k_item_bin;
-    // 12-base images (24-bit bucket ids) need 4096 per partition to stay within 4096 partitions
-    ig.low_bits = (uint32_t)std::max(std::min(2 * width, kMaxLowBits - 1), 2 * width - kMaxPartBits);
+    // 1024 buckets per partition keep a partition's candidate ids (~13k at hg38 scale) inside the 56 KB LDS stage of k_item_bin,
+    // which lets two of its blocks share a CU; 12-base images (24-bit bucket ids) need 4096 per partition to stay within 4096 partitions
+    ig.low_bits = (uint32_t)std::max(std::min(2 * width, kMaxLowBits - 2), 2 * width - kMaxPartBits);
     const uint32_t part_bits = 2u * (uint32_t)width - ig.low_bits;
     if (part_bits > (uint32_t)kMaxPartBits || ig.low_bits > (uint32_t)kMaxLowBits) { ctx->err = "bucket width too large for the candidate binning"; return FFH_E_ARG; }
     ig.n_part = 1u << part_bits;

@@ -113,7 +113,7 @@ constexpr int kPartThreads = 1024;
 constexpr int kPartItemsPerBlock = 32768;
 constexpr int kMaxPartBits = 12;   // <= 4096 partitions
 constexpr int kMaxLowBits = 12;    // <= 4096 buckets per partition (11 bits preferred: see prepare_side)
-constexpr int kBinStage = 26624;   // candidate ids staged in LDS per partition (104 KB); larger partitions scatter to memory
+constexpr int kBinStage = 14336;   // candidate ids staged in LDS per partition (56 KB: two blocks per CU); larger partitions scatter to memory
 constexpr int kGidBits = 20;       // guides per batch < 2^20
 
 struct ItemGeom {
