@@ -581,6 +581,11 @@ __device__ __forceinline__ double bcast_f64(double v, uint32_t l) {  // lane l's
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, l), hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), l);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, 64));
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     const uint64_t gd = guides[g];
     uint32_t run = p0, kept = 0;
     uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, closest_count = 0, n_scored = 0;
-    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
     for (uint32_t i = b; i < e && run < overflow; i += 64) {
         const bool in = i + lane < e;
         const uint64_t t = in ? st[i + lane] : 0ull;
@@ -836,27 +841,26 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         const uint32_t cm = wave_min_u32((keep && m > 0) ? m : 0xFFFFFFFFu);  // :62-67, folded chunk by chunk
         if (cm < closest) { closest = cm; closest_count = 0; }
         if (cm != 0xFFFFFFFFu && cm == closest) closest_count += wave_sum_u32((m == closest) ? ck : 0u);
-        const double fc = f * (double)c;
-        uint64_t scored = __ballot(keep && f == f);
-        while (scored) {                                                       // wave-uniform walk in hit order
-            const uint32_t l = (uint32_t)__builtin_ctzll(scored);
-            scored &= scored - 1;
-            cfd_sum += bcast_f64(fc, l);
-            hsu_sum += bcast_f64(h, l);
-            cfd_max = fmax(cfd_max, bcast_f64(f, l));
-            ++n_scored;
+        // ordered f64 sums: the kept hits are lanes 0 .. nk-1, walked in that order.  Unscored hits (the on-target itself) add +0.0,
+        // which leaves a non-negative sum bit for bit as it is, so the walk needs no mask; maxima do not depend on the order and
+        // are kept per lane (one wave reduction at the end).
+        const bool sc = keep && f == f;
+        const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
+        lane_cfd_max = fmax(lane_cfd_max, sc ? f : 0.0);
+        n_scored += (uint32_t)__popcll(__ballot(sc));
+        for (uint32_t l = 0; l < nk; ++l) {
+            cfd_sum += bcast_f64(fz, l);
+            hsu_sum += bcast_f64(hz, l);
         }
         if (want_jost) {
-            const double jc = j * (double)c;
-            uint64_t js = __ballot(keep && j == j);
-            while (js) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(js);
-                js &= js - 1;
-                jost_sum += bcast_f64(jc, l);
-                jost_max = fmax(jost_max, bcast_f64(j, l));
-            }
+            const bool sj = keep && j == j;
+            const double jz = sj ? j * (double)c : 0.0;
+            lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
+            for (uint32_t l = 0; l < nk; ++l) jost_sum += bcast_f64(jz, l);
         }
     }
+    cfd_max = wave_max_f64(lane_cfd_max);
+    jost_max = wave_max_f64(lane_jost_max);
     GuideSummary s;
     s.n_hits = kept; s.ot_count = run - p0; s.overflow = run >= overflow;
 #pragma unroll
