@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
     const uint32_t n = n_ret[g];
     const uint64_t b = ret_off[g];
     uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, n_scored = 0;
-    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
     for (uint32_t i = 0; i < n; i += 64) {  // pass 1: histogram, closest level, ordered f64 sums
         const bool in = i + lane < n;
         const uint32_t m = in ? mm[b + i + lane] : 0xFFu, c = in ? cnt[b + i + lane] : 0u;
@@ -756,28 +756,26 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
 #pragma unroll
         for (int k = 0; k < 5; ++k) hist[k] += (m == (uint32_t)k) ? c : 0u;     // ClosestHit.scala:57-59
         if (in && m > 0 && m < closest) closest = m;                               // :62-64
-        const double fc = f * (double)c;
-        uint64_t scored = __ballot(in && f == f);                                  // NaN = the on-target itself, not scored
-        while (scored) {                                                           // wave-uniform walk in hit order
-            const uint32_t l = (uint32_t)__builtin_ctzll(scored);
-            scored &= scored - 1;
-            cfd_sum += bcast_f64(fc, l);
-            hsu_sum += bcast_f64(h, l);
-            cfd_max = fmax(cfd_max, bcast_f64(f, l));                              // scores are >= 0, the empty max is 0.0
-            ++n_scored;
+        // the ordered walk of k_guide_epilogue: lanes 0 .. nin-1 in order, +0.0 for the unscored (NaN = the on-target itself)
+        const uint32_t nin = min(n - i, 64u);
+        const bool sc = in && f == f;
+        const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
+        lane_cfd_max = fmax(lane_cfd_max, sc ? f : 0.0);                            // scores are >= 0, the empty max is 0.0
+        n_scored += (uint32_t)__popcll(__ballot(sc));
+        for (uint32_t l = 0; l < nin; ++l) {
+            cfd_sum += bcast_f64(fz, l);
+            hsu_sum += bcast_f64(hz, l);
         }
         if (jost) {                                                                // JostAndSantosCRISPRi.scala:42-43, same walk
             const double j = in ? jost[b + i + lane] : __builtin_nan("");
-            const double jc = j * (double)c;
-            uint64_t js = __ballot(in && j == j);
-            while (js) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(js);
-                js &= js - 1;
-                jost_sum += bcast_f64(jc, l);
-                jost_max = fmax(jost_max, bcast_f64(j, l));
-            }
+            const bool sj = in && j == j;
+            const double jz = sj ? j * (double)c : 0.0;
+            lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
+            for (uint32_t l = 0; l < nin; ++l) jost_sum += bcast_f64(jz, l);
         }
     }
+    cfd_max = wave_max_f64(lane_cfd_max);
+    jost_max = wave_max_f64(lane_jost_max);
     closest = wave_min_u32(closest);
     uint32_t closest_count = 0, in_genome = 0;
     for (uint32_t i = 0; i < n; i += 64) {  // pass 2: occurrences at the closest level (ClosestHit.scala:62-67)
