@@ -168,6 +168,7 @@ struct ffh_ctx {
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
+    uint64_t last_tiles = 0;  // work items of the previous compare launch
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
     // scan state
@@ -309,6 +310,9 @@ static int prepare_database(ffh_ctx *ctx) {
     const int lc = ctx->geo.lc;
     int a = (int)std::floor(std::log((double)std::max<uint64_t>(ctx->T, 1) / 48.0) / std::log(4.0));
     if (ctx->plan_a >= 0) a = ctx->plan_a;
+    // small databases: an image with more than 4^10 buckets costs more in bucket-proportional passes (tile counting, table
+    // scans: 16.7 M buckets for a 12-base image) than its short candidate lists save, so the split stays near the middle
+    if (ctx->plan_a < 0) a = std::max(a, lc - 10);
     a = std::max(lc - 12, std::min(12, a));
     int rc = build_image(ctx, 0, a);
     if (rc) return rc;
@@ -778,7 +782,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ca.guide_base = g0; ca.tbits = ctx->tbits;
         // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
         // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
-        const unsigned cmp_grid = ctx->compare_grid;
+        // the grid only has to cover the work items four waves at a time; their number is known on the device only, so the
+        // previous launch's count (plus a margin) sizes this one -- a wrong guess costs time, never results
+        unsigned cmp_grid = ctx->compare_grid;
+        if (ctx->last_tiles) cmp_grid = (unsigned)std::min<uint64_t>(cmp_grid, std::max<uint64_t>(256, (ctx->last_tiles + ctx->last_tiles / 4) / 4 + 1));
         if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
@@ -805,6 +812,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ms_prep += a; ms_cmp += b;
         ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
+        ctx->last_tiles = (uint64_t)stats[0] + stats[1];
         ctx->tm.compare_launches++;
         cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
         g0 += ng;
@@ -813,7 +821,9 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(hipEventRecord(ctx->ev[5], st));
     // ---- order the hits by (guide, database index) ----
     ctx->hits_sorted = ctx->hits.p;
-    if (ctx->n_raw) {
+    if (ctx->n_raw && ctx->n_raw <= kSmallSort) {
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, ctx->hits.p, (uint32_t)ctx->n_raw);
+    } else if (ctx->n_raw) {
         const uint32_t nbk = sort_nblocks(ctx->n_raw);
         FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
         FFH_HIP(ctx->sort_table.reserve((size_t)256 * nbk + 1));

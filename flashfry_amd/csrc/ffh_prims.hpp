@@ -295,6 +295,28 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
     }
 }
 
+// up to kSmallSort keys: one block, bitonic network in LDS, in place (a handful of guides against a small database gives a few
+// thousand hits; the multi-pass radix sort would spend 20 launches on them)
+constexpr uint32_t kSmallSort = 4096;
+__global__ __launch_bounds__(1024) void k_sort_small(uint64_t *__restrict__ keys, uint32_t n) {
+    __shared__ uint64_t s[kSmallSort];
+    for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) s[i] = i < n ? keys[i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= kSmallSort; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < kSmallSort; i += blockDim.x) {
+                const uint32_t p = i ^ j;
+                if (p > i) {
+                    const uint64_t a = s[i], b = s[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s[i] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = s[i];
+}
+
 struct SortScratch {
     uint64_t *alt = nullptr;     // n keys
     uint64_t *val_alt = nullptr; // n payloads (radix_sort_pairs only)
