@@ -422,7 +422,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, (16 + 2 * kPairSlots) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
     if (e == hipSuccess) {
         ScoreTables h;
@@ -756,9 +756,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     unsigned long long cursor_before = 0;
     for (uint32_t g0 = 0; g0 < n_guides;) {
         const uint32_t ng = std::min(batch, n_guides - g0);
-        unsigned long long snap[3] = {0, 0, 0};
-        FFH_HIP(hipMemcpyAsync(snap, ctx->d_counters, sizeof snap, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipStreamSynchronize(st));
+        // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
+        FFH_HIP(hipMemsetAsync(ctx->d_counters + kPairSlotBase, 0, 2 * kPairSlots * sizeof(unsigned long long), st));
         const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
         if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
         FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
@@ -790,9 +789,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
-        unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+        unsigned long long cnt[5] = {0, 0, 0, 0, 0}, slots[2 * kPairSlots];
         uint32_t stats[2] = {0, 0};
         FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(slots, ctx->d_counters + kPairSlotBase, sizeof slots, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipMemcpyAsync(&stats[0], n_tiles0, 4, hipMemcpyDeviceToHost, st));
         if (plan.r2 >= 0) FFH_HIP(hipMemcpyAsync(&stats[1], n_tiles1, 4, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipStreamSynchronize(st));
@@ -803,9 +803,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
             if (cursor_before) FFH_HIP(hipMemcpy(keep.data(), ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToHost));
             FFH_HIP(ctx->hits.reserve((size_t)(cursor + cursor / 2)));
             if (cursor_before) FFH_HIP(hipMemcpy(ctx->hits.p, keep.data(), (size_t)cursor_before * 8, hipMemcpyHostToDevice));
-            FFH_HIP(hipMemcpy(ctx->d_counters, snap, sizeof snap, hipMemcpyHostToDevice));
+            FFH_HIP(hipMemcpy(ctx->d_counters, &cursor_before, 8, hipMemcpyHostToDevice));  // the hit cursor goes back to where this batch began
             continue;
         }
+        for (uint32_t k = 0; k < kPairSlots; ++k) { ctx->tm.pairs_prefix += slots[2 * k]; ctx->tm.pairs_suffix += slots[2 * k + 1]; }
         float a = 0, b = 0;
         FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
         FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
@@ -845,8 +846,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
     }
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
-    unsigned long long counters[3] = {0, 0, 0};
-    FFH_HIP(hipMemcpyAsync(counters, ctx->d_counters, sizeof counters, hipMemcpyDeviceToHost, st));
     FFH_HIP(hipStreamSynchronize(st));
     FFH_HIP(hipGetLastError());
     float ms_sort = 0, ms_total = 0;
@@ -854,7 +853,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[6]));
     ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp;
     ctx->tm.sort_ms = ms_sort; ctx->tm.total_scan_ms = ms_total; ctx->tm.n_raw_hits = ctx->n_raw;
-    ctx->tm.pairs_prefix = counters[1]; ctx->tm.pairs_suffix = counters[2];
     ctx->scanned = true;
     return FFH_OK;
 }
