@@ -191,9 +191,9 @@ def main():
     exch = ffdist.DeviceExchange(G, dev) if sharded else None
 
     def step():
-        ctx.scan(guides_np, args.max_mismatch)
         if not sharded:
-            return ctx.finalize(args.max_offtargets, summaries_only=True)
+            return ctx.discover(guides_np, args.max_mismatch, args.max_offtargets, summaries_only=True)  # ffh_discover = ffh_scan + ffh_finalize
+        ctx.scan(guides_np, args.max_mismatch)
         # bin shards: shard totals -> all-gather -> ordered cut-off continued across shards -> reduce of the aggregates,
         # all on device memory over RCCL; rank 0 takes the reduced aggregates to the host like the single-GPU step does
         res = exch.step(ctx, args.max_offtargets)

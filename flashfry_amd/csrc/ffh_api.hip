@@ -169,6 +169,7 @@ struct ffh_ctx {
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
     uint64_t last_tiles = 0;  // work items of the previous compare launch
+    bool scan_timing_pending = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
     // scan state
@@ -846,15 +847,24 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
     }
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
-    FFH_HIP(hipStreamSynchronize(st));
     FFH_HIP(hipGetLastError());
-    float ms_sort = 0, ms_total = 0;
-    FFH_HIP(hipEventElapsedTime(&ms_sort, ctx->ev[5], ctx->ev[6]));
-    FFH_HIP(hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[6]));
-    ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp;
-    ctx->tm.sort_ms = ms_sort; ctx->tm.total_scan_ms = ms_total; ctx->tm.n_raw_hits = ctx->n_raw;
+    // no synchronisation here: the ordering kernels run while the caller comes back with ffh_finalize / ffh_shard_totals (same
+    // stream); their timings are read when somebody asks for them (finish_scan_timings)
+    ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp; ctx->tm.n_raw_hits = ctx->n_raw;
+    ctx->scan_timing_pending = true;
     ctx->scanned = true;
     return FFH_OK;
+}
+
+static void finish_scan_timings(ffh_ctx *ctx) {
+    if (!ctx->scan_timing_pending) return;
+    ctx->scan_timing_pending = false;
+    (void)hipSetDevice(ctx->device);
+    if (hipEventSynchronize(ctx->ev[6]) != hipSuccess) return;
+    float ms_sort = 0, ms_total = 0;
+    (void)hipEventElapsedTime(&ms_sort, ctx->ev[5], ctx->ev[6]);
+    (void)hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[6]);
+    ctx->tm.sort_ms = ms_sort; ctx->tm.total_scan_ms = ms_total;
 }
 
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
@@ -900,7 +910,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     FFH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->st;
     const uint32_t G = ctx->n_guides;
-    FFH_HIP(hipEventRecord(ctx->ev[0], st));
+    FFH_HIP(hipEventRecord(ctx->ev[7], st));
     FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
     FFH_HIP(ctx->ot_count.reserve((size_t)G + 1));
     FFH_HIP(ctx->full.reserve((size_t)G + 1));
@@ -931,8 +941,9 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
         r->n_hits = r->guide_offsets[G];
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
         ctx->tm.finalize_ms = ms;
+        finish_scan_timings(ctx);
         *out = r;
         return FFH_OK;
     }
@@ -985,8 +996,9 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
     ctx->tm.finalize_ms = ms;
+    finish_scan_timings(ctx);
     *out = r;
     return FFH_OK;
 }
@@ -1062,6 +1074,7 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
 
 int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out) {
     if (!ctx || !out) return FFH_E_ARG;
+    finish_scan_timings(const_cast<ffh_ctx *>(ctx));
     *out = ctx->tm;
     return FFH_OK;
 }
