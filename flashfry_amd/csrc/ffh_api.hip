@@ -168,7 +168,6 @@ struct ffh_ctx {
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
-    uint64_t last_tiles = 0;  // work items of the previous compare launch
     bool scan_timing_pending = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
@@ -782,10 +781,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ca.guide_base = g0; ca.tbits = ctx->tbits;
         // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
         // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
-        // the grid only has to cover the work items four waves at a time; their number is known on the device only, so the
-        // previous launch's count (plus a margin) sizes this one -- a wrong guess costs time, never results
-        unsigned cmp_grid = ctx->compare_grid;
-        if (ctx->last_tiles) cmp_grid = (unsigned)std::min<uint64_t>(cmp_grid, std::max<uint64_t>(256, (ctx->last_tiles + ctx->last_tiles / 4) / 4 + 1));
+        const unsigned cmp_grid = ctx->compare_grid;
         if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
@@ -814,7 +810,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ms_prep += a; ms_cmp += b;
         ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
-        ctx->last_tiles = (uint64_t)stats[0] + stats[1];
         ctx->tm.compare_launches++;
         cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
         g0 += ng;
