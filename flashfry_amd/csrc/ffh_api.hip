@@ -168,7 +168,7 @@ struct ffh_ctx {
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
-    bool scan_timing_pending = false;
+    bool scan_timing_pending = false, hit_t_ready = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
     // scan state
@@ -836,11 +836,9 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
     FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, ((size_t)n_guides + 1) * 4, st));
     FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, ((size_t)n_guides + 1) * 4, st));
-    FFH_HIP(ctx->hit_t.reserve(ctx->n_raw + 1));
-    if (ctx->n_raw) {
+    if (ctx->n_raw)
         hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->seg_end.p);
-        hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
-    }
+    ctx->hit_t_ready = false;  // the target longs of the hits are gathered on demand (gather_hit_targets)
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
     FFH_HIP(hipGetLastError());
     // no synchronisation here: the ordering kernels run while the caller comes back with ffh_finalize / ffh_shard_totals (same
@@ -848,6 +846,18 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp; ctx->tm.n_raw_hits = ctx->n_raw;
     ctx->scan_timing_pending = true;
     ctx->scanned = true;
+    return FFH_OK;
+}
+
+// hit_t[i] = target long of sorted hit i: needed by the paths that deliver hit lists or shard totals; the aggregates-only epilogue
+// gathers on the fly
+static int gather_hit_targets(ffh_ctx *ctx) {
+    if (ctx->hit_t_ready) return FFH_OK;
+    FFH_HIP(ctx->hit_t.reserve(ctx->n_raw + 1));
+    if (ctx->n_raw)
+        hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, ctx->st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
+    FFH_HIP(hipGetLastError());
+    ctx->hit_t_ready = true;
     return FFH_OK;
 }
 
@@ -867,6 +877,7 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(ctx->totals.reserve((size_t)ctx->n_guides + 1));
+    { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
     if (ctx->n_guides) {
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
                            ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p);
@@ -881,6 +892,7 @@ int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals, uint32_t clam
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(hipDeviceSynchronize());  // the caller's buffer may still be written by another stream (its allocation's fill, a collective)
+    { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
     if (ctx->n_guides)
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
                            ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, device_totals);
@@ -925,7 +937,9 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         ffh_result *r = new (std::nothrow) ffh_result();
         if (!r || !r->allocate(ctx->pool, G, 0, 0, false)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
         r->scores_valid = ctx->geo.cas9_23;
-        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, ctx->guides.p, ctx->geo,
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
+                                  (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                                  d_prior, ctx->guides.p, ctx->geo,
                                   ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p);
         exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
         hipError_t e = hipEventRecord(ctx->ev[1], st);
@@ -942,6 +956,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         *out = r;
         return FFH_OK;
     }
+    { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
     if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
                               ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr);
     exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);

@@ -803,7 +803,10 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
 // guide and one pass over its hits: ordered cut-off (k_cutoff), per-hit scores (k_score_hits) and the aggregation
 // (k_guide_aggregate) without any per-hit array in between.  Same arithmetic in the same order, so the summaries are
 // bit-identical to the three-kernel path that also delivers the hit lists.
+// st == nullptr: the target longs of the hits have not been gathered (k_hit_targets); the kernel then reads them through the
+// sorted hit keys itself -- its waves are busy with the ordered walk, so the gather hides behind them instead of costing a pass.
 __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
+                                                        const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
                                                         const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
                                                         const ScoreTables *__restrict__ tab, uint32_t n_guides, uint32_t overflow, int want_jost,
                                                         uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out) {
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
     for (uint32_t i = b; i < e && run < overflow; i += 64) {
         const bool in = i + lane < e;
-        const uint64_t t = in ? st[i + lane] : 0ull;
+        const uint64_t t = !in ? 0ull : st ? st[i + lane] : targets[hit_keys[i + lane] & ((1ull << tbits) - 1ull)];
         const uint32_t c = in ? (uint32_t)(t >> 48) : 0u;
         const uint32_t incl = wave_inclusive_scan_u32(c, lane);
         const bool keep = in && (run + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
