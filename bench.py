@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--guides", type=int, default=100000)
     ap.add_argument("--max-mismatch", type=int, default=4)
     ap.add_argument("--max-offtargets", type=int, default=2000)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--workload", default="hg38-scale")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure the compare kernel's HBM traffic")
     ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"), help="where the PMC passes write their CSVs")
@@ -101,19 +101,34 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
         dt = time.perf_counter() - t0
         return idx, dt, res
 
-    nb = 8
-    idx, dt, res = run(nb)
-    # one calibration round towards the time budget
-    per_bin = max(dt, 1e-3) / nb
-    nb2 = int(min(4096, max(nb, budget_s / per_bin)))
-    if nb2 > nb * 2:
-        nb = nb2
-        idx, dt, res = run(nb)
+    # The reference's run has a fixed part -- the guide x bin prefix filter over ALL 16384 bins (LinearTraversal.scala:82-97),
+    # the same whatever the sample holds -- and a part proportional to the bins scanned.  Timing a few bins and dividing by
+    # their targets would charge the whole filter to them (and understate the CPU ~30x), so the two parts are timed apart:
+    # F = a run over a database whose bins are all empty, c = (run over the first nb bins - F) / nb; the rate quoted is
+    # the one a full run would have, targets_per_bin / (c + F / 16384).
+    n_bins = 16384
+    _, filt, _ = run(0)
     G = len(guides_np)
-    return {"value": G * idx / dt, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port",
-            "sample": "oracle/ff_oracle.c (C restatement of the reference loop structure, not the JVM), 1 thread, all %d guides vs the "
-                      "first %d of 16384 bins (%d targets), %.1f s incl. the 16384-bin x guide prefix filter" % (G, nb, idx, dt),
-            "seconds": dt, "executed_comparisons": int(res.all_comparisons), "sample_targets": idx}
+    # sample size from a nominal rate (3e8 full comparisons/s; ~0.76 % of the pairs of a bin survive its prefix filters), so the
+    # fixed part is paid twice, not three times; a second round only if that guess left most of the budget unused
+    est_per_bin = max(G * (targets_dev.numel() / n_bins) * 0.0076 / 3e8, 1e-5)
+    nb = int(max(4, min(n_bins // 4, budget_s / est_per_bin)))
+    idx, dt, res = run(nb)
+    spent = filt + dt
+    per_bin = max(dt - filt, 1e-4) / nb
+    if (dt - filt) < budget_s / 4 and nb < n_bins // 4:
+        nb = int(min(n_bins // 4, budget_s / per_bin))
+        idx, dt, res = run(nb)
+        spent += dt
+        per_bin = max(dt - filt, 1e-4) / nb
+    full_run = filt + per_bin * n_bins
+    return {"value": G * (idx / nb) * n_bins / full_run, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port",
+            "sample": "oracle/ff_oracle.c (C restatement of the reference loop structure, not the JVM), 1 thread, all %d guides vs the first %d of "
+                      "%d bins (%d targets): %.2f s, of which %.2f s is the guide x bin prefix filter over all %d bins (timed alone on an empty "
+                      "database); value = the rate of a full run, targets per bin / (scan seconds per bin + filter seconds / %d)"
+                      % (G, nb, n_bins, idx, dt, filt, n_bins, n_bins),
+            "seconds": spent, "filter_seconds": filt, "scan_seconds_per_bin": per_bin, "projected_full_run_seconds": full_run,
+            "sample_only_rate": G * idx / dt, "executed_comparisons": int(res.all_comparisons), "sample_targets": idx}
 
 
 def main():
@@ -259,6 +274,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ffh::k_compare", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
                          "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3),
+                         # SURVEY.md section 8d's integer-VALU figure: 12 lane-ops per executed comparison against 256 CU x 64 lanes x 2.4 GHz
+                         "valu_frac_survey_formula": pairs * 12.0 / (cmp_ms * 1e-3 * 3.9e13),
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
             "cpu_baseline": cpu,
             "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},

@@ -422,7 +422,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, (16 + 2 * kPairSlots) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, (16 + 2 * kPairSlots + 8) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
     if (e == hipSuccess) {
         ScoreTables h;
@@ -757,7 +757,12 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     for (uint32_t g0 = 0; g0 < n_guides;) {
         const uint32_t ng = std::min(batch, n_guides - g0);
         // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
-        FFH_HIP(hipMemsetAsync(ctx->d_counters + kPairSlotBase, 0, 2 * kPairSlots * sizeof(unsigned long long), st));
+        {
+            FlushArgs fa;
+            fa.hits = ctx->hits.p; fa.cap = (uint64_t)ctx->hits.cap; fa.tidx_p = ctx->img[0].tidx.p; fa.tidx_s = ctx->img[1].tidx.p;
+            fa.guide_base = g0; fa.tbits = ctx->tbits;
+            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, fa);
+        }
         const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
         if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
         FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
@@ -774,11 +779,10 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(hipEventRecord(ctx->ev[3], st));
         CompareArgs ca;
         ca.tiles = ctx->tiles.p; ca.n_tiles_a = n_tiles0; ca.n_tiles_b = n_tiles1;
-        ca.keys[0] = ctx->img[0].keys.p; ca.keys[1] = ctx->img[1].keys.p; ca.tidx[0] = ctx->img[0].tidx.p; ca.tidx[1] = ctx->img[1].tidx.p;
+        ca.keys[0] = ctx->img[0].keys.p; ca.keys[1] = ctx->img[1].keys.p;
         ca.slots = ctx->item_gid.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
         ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
-        ca.r1 = plan.r1; ca.hits = ctx->hits.p; ca.cursor = ctx->d_counters; ca.cap = (uint64_t)ctx->hits.cap;
-        ca.guide_base = g0; ca.tbits = ctx->tbits;
+        ca.r1 = plan.r1; ca.cursor = ctx->d_counters;
         // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
         // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
         const unsigned cmp_grid = ctx->compare_grid;

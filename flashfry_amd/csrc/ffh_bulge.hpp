@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_bulge_scan(const uint64_t *__restrict__
             if (m) {
                 unsigned long long base = 0;
                 if (lane_id() == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+                base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
                 if (hit) {
                     const unsigned long long slot = base + mbcnt(m);
                     if (slot < cap) {

@@ -322,35 +322,52 @@ constexpr int kCmpThreads = 256;
 constexpr int kStage = 192;  // staged hits per wave
 
 constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
+constexpr uint32_t kFlushArgBase = kPairSlotBase + 2 * kPairSlots;  // FlushArgs of the current launch live behind them
+// What a wave needs only when it empties its staged hits (once per ~130 hits).  It is read from device memory at that point
+// instead of being kernel arguments: as arguments the twelve scalars stay live through the whole hot loop, and the register
+// allocator pays for them by spilling the item descriptors of the software pipeline to VGPR lanes on every item.
+struct FlushArgs {
+    uint64_t *hits;
+    uint64_t cap;
+    const uint32_t *tidx_p, *tidx_s;
+    uint32_t guide_base;  // first guide of this batch
+    int tbits;            // hit key = (global guide << tbits) | database index
+};
+static_assert(sizeof(FlushArgs) == 40, "FlushArgs is stored as five 64-bit words");
 struct CompareArgs {
     const uint4 *tiles;
     const uint32_t *n_tiles_a, *n_tiles_b;
     const uint64_t *keys[2];
-    const uint32_t *tidx[2];
     const uint32_t *slots;
     const uint64_t *gkey;
     int max_mm;
     uint32_t prefix_mask;
     int r1;
-    uint64_t *hits;
-    unsigned long long *cursor;  // [0] hit cursor; [kPairSlotBase + 2 * slot + side] executed pair tests, summed by the host
-    uint64_t cap;
-    uint32_t guide_base;         // first guide of this batch
-    int tbits;                   // hit key = (global guide << tbits) | database index
+    unsigned long long *cursor;  // [0] hit cursor; [kPairSlotBase + 2 * slot + side] executed pair tests, summed by the host; [kFlushArgBase ..] FlushArgs
 };
+
+// before every compare launch: clears the per-launch pair counters and stores the launch's FlushArgs (one launch in place of a memset)
+__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, FlushArgs f) {
+    if (threadIdx.x < 2 * kPairSlots) cursor[kPairSlotBase + threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) *reinterpret_cast<FlushArgs *>(cursor + kFlushArgBase) = f;
+}
 
 struct HitStage {
     uint64_t *my;
     uint32_t fill;
     uint32_t lane;
-    uint64_t *hits;
     unsigned long long *cursor;
-    uint64_t cap;
-    const uint32_t *tidx_p, *tidx_s;
-    uint32_t guide_base;
-    int tbits;
 
     __device__ __forceinline__ void flush() {
+        // five wave-uniform words, moved to scalar registers so they do not raise the vector register count of the hot loop
+        const unsigned long long *q = cursor + kFlushArgBase;
+        auto uni = [](unsigned long long v) -> unsigned long long {
+            return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);  // the builtin returns int
+        };
+        FlushArgs f;
+        f.hits = (uint64_t *)uni(q[0]); f.cap = uni(q[1]); f.tidx_p = (const uint32_t *)uni(q[2]); f.tidx_s = (const uint32_t *)uni(q[3]);
+        const unsigned long long gb = uni(q[4]);
+        f.guide_base = (uint32_t)gb; f.tbits = (int)(gb >> 32);
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(cursor, (unsigned long long)fill);
         base = __shfl(base, 0, 64);
@@ -360,21 +377,21 @@ struct HitStage {
         // staged record = (batch-local guide << 32) | side << 31 | position in that side's image; it leaves as the sort key
         // (global guide << tbits) | database index -- the lookup rides on the flush instead of a pass of its own over all hits
         for (uint32_t i = lane; i < fill; i += 64)
-            if (base + i < cap) {
+            if (base + i < f.cap) {
                 const uint64_t h = my[i];
                 const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
-                const uint32_t ti = (lo >> 31) ? tidx_s[pos] : tidx_p[pos];
-                hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
+                const uint32_t ti = (lo >> 31) ? f.tidx_s[pos] : f.tidx_p[pos];
+                f.hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + f.guide_base) << f.tbits) | ti;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         fill = 0;
     }
-    // wave-uniform call: `mask` = ballot of the lanes that hit; every hitting lane brings its own (guide, position)
-    __device__ __forceinline__ void push(uint64_t mask, bool hit, uint32_t gid, uint32_t pos) {
-        if (fill > kStage - 64) flush();  // room for one more wave-wide batch
-        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid << 32) | pos;
+    // wave-uniform call: `mask` = ballot of `hit`; every hitting lane records (candidate guide id, position)
+    __device__ __forceinline__ void push(uint64_t mask, bool hit, const uint32_t *gid_lds, uint32_t idx, uint32_t pos) {
+        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid_lds[idx] << 32) | pos;
         fill += (uint32_t)__popcll(mask);
+        if (fill > kStage - 64) flush();  // always leave room for one more wave-wide batch (the predicate never lives across the flush)
     }
 };
 
@@ -386,7 +403,8 @@ struct WaveCtx {  // per-wave state shared by the chunk loops
     const uint32_t *gid_lds;  // 64 candidate guide ids
     uint32_t lane;
     uint32_t side_bit;         // side << 31, or'ed into the recorded position
-    bool suffix;
+    uint32_t pm;               // suffix item: the prefix part of the comparison mask; prefix item: 0
+    int r1s;                   // suffix item: r1; prefix item: -1
 };
 
 // one 64-lane step against W guides at once; `cnt` <= 64 / W targets, key_lds[koff ..], image position pos0 + ..
@@ -399,7 +417,6 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     // lanes without a target carry the all-ones key: it differs from every candidate (real or sentinel) in >= 12 bits
     const uint64_t k = valid ? w.key_lds[koff + tl] : ~0ull;
     const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
-    const uint64_t valid_mask = __ballot(valid);
     const uint32_t max_mm = (uint32_t)w.a->max_mm;
     const uint32_t iters = (n + W - 1) / W;
     auto dist = [&](uint32_t idx, uint32_t &y) -> uint32_t {  // mismatches of this lane's target vs candidate idx
@@ -407,14 +424,17 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
         y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
         return (uint32_t)__popc(y);
     };
+    // the hit predicate stays a lane mask from the compare to the staged store: a candidate without a hit costs one vector
+    // compare and one scalar branch
     auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
-        uint64_t m = __builtin_amdgcn_ballot_w64(p <= max_mm);
-        if (CHECK) m &= valid_mask & __builtin_amdgcn_ballot_w64(idx < n);  // the sentinels are not safe for max_mm >= 12
-        if (m && w.suffix) m &= __builtin_amdgcn_ballot_w64((uint32_t)__popc(y & w.a->prefix_mask) > (uint32_t)w.a->r1);
-        if (m) {
-            const bool hit = (m >> w.lane) & 1ull;
-            w.hs->push(m, hit, hit ? w.gid_lds[idx] : 0u, (pos0 + tl) | w.side_bit);
-        }
+        bool h = p <= max_mm;
+        if (CHECK) h = h && valid && idx < n;  // the sentinels are not safe for max_mm >= 12
+        if (!__builtin_amdgcn_ballot_w64(h)) return;
+        // suffix items keep a pair only if its prefix part has more than r1 mismatches; prefix items run the same three
+        // instructions with pm = 0, r1s = -1 (always true) instead of a branch that would park the predicate in a VGPR
+        h = h && (int)__popc(y & w.pm) > w.r1s;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(h);
+        if (m) w.hs->push(m, h, w.gid_lds, idx, (pos0 + tl) | w.side_bit);
     };
     // four candidates per step; ONE vector compare and ONE scalar branch decide whether any of the 256 pairs is within
     // max_mm (the scalar unit is shared by the CU's four SIMDs: mask algebra per pair would make it the bottleneck)
@@ -442,7 +462,7 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
 // the read-only streams are separate __restrict__ kernel parameters (noalias lets the compiler keep the descriptor
 // loads on the scalar unit and reorder the vector loads around the hit stores)
 template <bool CHECK>
-__global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
+__global__ __launch_bounds__(kCmpThreads, 7) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
                                                          const uint64_t *__restrict__ keys_s, const uint32_t *__restrict__ slots,
                                                          const uint64_t *__restrict__ gkey, const CompareArgs a) {
     __shared__ uint64_t stage[kCmpThreads / 64][kStage];
@@ -456,12 +476,12 @@ __global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restr
     const uint32_t n_tiles = *a.n_tiles_a + *a.n_tiles_b;
     if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
     __syncthreads();
-    HitStage hs{stage[wave], 0u, lane, a.hits, a.cursor, a.cap, a.tidx[0], a.tidx[1], a.guide_base, a.tbits};
+    HitStage hs{stage[wave], 0u, lane, a.cursor};
     unsigned long long pairs[2] = {0, 0};
     // padding candidate: the 12 unused high bits of both planes set, the 20 used ones clear.  It differs from every real
     // key in those 12 bits and from the all-ones key of an idle lane in the 20 low ones: never within max_mm < 12
     const uint64_t sentinel = 0xFFF00000FFF00000ull;
-    WaveCtx w{&a, &hs, key_lds[wave], gk_lds[wave], gid_lds[wave], lane, 0u, false};
+    WaveCtx w{&a, &hs, key_lds[wave], gk_lds[wave], gid_lds[wave], lane, 0u, 0u, -1};
 
     uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave;
     if (t >= n_tiles) goto done;
@@ -508,7 +528,8 @@ __global__ __launch_bounds__(kCmpThreads, 8) void k_compare(const uint4 *__restr
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- stage C: compute item i out of LDS ----
-            w.suffix = side != 0;
+            w.pm = side ? a.prefix_mask : 0u;
+            w.r1s = side ? a.r1 : -1;
             w.side_bit = side << 31;
             pairs[side] += (unsigned long long)kcnt * ng;
             for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
