@@ -790,14 +790,12 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
-        unsigned long long cnt[5] = {0, 0, 0, 0, 0}, slots[2 * kPairSlots];
-        uint32_t stats[2] = {0, 0};
+        unsigned long long cnt[kPairSlotBase + 2 * kPairSlots];  // one read-back: hit cursor, work-item counts, pair counters
         FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(slots, ctx->d_counters + kPairSlotBase, sizeof slots, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(&stats[0], n_tiles0, 4, hipMemcpyDeviceToHost, st));
-        if (plan.r2 >= 0) FFH_HIP(hipMemcpyAsync(&stats[1], n_tiles1, 4, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipStreamSynchronize(st));
         FFH_HIP(hipGetLastError());
+        const unsigned long long *slots = cnt + kPairSlotBase;
+        const uint32_t stats[2] = {(uint32_t)cnt[kTileStatBase], (uint32_t)cnt[kTileStatBase + 1]};
         const unsigned long long cursor = cnt[0];
         if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept)
             std::vector<uint64_t> keep((size_t)cursor_before);

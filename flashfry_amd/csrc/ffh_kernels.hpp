@@ -322,6 +322,7 @@ constexpr int kCmpThreads = 256;
 constexpr int kStage = 192;  // staged hits per wave
 
 constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
+constexpr uint32_t kTileStatBase = 13;  // cursor[13], cursor[14]: work items of the prefix / suffix image in this launch
 constexpr uint32_t kFlushArgBase = kPairSlotBase + 2 * kPairSlots;  // FlushArgs of the current launch live behind them
 // What a wave needs only when it empties its staged hits (once per ~130 hits).  It is read from device memory at that point
 // instead of being kernel arguments: as arguments the twelve scalars stay live through the whole hot loop, and the register
@@ -475,6 +476,8 @@ __global__ __launch_bounds__(kCmpThreads, 7) void k_compare(const uint4 *__restr
     const uint32_t n_waves = gridDim.x * (kCmpThreads / 64);
     const uint32_t n_tiles = *a.n_tiles_a + *a.n_tiles_b;
     if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
+    // the work-item counts ride back to the host in the counter block (one copy after the launch instead of three)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.cursor[kTileStatBase] = *a.n_tiles_a; a.cursor[kTileStatBase + 1] = *a.n_tiles_b; }
     __syncthreads();
     HitStage hs{stage[wave], 0u, lane, a.cursor};
     unsigned long long pairs[2] = {0, 0};
