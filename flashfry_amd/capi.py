@@ -103,7 +103,8 @@ def load_library(build=True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.build_hip_library() if build else _build.LIB
+    # FFH_LIBRARY names another build of the same library (A/B comparisons of kernel variants on one box)
+    path = os.environ.get("FFH_LIBRARY") or (_build.build_hip_library() if build else _build.LIB)
     if not os.path.exists(path):
         raise ImportError("libflashfry_hip.so is missing (%s): build it with `python -m flashfry_amd._build`; "
                           "there is no CPU fallback" % path)

@@ -420,11 +420,6 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
     const uint32_t max_mm = (uint32_t)w.a->max_mm;
     const uint32_t iters = (n + W - 1) / W;
-    auto dist = [&](uint32_t idx, uint32_t &y) -> uint32_t {  // mismatches of this lane's target vs candidate idx
-        const uint64_t g = w.gk_lds[idx];
-        y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
-        return (uint32_t)__popc(y);
-    };
     // the hit predicate stays a lane mask from the compare to the staged store: a candidate without a hit costs one vector
     // compare and one scalar branch
     auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
@@ -439,24 +434,57 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     };
     // four candidates per step; ONE vector compare and ONE scalar branch decide whether any of the 256 pairs is within
     // max_mm (the scalar unit is shared by the CU's four SIMDs: mask algebra per pair would make it the bottleneck)
-    uint32_t j = 0;
-    for (; j + 4 <= iters; j += 4) {
-        uint32_t y0, y1, y2, y3;
-        const uint32_t i0 = j * W + gs, i1 = i0 + W, i2 = i0 + 2 * W, i3 = i0 + 3 * W;
-        const uint32_t p0 = dist(i0, y0), p1 = dist(i1, y1), p2 = dist(i2, y2), p3 = dist(i3, y3);
-        const uint32_t best = min(min(p0, p1), min(p2, p3));
-        if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
-            report(p0, y0, i0);
-            report(p1, y1, i1);
-            report(p2, y2, i2);
-            report(p3, y3, i3);
+    // the loop variable is the LDS address of the group's first candidate key (one add, one compare, one branch of loop control
+    // per group of four); the candidate index is only derived from it when something hit
+    typedef __attribute__((address_space(3))) const uint64_t lds_key;  // 32-bit LDS addresses: the loop control stays in single registers
+    auto dist_at = [&](lds_key *gp, uint32_t &y) -> uint32_t {
+        const uint64_t g = *gp;
+        y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
+        return (uint32_t)__popc(y);
+    };
+    if constexpr (W == 1) {
+        // full-width chunks (all of the suffix image, the first chunk of most prefix buckets): the candidate address is wave-uniform,
+        // so it is the loop variable itself -- one add, one compare, one branch of loop control per group of four
+        lds_key *const gbase = (lds_key *)w.gk_lds;
+        lds_key *gp = gbase, *const g4 = gbase + (iters & ~3u), *const ge = gbase + iters;
+        for (; gp != g4; gp += 4) {
+            uint32_t y0, y1, y2, y3;
+            const uint32_t p0 = dist_at(gp, y0), p1 = dist_at(gp + 1, y1), p2 = dist_at(gp + 2, y2), p3 = dist_at(gp + 3, y3);
+            const uint32_t best = min(min(p0, p1), min(p2, p3));
+            if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
+                const uint32_t i0 = (uint32_t)(gp - gbase);
+                report(p0, y0, i0);
+                report(p1, y1, i0 + 1);
+                report(p2, y2, i0 + 2);
+                report(p3, y3, i0 + 3);
+            }
         }
-    }
-    for (; j < iters; ++j) {
-        uint32_t y;
-        const uint32_t i0 = j * W + gs;
-        const uint32_t p = dist(i0, y);
-        if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, i0);
+        for (; gp != ge; ++gp) {
+            uint32_t y;
+            const uint32_t p = dist_at(gp, y);
+            if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, (uint32_t)(gp - gbase));
+        }
+    } else {
+        lds_key *const gbase = (lds_key *)w.gk_lds;
+        uint32_t j = 0;
+        for (; j + 4 <= iters; j += 4) {
+            uint32_t y0, y1, y2, y3;
+            const uint32_t i0 = j * W + gs, i1 = i0 + W, i2 = i0 + 2 * W, i3 = i0 + 3 * W;
+            const uint32_t p0 = dist_at(gbase + i0, y0), p1 = dist_at(gbase + i1, y1), p2 = dist_at(gbase + i2, y2), p3 = dist_at(gbase + i3, y3);
+            const uint32_t best = min(min(p0, p1), min(p2, p3));
+            if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
+                report(p0, y0, i0);
+                report(p1, y1, i1);
+                report(p2, y2, i2);
+                report(p3, y3, i3);
+            }
+        }
+        for (; j < iters; ++j) {
+            uint32_t y;
+            const uint32_t i0 = j * W + gs;
+            const uint32_t p = dist_at(gbase + i0, y);
+            if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, i0);
+        }
     }
 }
 
