@@ -790,6 +790,47 @@ struct GuideSummary {  // mirrors ffh_guide_summary
     double cfd_max, cfd_sum, hsu_sum, jost_max, jost_sum;
 };
 
+// The ordered f64 walk shared by the two aggregation kernels.  A wave parks its lanes' addends in LDS and every lane then folds
+// them in lane order -- the same sequence of additions as a scalar loop over the hits in database order, hence bit-identical sums
+// -- reading each addend pair back with ONE uniform LDS read.  (Broadcasting with v_readlane cost four scalar-register moves per
+// hit on the vector pipe; the adds themselves are two.)  Lanes past `n` hold +0.0, which a non-negative sum absorbs unchanged, so
+// the loop runs in unrolled groups of kWalkUnroll without a remainder.
+constexpr int kWalkUnroll = 4;
+struct WalkLds {
+    double fh[4][64][2];  // [wave][lane]{cfd x count, hsu}
+    double j[4][64];      // [wave][lane] jost x count
+};
+__device__ __forceinline__ void walk_park(WalkLds &w, uint32_t wave, uint32_t lane, double fz, double hz) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous chunk's reads are done
+    __builtin_amdgcn_wave_barrier();
+    w.fh[wave][lane][0] = fz;
+    w.fh[wave][lane][1] = hz;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void walk_fold(const WalkLds &w, uint32_t wave, uint32_t n, double &cfd_sum, double &hsu_sum) {
+    for (uint32_t l = 0; l < n; l += kWalkUnroll) {
+#pragma unroll
+        for (int k = 0; k < kWalkUnroll; ++k) {
+            cfd_sum += w.fh[wave][l + k][0];
+            hsu_sum += w.fh[wave][l + k][1];
+        }
+    }
+}
+__device__ __forceinline__ void walk_fold_jost(WalkLds &w, uint32_t wave, uint32_t lane, uint32_t n, double jz, double &jost_sum) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    w.j[wave][lane] = jz;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t l = 0; l < n; l += kWalkUnroll) {
+#pragma unroll
+        for (int k = 0; k < kWalkUnroll; ++k) jost_sum += w.j[wave][l + k];
+    }
+}
+
 // One wave per guide.  Integer aggregates are wave reductions (exact in any order); the two f64 sums are accumulated
 // hit by hit IN DATABASE ORDER (lane values broadcast one after the other) so that they associate exactly like the
 // reference's sequential folds (Doench2016CFDScore.scala:79, CrisprMitEduOffTarget.scala:104).
@@ -798,7 +839,8 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
                                                          const uint8_t *__restrict__ mm, const uint32_t *__restrict__ cnt, const double *__restrict__ cfd,
                                                          const double *__restrict__ hsu, const double *__restrict__ jost /* may be null */,
                                                          uint32_t n_guides, GuideSummary *__restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ WalkLds wk;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
     const uint32_t n = n_ret[g];
     const uint64_t b = ret_off[g];
@@ -817,16 +859,14 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
         const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
         lane_cfd_max = fmax(lane_cfd_max, sc ? f : 0.0);                            // scores are >= 0, the empty max is 0.0
         n_scored += (uint32_t)__popcll(__ballot(sc));
-        for (uint32_t l = 0; l < nin; ++l) {
-            cfd_sum += bcast_f64(fz, l);
-            hsu_sum += bcast_f64(hz, l);
-        }
+        walk_park(wk, wave, lane, fz, hz);
+        walk_fold(wk, wave, nin, cfd_sum, hsu_sum);
         if (jost) {                                                                // JostAndSantosCRISPRi.scala:42-43, same walk
             const double j = in ? jost[b + i + lane] : __builtin_nan("");
             const bool sj = in && j == j;
             const double jz = sj ? j * (double)c : 0.0;
             lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
-            for (uint32_t l = 0; l < nin; ++l) jost_sum += bcast_f64(jz, l);
+            walk_fold_jost(wk, wave, lane, nin, jz, jost_sum);
         }
     }
     cfd_max = wave_max_f64(lane_cfd_max);
@@ -868,8 +908,9 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         double *dst = reinterpret_cast<double *>(&lt);
         for (uint32_t i = threadIdx.x; i < sizeof(ScoreTables) / sizeof(double); i += blockDim.x) dst[i] = src[i];
     }
+    __shared__ WalkLds wk;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
     const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
     const uint64_t gd = guides[g];
@@ -904,15 +945,13 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
         lane_cfd_max = fmax(lane_cfd_max, sc ? f : 0.0);
         n_scored += (uint32_t)__popcll(__ballot(sc));
-        for (uint32_t l = 0; l < nk; ++l) {
-            cfd_sum += bcast_f64(fz, l);
-            hsu_sum += bcast_f64(hz, l);
-        }
+        walk_park(wk, wave, lane, fz, hz);
+        walk_fold(wk, wave, nk, cfd_sum, hsu_sum);
         if (want_jost) {
             const bool sj = keep && j == j;
             const double jz = sj ? j * (double)c : 0.0;
             lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
-            for (uint32_t l = 0; l < nk; ++l) jost_sum += bcast_f64(jz, l);
+            walk_fold_jost(wk, wave, lane, nk, jz, jost_sum);
         }
     }
     cfd_max = wave_max_f64(lane_cfd_max);
