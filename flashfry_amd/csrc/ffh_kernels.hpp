@@ -681,10 +681,10 @@ struct ScoreTables {
 
 // mismatches + pam*CFD (Doench2016CFDScore.scala:67-73,132-151) + Hsu2013 hit score (CrisprMitEduOffTarget.scala:107-148)
 // of one (guide, target) pair; both scores are NaN for a 0-mismatch hit (the on-target itself) and for enzymes the
-// models are not defined over.  The multiplications run in the reference's order (position 0..19, PAM last).
-// UNROLL: the 20 positions as straight-line code (thread-per-hit kernels: every table load in flight at once) or as a loop
-// (the wave-per-guide epilogue keeps its tables in LDS and needs the registers for occupancy); same operations, same order.
-template <bool UNROLL = true>
+// models are not defined over.  The multiplications run in the reference's order (position 0..19, PAM last).  The reference
+// multiplies through all twenty positions; where the bases agree its factor is exactly 1.0 (Doench) or absent (Hsu), and x * 1.0
+// is x bit for bit, so only the mismatching positions -- the set bits of the planar XOR, highest bit = base 0 -- are visited:
+// at most maxMismatch iterations instead of twenty.
 __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab, int &mm_out, double &cfd,
                                            double &hsu) {
     const uint64_t pg = planar_key(gd, geo.c0, geo.lc), pt = planar_key(t, geo.c0, geo.lc);
@@ -694,21 +694,17 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
     cfd = __builtin_nan("");
     hsu = __builtin_nan("");
     if (geo.cas9_23 && mm != 0) {
-        // base i (0 = 5' end) of a 23-mer sits at bits [2(22-i)+1 : 2(22-i)]
+        // base i (0 = 5' end) of a 23-mer sits at bits [2(22-i)+1 : 2(22-i)] of the long and at bit 19-i of the planes
         double score = 1.0, part_one = 1.0;
-        int first = -1, last = -1;
-        constexpr int kUnroll = UNROLL ? 20 : 1;
-#pragma unroll kUnroll
-        for (int b = 0; b < 20; ++b) {
-            const int sh = 2 * (22 - b);
+        for (uint32_t m = y; m;) {
+            const int hb = 31 - __clz((int)m);
+            m ^= 1u << hb;
+            const int b = 19 - hb, sh = 2 * (22 - b);
             const uint32_t gb = (uint32_t)(gd >> sh) & 3u, ob = (uint32_t)(t >> sh) & 3u;
-            score *= tab->cfd_mm[b * 16 + gb * 4 + ob];  // 1.0 where the bases agree
-            if (gb != ob) {
-                part_one = part_one * (1.0 - tab->hsu_coeff[b]);
-                if (first < 0) first = b;
-                last = b;
-            }
+            score *= tab->cfd_mm[b * 16 + gb * 4 + ob];
+            part_one = part_one * (1.0 - tab->hsu_coeff[b]);
         }
+        const int first = 19 - (31 - __clz((int)y)), last = 19 - (__ffs((int)y) - 1);
         cfd = tab->cfd_pam[(uint32_t)t & 15u] * score;
         double part_two = 1.0;
         if (mm >= 2) {
@@ -728,16 +724,20 @@ __device__ __forceinline__ void score_pair(uint64_t gd, uint64_t t, const Geomet
 // the mismatching positions 1..19 of the mean activity for (position, off-target base, complement of the guide base),
 // multiplied in ascending position.  20-mers (scan length 23) skip their first base, 19-mers (22) use all of theirs.
 // Defined for every Cas9 pack (:53-58); the caller skips pairs with no mismatch among the compared bases (:40).
-template <bool UNROLL = true>
+// Agreeing positions carry 1.0 in the table, so again only the mismatching ones are visited.
 __device__ __forceinline__ double jost_pair(uint64_t gd, uint64_t t, const Geometry &geo, const ScoreTables *__restrict__ tab) {
+    const uint64_t pg = planar_key(gd, geo.c0, geo.lc), pt = planar_key(t, geo.c0, geo.lc);
+    const uint32_t y = ((uint32_t)(pg >> 32) ^ (uint32_t)(pt >> 32)) | ((uint32_t)pg ^ (uint32_t)pt);
     const int first = geo.scan_len == 23 ? 1 : 0;
     double total = 1.0;
-    constexpr int kUnroll = UNROLL ? 19 : 1;
-#pragma unroll kUnroll
-    for (int k = 0; k < 19; ++k) {
-        const int sh = 2 * (geo.scan_len - 1 - (first + k));
+    for (uint32_t m = y; m;) {
+        const int hb = 31 - __clz((int)m);
+        m ^= 1u << hb;
+        const int b = geo.lc - 1 - hb, k = b - first;  // base b of the protospacer = table row k
+        if (k < 0 || k >= 19) continue;
+        const int sh = 2 * (geo.scan_len - 1 - b);
         const uint32_t gb = (uint32_t)(gd >> sh) & 3u, ob = (uint32_t)(t >> sh) & 3u;
-        total *= tab->jost[k * 16 + ob * 4 + gb];  // 1.0 where the bases agree
+        total *= tab->jost[k * 16 + ob * 4 + gb];
     }
     return total;
 }
@@ -929,8 +929,8 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         int mmi = 0xFF;
         double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
         if (keep) {
-            score_pair<false>(gd, t, geo, &lt, mmi, f, h);
-            if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair<false>(gd, t, geo, &lt);
+            score_pair(gd, t, geo, &lt, mmi, f, h);
+            if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair(gd, t, geo, &lt);
         }
         const uint32_t m = keep ? (uint32_t)mmi : 0xFFu, ck = keep ? c : 0u;
 #pragma unroll
