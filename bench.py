@@ -205,15 +205,20 @@ def main():
 
     exch = ffdist.DeviceExchange(G, dev) if sharded else None
 
+    class _Reduced:  # the sharded step's result: the reduced per-guide aggregates, on rank 0
+        summaries = None
+
     def step():
         if not sharded:
             return ctx.discover(guides_np, args.max_mismatch, args.max_offtargets, summaries_only=True)  # ffh_discover = ffh_scan + ffh_finalize
         ctx.scan(guides_np, args.max_mismatch)
-        # bin shards: shard totals -> all-gather -> ordered cut-off continued across shards -> reduce of the aggregates,
-        # all on device memory over RCCL; rank 0 takes the reduced aggregates to the host like the single-GPU step does
-        res = exch.step(ctx, args.max_offtargets)
+        # bin shards: every shard aggregates on its own and reports its totals -> all-gather -> the guides whose ordered cut-off the
+        # earlier shards move are aggregated again -> reduction of the aggregates; all on device memory over RCCL, stream-ordered.
+        # Rank 0 takes the reduced aggregates to the host like the single-GPU step does
+        exch.step(ctx, args.max_offtargets)
+        res = _Reduced()
         if rank == 0:
-            res.reduced = exch.summaries_numpy()
+            res.summaries = exch.summaries_numpy()
         return res
 
     for _ in range(args.warmup):
@@ -246,7 +251,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         cmp_ms = float(np.mean([t["compare_ms"] for t in tms]))
         raw_hits = int(np.mean([t["n_raw_hits"] for t in tms]))
-        final = res.reduced if sharded else res.summaries
+        final = res.summaries
         kept_pos = int(final["ot_count"].sum())
         # algorithmic bytes of ONE compare launch: every resident target once (8 B), every guide once (8 B), one 8-byte record per hit
         b_alg = 8 * T + 8 * G + 8 * raw_hits

@@ -24,7 +24,7 @@ SYMBOLS = [
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
     "ffh_bulge_result_hit_targets", "ffh_bulge_result_hit_mismatches", "ffh_bulge_result_hit_bulge_type", "ffh_bulge_result_hit_bulge_position",
-    "ffh_bulge_result_free", "ffh_exchange_pack", "ffh_exchange_mask", "ffh_exchange_unpack", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
+    "ffh_bulge_result_free", "ffh_exchange_pack", "ffh_exchange_mask", "ffh_exchange_unpack", "ffh_use_stream", "ffh_finalize_shard", "ffh_exchange_prior", "ffh_finalize_shard_fixup", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
@@ -150,6 +150,10 @@ def load_library(build=True):
     L.ffh_exchange_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ffh_exchange_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.ffh_exchange_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ffh_use_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ffh_finalize_shard.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+    L.ffh_exchange_prior.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.ffh_finalize_shard_fixup.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ffh_finalize.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_discover.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_score_lists.argtypes = [C.c_void_p, u64p, C.c_uint32, u64p, u64p, C.POINTER(C.c_void_p)]
@@ -390,6 +394,22 @@ class Context:
 
     def exchange_unpack(self, summ_ptr, n, max_ptr, sum_ptr, fsum_all_ptr, world):
         self._check(self.L.ffh_exchange_unpack(self.h, summ_ptr, n, max_ptr, sum_ptr, fsum_all_ptr, world))
+
+    def use_stream(self, hip_stream, on=True):
+        """issue this context's work on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream)"""
+        self._check(self.L.ffh_use_stream(self.h, C.c_void_p(hip_stream), 1 if on else 0))
+
+    def finalize_shard(self, max_offtargets, summ_ptr, totals_ptr, jost=False):
+        """this shard's aggregates as if it were the first shard -> device summaries, and its saturated totals -> device totals"""
+        self._check(self.L.ffh_finalize_shard(self.h, max_offtargets, FINALIZE_JOST if jost else 0, C.c_void_p(summ_ptr), C.c_void_p(totals_ptr)))
+
+    def exchange_prior(self, all_totals_ptr, n, rank, clamp, prior_ptr):
+        self._check(self.L.ffh_exchange_prior(self.h, C.c_void_p(all_totals_ptr), n, rank, clamp, C.c_void_p(prior_ptr)))
+
+    def finalize_shard_fixup(self, max_offtargets, prior_ptr, totals_ptr, summ_ptr, jost=False):
+        """re-aggregate, with the prior, the guides whose cut-off the earlier shards change; their device summaries are overwritten"""
+        self._check(self.L.ffh_finalize_shard_fixup(self.h, max_offtargets, FINALIZE_JOST if jost else 0, C.c_void_p(prior_ptr), C.c_void_p(totals_ptr),
+                                                    C.c_void_p(summ_ptr)))
 
     def finalize_device_prior(self, max_offtargets, prior_device_ptr, summaries_only=True, jost=False):
         """finalize with the prior totals taken from device memory (n_guides uint32)"""

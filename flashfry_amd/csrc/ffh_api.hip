@@ -153,6 +153,8 @@ struct ffh_result {
 struct ffh_ctx {
     int device = 0, enzyme = 0;
     hipStream_t st = nullptr;
+    hipStream_t own_st = nullptr;  // the stream the context created; st may name the caller's instead (ffh_use_stream)
+    bool borrowed = false;
     Geometry geo{};
     std::string err;
 
@@ -168,7 +170,7 @@ struct ffh_ctx {
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
     unsigned compare_grid = 256 * 8 * 8;
-    bool scan_timing_pending = false, hit_t_ready = false;
+    bool scan_timing_pending = false, finalize_timing_pending = false, hit_t_ready = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
     // scan state
@@ -377,6 +379,12 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     return FFH_OK;
 }
 
+// Device buffers of the caller are produced and consumed by the caller's streams (a tensor fill, an RCCL collective).  With the
+// context on its own stream the entry points that touch them wait for the device before and for the stream after their kernels;
+// on the caller's stream (ffh_use_stream) stream order does the same for free.
+static hipError_t fence_in(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : hipDeviceSynchronize(); }
+static hipError_t fence_out(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : hipStreamSynchronize(ctx->st); }
+
 // =============================================================================================================
 // C ABI
 // =============================================================================================================
@@ -420,7 +428,8 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     if (const char *e = std::getenv("FFH_COMPARE_GRID")) { const long v = std::atol(e); if (v > 0) ctx->compare_grid = (unsigned)v; }
     if (const char *e = std::getenv("FFH_MAX_GUIDE_BATCH")) { const long v = std::atol(e); if (v > 0) ctx->max_guide_batch = (uint32_t)v; }
     hipError_t e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_st, hipStreamNonBlocking);
+    ctx->st = ctx->own_st;
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, (16 + 2 * kPairSlots + 8) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
@@ -445,11 +454,11 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
 void ffh_destroy(ffh_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+    (void)hipStreamSynchronize(ctx->st);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
-    if (ctx->st) (void)hipStreamDestroy(ctx->st);
+    if (ctx->own_st) (void)hipStreamDestroy(ctx->own_st);
     delete ctx;  // the device buffers free themselves
 }
 
@@ -873,6 +882,15 @@ static void finish_scan_timings(ffh_ctx *ctx) {
     (void)hipEventElapsedTime(&ms_total, ctx->ev[0], ctx->ev[6]);
     ctx->tm.sort_ms = ms_sort; ctx->tm.total_scan_ms = ms_total;
 }
+static void finish_finalize_timing(ffh_ctx *ctx) {  // the stream-ordered shard epilogue leaves its two events behind
+    if (!ctx->finalize_timing_pending) return;
+    ctx->finalize_timing_pending = false;
+    (void)hipSetDevice(ctx->device);
+    if (hipEventSynchronize(ctx->ev[1]) != hipSuccess) return;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
+    ctx->tm.finalize_ms = ms;
+}
 
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     if (!ctx || !totals) return FFH_E_ARG;
@@ -942,7 +960,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
-                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p);
+                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr);
         exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
         hipError_t e = hipEventRecord(ctx->ev[1], st);
         if (e == hipSuccess) e = hipGetLastError();
@@ -1087,6 +1105,7 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
 int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out) {
     if (!ctx || !out) return FFH_E_ARG;
     finish_scan_timings(const_cast<ffh_ctx *>(ctx));
+    finish_finalize_timing(const_cast<ffh_ctx *>(ctx));
     *out = ctx->tm;
     return FFH_OK;
 }
@@ -1374,6 +1393,15 @@ void ffh_bulge_result_free(ffh_bulge_result *r) { delete r; }
 // =====================================================================================================================
 namespace ffh {
 
+// prior of a shard = positions of the shards before it in database order, saturated like every running total (CRISPRSiteOT.scala:45)
+__global__ void k_exchange_prior(const uint32_t *__restrict__ all_totals, uint32_t n, uint32_t rank, uint32_t clamp, uint32_t *__restrict__ prior) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint64_t sum = 0;
+    for (uint32_t r = 0; r < rank; ++r) sum += all_totals[(size_t)r * n + g];
+    prior[g] = (uint32_t)(sum < clamp ? sum : clamp);
+}
+
 // lanes of the MAX collective: overflow, cfd_max, jost_max, -closest (so that the MAX delivers the MIN); lanes of the SUM
 // collective: n_hits, ot_count, hist[5], in_genome, n_scored, closest_count (filled by k_exchange_mask); f64 sums gathered apart
 __global__ void k_exchange_pack(const GuideSummary *__restrict__ s, uint32_t n, double *__restrict__ mx, int32_t *__restrict__ sums, double *__restrict__ fsum) {
@@ -1418,32 +1446,78 @@ __global__ void k_exchange_unpack(GuideSummary *__restrict__ s, uint32_t n, cons
 
 extern "C" {
 
+int ffh_use_stream(ffh_ctx *ctx, void *hip_stream, int on) {
+    if (!ctx) return FFH_E_ARG;
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(hipStreamSynchronize(ctx->st));  // nothing of the old stream may still be in flight when the order changes
+    ctx->borrowed = on != 0;
+    ctx->st = ctx->borrowed ? (hipStream_t)hip_stream : ctx->own_st;
+    return FFH_OK;
+}
+
+// the aggregates of this shard as if it were the first one (prior 0), and its saturated totals: one pass of the fused epilogue
+static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, const uint32_t *d_prior, const uint32_t *d_fix_totals, void *d_summaries,
+                          uint32_t *d_totals) {
+    if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    if (max_offtargets < 0) { ctx->err = "bad argument"; return FFH_E_ARG; }
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(fence_in(ctx));
+    const uint32_t G = ctx->n_guides;
+    FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
+    if (!d_fix_totals) FFH_HIP(hipEventRecord(ctx->ev[7], ctx->st));
+    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+                              (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                              d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p,
+                              (GuideSummary *)d_summaries, d_totals, d_fix_totals);
+    FFH_HIP(hipGetLastError());
+    if (!d_fix_totals) { FFH_HIP(hipEventRecord(ctx->ev[1], ctx->st)); ctx->finalize_timing_pending = true; }
+    FFH_HIP(fence_out(ctx));
+    return FFH_OK;
+}
+int ffh_finalize_shard(ffh_ctx *ctx, int max_offtargets, unsigned flags, void *d_summaries, uint32_t *d_totals) {
+    if (!ctx || !d_summaries || !d_totals) return FFH_E_ARG;
+    return shard_epilogue(ctx, max_offtargets, flags, nullptr, nullptr, d_summaries, d_totals);
+}
+int ffh_finalize_shard_fixup(ffh_ctx *ctx, int max_offtargets, unsigned flags, const uint32_t *d_prior, const uint32_t *d_totals, void *d_summaries) {
+    if (!ctx || !d_prior || !d_totals || !d_summaries) return FFH_E_ARG;
+    return shard_epilogue(ctx, max_offtargets, flags, d_prior, d_totals, d_summaries, nullptr);
+}
+int ffh_exchange_prior(ffh_ctx *ctx, const uint32_t *d_all_totals, uint32_t n, uint32_t rank, uint32_t clamp, uint32_t *d_prior) {
+    if (!ctx || !d_all_totals || !d_prior) return FFH_E_ARG;
+    FFH_HIP(hipSetDevice(ctx->device));
+    FFH_HIP(fence_in(ctx));
+    if (n) hipLaunchKernelGGL(k_exchange_prior, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, d_all_totals, n, rank, clamp, d_prior);
+    FFH_HIP(hipGetLastError());
+    FFH_HIP(fence_out(ctx));
+    return FFH_OK;
+}
+
 int ffh_exchange_pack(ffh_ctx *ctx, const void *d_summaries, uint32_t n, double *d_max, int32_t *d_sum, double *d_fsum) {
     if (!ctx || !d_summaries || !d_max || !d_sum || !d_fsum) return FFH_E_ARG;
     FFH_HIP(hipSetDevice(ctx->device));
-    FFH_HIP(hipDeviceSynchronize());
+    FFH_HIP(fence_in(ctx));
     if (n) hipLaunchKernelGGL(k_exchange_pack, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (const GuideSummary *)d_summaries, n, d_max, d_sum, d_fsum);
     FFH_HIP(hipGetLastError());
-    FFH_HIP(hipStreamSynchronize(ctx->st));
+    FFH_HIP(fence_out(ctx));
     return FFH_OK;
 }
 int ffh_exchange_mask(ffh_ctx *ctx, const void *d_summaries, uint32_t n, const double *d_max_reduced, int32_t *d_sum) {
     if (!ctx || !d_summaries || !d_max_reduced || !d_sum) return FFH_E_ARG;
     FFH_HIP(hipSetDevice(ctx->device));
-    FFH_HIP(hipDeviceSynchronize());  // the collective ran on another stream
+    FFH_HIP(fence_in(ctx));  // the collective ran on another stream
     if (n) hipLaunchKernelGGL(k_exchange_mask, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (const GuideSummary *)d_summaries, n, d_max_reduced, d_sum);
     FFH_HIP(hipGetLastError());
-    FFH_HIP(hipStreamSynchronize(ctx->st));
+    FFH_HIP(fence_out(ctx));
     return FFH_OK;
 }
 int ffh_exchange_unpack(ffh_ctx *ctx, void *d_summaries, uint32_t n, const double *d_max_reduced, const int32_t *d_sum_reduced, const double *d_fsum_all,
                         uint32_t world) {
     if (!ctx || !d_summaries || !d_max_reduced || !d_sum_reduced || !d_fsum_all || !world) return FFH_E_ARG;
     FFH_HIP(hipSetDevice(ctx->device));
-    FFH_HIP(hipDeviceSynchronize());
+    FFH_HIP(fence_in(ctx));
     if (n) hipLaunchKernelGGL(k_exchange_unpack, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->st, (GuideSummary *)d_summaries, n, d_max_reduced, d_sum_reduced, d_fsum_all, world);
     FFH_HIP(hipGetLastError());
-    FFH_HIP(hipStreamSynchronize(ctx->st));
+    FFH_HIP(fence_out(ctx));
     return FFH_OK;
 }
 

@@ -901,7 +901,9 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
                                                         const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
                                                         const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
                                                         const ScoreTables *__restrict__ tab, uint32_t n_guides, uint32_t overflow, int want_jost,
-                                                        uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out) {
+                                                        uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out,
+                                                        uint32_t *__restrict__ totals_out /* nullable: min(positions of all hits, overflow) */,
+                                                        const uint32_t *__restrict__ fix_totals /* nullable: redo only guides the prior changes */) {
     __shared__ ScoreTables lt;  // 4.6 KB: the coefficient tables, read with rolled loops (low register count -> 8 waves per SIMD)
     {
         const double *src = reinterpret_cast<const double *>(tab);
@@ -913,6 +915,9 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
     const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
+    // multi-GPU fix-up pass: a shard's own aggregates (computed with prior 0) stand unless the positions of the shards before it
+    // push this guide's running total to the limit inside or before this shard
+    if (fix_totals && !(p0 > 0u && p0 + fix_totals[g] >= overflow)) return;
     const uint64_t gd = guides[g];
     uint32_t run = p0, kept = 0;
     uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, closest_count = 0, n_scored = 0;
@@ -965,7 +970,10 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     s.in_genome = s.hist[0]; s.n_scored = n_scored;
     s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
     s.jost_max = jost_max; s.jost_sum = jost_sum;
-    if (lane == 0) { out[g] = s; n_ret[g] = kept; }
+    if (lane == 0) {
+        out[g] = s; n_ret[g] = kept;
+        if (totals_out) totals_out[g] = min(run - p0, overflow);
+    }
 }
 
 __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ out_off,

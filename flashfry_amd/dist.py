@@ -164,12 +164,29 @@ class DeviceExchange:
         ctx.exchange_unpack(self.summ.data_ptr(), G, self.mx.data_ptr(), self.sums.data_ptr(), self.fsum_all.data_ptr(), self.world)
         return self.summ
 
-    def step(self, ctx, max_offtargets, jost=False):
+    def step_two_pass(self, ctx, max_offtargets, jost=False):
+        """the exchange in its first form: totals pass, all-gather, prior, full aggregation pass with the prior, reduction"""
         prior = self.prior_totals(ctx, max_offtargets)
         res = ctx.finalize_device_prior(max_offtargets, prior.data_ptr(), summaries_only=True, jost=jost)
         ctx.summaries_to_device(self.summ.data_ptr())
         self.reduce_summaries_fused(ctx)
         return res
+
+    def step(self, ctx, max_offtargets, jost=False):
+        """One aggregation pass per shard, stream-ordered, no host round trip: every shard aggregates as if it were the first
+        (ffh_finalize_shard also yields its totals), the totals are all-gathered, and only the guides whose cut-off the earlier
+        shards actually move -- prior > 0 and prior + shard total >= maximumOffTargets -- are aggregated again with the prior
+        (ffh_finalize_shard_fixup).  Same reduced summaries as step_two_pass, bit for bit.  With device buffers the context is
+        put on torch's current stream, so the library kernels and the RCCL collectives form one ordered sequence."""
+        if self.summ.is_cuda and not getattr(ctx, "_on_caller_stream", False):
+            ctx.use_stream(self.torch.cuda.current_stream().cuda_stream)
+            ctx._on_caller_stream = True
+        ctx.finalize_shard(max_offtargets, self.summ.data_ptr(), self.totals.data_ptr(), jost=jost)
+        self._all_gather(self.all_totals, self.totals)
+        ctx.exchange_prior(self.all_totals.data_ptr(), self.G, self.rank, max_offtargets, self.prior.data_ptr())
+        ctx.finalize_shard_fixup(max_offtargets, self.prior.data_ptr(), self.totals.data_ptr(), self.summ.data_ptr(), jost=jost)
+        self.reduce_summaries_fused(ctx)
+        return None
 
     def summaries_numpy(self):
         """the reduced summaries on the host (through a page-locked staging tensor when the buffers live on a GPU)"""

@@ -224,6 +224,28 @@ int ffh_exchange_mask(ffh_ctx *ctx, const void *device_summaries, uint32_t n_gui
 int ffh_exchange_unpack(ffh_ctx *ctx, void *device_summaries, uint32_t n_guides, const double *device_max_reduced, const int32_t *device_sum_reduced,
                         const double *device_fsum_all /* [world][n_guides][3] */, uint32_t world);
 
+/* The exchange without a host round trip and without a second pass over the hits.  The ordered cut-off couples the shards only
+ * for a guide whose positions reach maximumOffTargets somewhere along the shard order (crispr/CRISPRSiteOT.scala:39-46): for every
+ * other guide the aggregates a shard computes on its own are already final.  So every shard first aggregates as if it were the
+ * first one,
+ *   ffh_finalize_shard        aggregates with prior 0 -> device_summaries [n_guides], shard totals (saturated at max_offtargets)
+ *                             -> device_totals [n_guides];                                          then all-gather of the totals
+ *   ffh_exchange_prior        device_prior[g] = min(sum of all_totals[r][g] over r < rank, clamp)
+ *   ffh_finalize_shard_fixup  re-aggregates, with the prior, exactly the guides it changes anything for (prior > 0 and
+ *                             prior + shard total >= max_offtargets) and overwrites their entries of device_summaries
+ * and the three reduction collectives above follow.  Same results as ffh_shard_totals_device + ffh_finalize(prior) +
+ * ffh_summaries_to_device, bit for bit.
+ * ffh_use_stream(on = 1): the context issues its work on the caller's HIP stream (a hipStream_t; NULL is the default stream) --
+ * the stream the caller's collectives are ordered with (PyTorch: torch.cuda.current_stream().cuda_stream) -- and the
+ * device-buffer entry points of this section then neither wait for the device before nor for the stream after their kernels:
+ * the exchange is one stream-ordered sequence.  The stream stays the caller's.  on = 0: back to the context's own stream. */
+int ffh_use_stream(ffh_ctx *ctx, void *hip_stream, int on);
+int ffh_finalize_shard(ffh_ctx *ctx, int max_offtargets, unsigned flags /* FFH_FINALIZE_JOST */, void *device_summaries, uint32_t *device_totals);
+int ffh_exchange_prior(ffh_ctx *ctx, const uint32_t *device_all_totals /* [world][n_guides] */, uint32_t n_guides, uint32_t rank, uint32_t clamp,
+                       uint32_t *device_prior);
+int ffh_finalize_shard_fixup(ffh_ctx *ctx, int max_offtargets, unsigned flags, const uint32_t *device_prior, const uint32_t *device_totals,
+                             void *device_summaries);
+
 /* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
  * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the
  * lists are taken as they are (no cut-off, overflow = 0).  No database needs to be loaded.  The result carries

@@ -472,6 +472,59 @@ def test_device_resident_exchange_entry_points(capi, oracle):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("on_caller_stream", [False, True])
+def test_one_pass_shard_finalize_equals_the_two_pass_exchange(capi, oracle, on_caller_stream):
+    """ffh_finalize_shard / ffh_exchange_prior / ffh_finalize_shard_fixup (one aggregation pass per shard; only the guides whose
+    cut-off the earlier shards move are aggregated again) against ffh_shard_totals + ffh_finalize(prior): three shards on the one
+    GPU, a maximumOffTargets small enough that the limit is reached in the first, the second, the third shard or never"""
+    import torch
+    odb, t, p, g = dense_case(oracle, seed=21)
+    counts = (t >> np.uint64(48)).astype(np.int64)
+    cuts = [0, len(t) // 3, 2 * len(t) // 3, len(t)]
+    pcuts = [int(counts[:c].sum()) for c in cuts]
+    dev = torch.device("cuda", 0)
+    n, isz = len(g), capi.SUMMARY_DTYPE.itemsize
+    for max_ot in (25, 60, 2000):
+        ctxs = [capi.Context(3) for _ in range(3)]
+        try:
+            want, prior_want, tots = [], [], []
+            for r, c in enumerate(ctxs):
+                c.load_soa(t[cuts[r]:cuts[r + 1]], p[pcuts[r]:pcuts[r + 1]])
+                c.scan(g, 5)
+                prior = np.minimum(np.sum(tots, axis=0, dtype=np.int64), max_ot).astype(np.uint32) if tots else None
+                prior_want.append(prior if prior is not None else np.zeros(n, np.uint32))
+                want.append(c.finalize(max_ot, prior_totals=prior, summaries_only=True, jost=True).summaries.copy())
+                tots.append(c.shard_totals(max_ot).astype(np.int64))
+            if on_caller_stream:
+                for c in ctxs:
+                    c.use_stream(torch.cuda.current_stream().cuda_stream)
+            summ = [torch.zeros(n * isz, dtype=torch.uint8, device=dev) for _ in ctxs]
+            totals = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in ctxs]
+            for c, sm, tt in zip(ctxs, summ, totals):
+                c.finalize_shard(max_ot, sm.data_ptr(), tt.data_ptr(), jost=True)
+            all_totals = torch.cat(totals)                                        # the all-gather
+            redone = 0
+            for r, (c, sm, tt) in enumerate(zip(ctxs, summ, totals)):
+                assert np.array_equal(tt.cpu().numpy().astype(np.int64), tots[r])
+                prior = torch.zeros(n, dtype=torch.int32, device=dev)
+                c.exchange_prior(all_totals.data_ptr(), n, r, max_ot, prior.data_ptr())
+                assert np.array_equal(prior.cpu().numpy().astype(np.uint32), prior_want[r])
+                before = sm.cpu().numpy().tobytes()
+                c.finalize_shard_fixup(max_ot, prior.data_ptr(), tt.data_ptr(), sm.data_ptr(), jost=True)
+                after = sm.cpu().numpy()
+                redone += before != after.tobytes()
+                got = after.view(capi.SUMMARY_DTYPE)
+                bad = [i for i in range(n) if got[i].tobytes() != want[r][i].tobytes()]
+                assert not bad, (max_ot, r, bad[:3], got[bad[0]], want[r][bad[0]])
+            if max_ot < 2000:
+                assert redone >= 1 and want[2]["overflow"].any() and not want[2]["overflow"].all()
+            else:
+                assert redone == 0
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_cas12a_bulge_search_matches_the_brute_force_specification(capi, oracle):
     """config C5 (Cas12a TTTV, mismatches + one bulge; the reference has no bulge search: parity is against this repository's own
     specification, restated with strings in the oracle): every (guide, target) pair of a small database, all three alignment kinds"""
