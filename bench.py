@@ -7,7 +7,7 @@ candidate lists -> compare kernel -> hit ordering -> ordered cut-off -> CFD/Hsu2
 images are already in HBM when the timed region starts (ffh_db_load_soa is outside it; its device time is reported
 as db_prepare_ms).  Inputs are synthetic and seeded (flashfry_amd/synth.py) -- there is no genome on the box.
 
-  python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N > 1: every rank owns its own database shard of the same size (weak scaling: a genome N times larger, bins sharded
@@ -30,8 +30,8 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--targets", type=float, default=3.0e8, help="unique targets per GPU shard (hg38 NGG ~ 3e8)")
     ap.add_argument("--guides", type=int, default=100000)
     ap.add_argument("--max-mismatch", type=int, default=4)
