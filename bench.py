@@ -81,6 +81,50 @@ def measure_traffic(args):
     return {"fetch_kib": cmp_fetch, "write_kib": cmp_write, "calibration_fetch_kib": cal}
 
 
+_CPU_MT = None
+
+
+def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single_rate, filt, per_bin):
+    """The same port with one thread per usable host core, each scanning its own sample of bins at the same time (ctypes releases
+    the GIL inside the C call).  What is measured is how much slower a thread gets when all cores run (memory bandwidth, clocks):
+    wall time of the concurrent runs against the single-thread model F + c * bins for the same sample.  The all-core rate quoted
+    is single-thread rate x threads x that efficiency, i.e. a run that splits the 16384 bins (and their share of the prefix filter)
+    evenly over the threads."""
+    import ctypes
+    import threading
+    from flashfry_amd import capi
+    from tests import oracle_lib
+    threads = max(1, int(capi.load_library().ffh_host_threads()))
+    bins_each = int(max(4, min(64, 4.0 / max(per_bin, 1e-6))))   # ~4 s of scan per thread on top of the filter
+    lib = oracle.lib
+    g = np.ascontiguousarray(guides_np, dtype=np.uint64)
+    gp = g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    dbs = [run.build(bins_each) for _ in range(threads)]          # every thread owns a database object (same sample)
+    times = [0.0] * threads
+
+    def work(k):
+        t0 = time.perf_counter()
+        r = lib.ffo_discover(dbs[k].h, gp, len(g), max_mm, max_ot, 0)
+        times[k] = time.perf_counter() - t0
+        if r:
+            lib.ffo_result_free(r)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    wall = time.perf_counter() - t0
+    model = filt + per_bin * bins_each
+    eff = min(1.0, model / max(wall, 1e-9))
+    return {"value": single_rate * threads * eff, "unit": "guide*target comparisons/s", "cores": threads, "kind": "port",
+            "sample": "oracle/ff_oracle.c, %d threads (the usable cores of this box) each running the single-thread sample of %d bins at the same "
+                      "time: %.2f s wall against %.2f s for one thread alone -> parallel efficiency %.2f; value = single-thread rate x threads x efficiency"
+                      % (threads, bins_each, wall, model, eff),
+            "seconds": wall, "parallel_efficiency": eff}
+
+
 def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max_ot, budget_s):
     """the oracle (C restatement of the reference algorithm, single thread) timed on a bounded sample: the first
     `nbins` of the 16384 database bins, all guides"""
@@ -89,17 +133,24 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
     from flashfry_amd import synth
     oracle = oracle_lib.load()
 
-    def run(nbins):
+    def build(nbins):
         limit = nbins << 32  # 7-base bin = bits [45:32] of a Cas9 23-mer
         seq = targets_dev & ((1 << 46) - 1)
         idx = int(torch.searchsorted(seq, torch.tensor([limit], device=seq.device, dtype=seq.dtype))[0])
         t = targets_dev[:idx].cpu().numpy().view(np.uint64)
         p = positions_dev[:int(pos_off_dev[idx])].cpu().numpy().view(np.uint64)
         odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+        odb.sample_targets = idx
+        return odb
+
+    def run(nbins):
+        odb = build(nbins)
         t0 = time.perf_counter()
         res = odb.discover(guides_np, max_mm, max_ot)
         dt = time.perf_counter() - t0
-        return idx, dt, res
+        return odb.sample_targets, dt, res
+
+    run.build = build
 
     # The reference's run has a fixed part -- the guide x bin prefix filter over ALL 16384 bins (LinearTraversal.scala:82-97),
     # the same whatever the sample holds -- and a part proportional to the bins scanned.  Timing a few bins and dividing by
@@ -122,6 +173,13 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
         spent += dt
         per_bin = max(dt - filt, 1e-4) / nb
     full_run = filt + per_bin * n_bins
+    single = G * (idx / nb) * n_bins / full_run
+    global _CPU_MT
+    _CPU_MT = None
+    try:  # SURVEY.md section 8d also asks for the port on all host cores (bins are independent: one thread per bin range)
+        _CPU_MT = cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single, filt, per_bin)
+    except Exception as e:
+        _CPU_MT = {"value": None, "unit": "guide*target comparisons/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     return {"value": G * (idx / nb) * n_bins / full_run, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port",
             "sample": "oracle/ff_oracle.c (C restatement of the reference loop structure, not the JVM), 1 thread, all %d guides vs the first %d of "
                       "%d bins (%d targets): %.2f s, of which %.2f s is the guide x bin prefix filter over all %d bins (timed alone on an empty "
@@ -283,6 +341,7 @@ def main():
                          "valu_frac_survey_formula": pairs * 12.0 / (cmp_ms * 1e-3 * 3.9e13),
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": _CPU_MT,
             "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
             "discover_wall_s": dt / args.steps,
             "db_prepare_ms": info.prepare_ms,

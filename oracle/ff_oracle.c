@@ -28,8 +28,11 @@ void ffo_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-static uint64_t g_bit_comparisons;  /* BitEncoding.allComparisons, bitcoding/BitEncoding.scala:193 */
-static uint64_t g_all_comparisons;  /* Traverser.allComparisons, reference/traverser/Traverser.scala:74 */
+/* per thread: bench.py's all-core baseline runs one discover per thread, and shared counters in the inner loop would make the
+ * threads fight over one cache line (the reference itself is single-threaded); initial-exec: a plain %fs-relative access, the
+ * default model of a shared object would call __tls_get_addr on every comparison */
+static __thread uint64_t g_bit_comparisons __attribute__((tls_model("initial-exec")));  /* BitEncoding.allComparisons, bitcoding/BitEncoding.scala:193 */
+static __thread uint64_t g_all_comparisons __attribute__((tls_model("initial-exec")));  /* Traverser.allComparisons, reference/traverser/Traverser.scala:74 */
 uint64_t ffo_counter_bit_comparisons(void) { return g_bit_comparisons; }
 uint64_t ffo_counter_all_comparisons(void) { return g_all_comparisons; }
 void ffo_counters_reset(void) { g_bit_comparisons = g_all_comparisons = 0; }
