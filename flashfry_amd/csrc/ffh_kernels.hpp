@@ -425,12 +425,13 @@ __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint
     auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
         bool h = p <= max_mm;
         if (CHECK) h = h && valid && idx < n;  // the sentinels are not safe for max_mm >= 12
-        if (!__builtin_amdgcn_ballot_w64(h)) return;
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(h);
+        if (!m1) return;
         // suffix items keep a pair only if its prefix part has more than r1 mismatches; prefix items run the same three
         // instructions with pm = 0, r1s = -1 (always true) instead of a branch that would park the predicate in a VGPR
-        h = h && (int)__popc(y & w.pm) > w.r1s;
-        const uint64_t m = __builtin_amdgcn_ballot_w64(h);
-        if (m) w.hs->push(m, h, w.gid_lds, idx, (pos0 + tl) | w.side_bit);
+        const bool far = (int)__popc(y & w.pm) > w.r1s;
+        const uint64_t m = m1 & __builtin_amdgcn_ballot_w64(far);  // the two lane masks meet on the scalar side
+        if (m) w.hs->push(m, h && far, w.gid_lds, idx, (pos0 + tl) | w.side_bit);
     };
     // four candidates per step; ONE vector compare and ONE scalar branch decide whether any of the 256 pairs is within
     // max_mm (the scalar unit is shared by the CU's four SIMDs: mask algebra per pair would make it the bottleneck)
