@@ -472,13 +472,16 @@ def test_device_resident_exchange_entry_points(capi, oracle):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("on_caller_stream", [False, True])
+@pytest.mark.parametrize("on_caller_stream", [False, "default", "side"])
 def test_one_pass_shard_finalize_equals_the_two_pass_exchange(capi, oracle, on_caller_stream):
     """ffh_finalize_shard / ffh_exchange_prior / ffh_finalize_shard_fixup (one aggregation pass per shard; only the guides whose
     cut-off the earlier shards move are aggregated again) against ffh_shard_totals + ffh_finalize(prior): three shards on the one
     GPU, a maximumOffTargets small enough that the limit is reached in the first, the second, the third shard or never"""
+    import contextlib
     import torch
     odb, t, p, g = dense_case(oracle, seed=21)
+    side = torch.cuda.Stream() if on_caller_stream == "side" else None   # a stream of the caller's other than the default one
+    scope = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
     counts = (t >> np.uint64(48)).astype(np.int64)
     cuts = [0, len(t) // 3, 2 * len(t) // 3, len(t)]
     pcuts = [int(counts[:c].sum()) for c in cuts]
@@ -495,27 +498,31 @@ def test_one_pass_shard_finalize_equals_the_two_pass_exchange(capi, oracle, on_c
                 prior_want.append(prior if prior is not None else np.zeros(n, np.uint32))
                 want.append(c.finalize(max_ot, prior_totals=prior, summaries_only=True, jost=True).summaries.copy())
                 tots.append(c.shard_totals(max_ot).astype(np.int64))
-            if on_caller_stream:
-                for c in ctxs:
-                    c.use_stream(torch.cuda.current_stream().cuda_stream)
-            summ = [torch.zeros(n * isz, dtype=torch.uint8, device=dev) for _ in ctxs]
-            totals = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in ctxs]
-            for c, sm, tt in zip(ctxs, summ, totals):
-                c.finalize_shard(max_ot, sm.data_ptr(), tt.data_ptr(), jost=True)
-            all_totals = torch.cat(totals)                                        # the all-gather
-            redone = 0
-            for r, (c, sm, tt) in enumerate(zip(ctxs, summ, totals)):
-                assert np.array_equal(tt.cpu().numpy().astype(np.int64), tots[r])
-                prior = torch.zeros(n, dtype=torch.int32, device=dev)
-                c.exchange_prior(all_totals.data_ptr(), n, r, max_ot, prior.data_ptr())
-                assert np.array_equal(prior.cpu().numpy().astype(np.uint32), prior_want[r])
-                before = sm.cpu().numpy().tobytes()
-                c.finalize_shard_fixup(max_ot, prior.data_ptr(), tt.data_ptr(), sm.data_ptr(), jost=True)
-                after = sm.cpu().numpy()
-                redone += before != after.tobytes()
-                got = after.view(capi.SUMMARY_DTYPE)
-                bad = [i for i in range(n) if got[i].tobytes() != want[r][i].tobytes()]
-                assert not bad, (max_ot, r, bad[:3], got[bad[0]], want[r][bad[0]])
+            with scope():
+                if on_caller_stream:
+                    for c in ctxs:
+                        c.use_stream(torch.cuda.current_stream().cuda_stream)
+                summ = [torch.zeros(n * isz, dtype=torch.uint8, device=dev) for _ in ctxs]
+                totals = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in ctxs]
+                for c, sm, tt in zip(ctxs, summ, totals):
+                    c.finalize_shard(max_ot, sm.data_ptr(), tt.data_ptr(), jost=True)
+                all_totals = torch.cat(totals)                                        # the all-gather
+                redone = 0
+                for r, (c, sm, tt) in enumerate(zip(ctxs, summ, totals)):
+                    assert np.array_equal(tt.cpu().numpy().astype(np.int64), tots[r])
+                    prior = torch.zeros(n, dtype=torch.int32, device=dev)
+                    c.exchange_prior(all_totals.data_ptr(), n, r, max_ot, prior.data_ptr())
+                    assert np.array_equal(prior.cpu().numpy().astype(np.uint32), prior_want[r])
+                    before = sm.cpu().numpy().tobytes()
+                    c.finalize_shard_fixup(max_ot, prior.data_ptr(), tt.data_ptr(), sm.data_ptr(), jost=True)
+                    after = sm.cpu().numpy()
+                    redone += before != after.tobytes()
+                    got = after.view(capi.SUMMARY_DTYPE)
+                    bad = [i for i in range(n) if got[i].tobytes() != want[r][i].tobytes()]
+                    assert not bad, (max_ot, r, bad[:3], got[bad[0]], want[r][bad[0]])
+                if on_caller_stream:
+                    for c in ctxs:
+                        c.use_stream(0, on=False)   # back on their own streams before the caller's stream goes away
             if max_ot < 2000:
                 assert redone >= 1 and want[2]["overflow"].any() and not want[2]["overflow"].all()
             else:
