@@ -188,6 +188,7 @@ struct ffh_ctx {
     // per-pass scratch
     DevBuf<uint64_t> gkey;                                  // planar guide keys of the current batch (L2-resident)
     DevBuf<uint32_t> gbucket[2], patterns[2], tstart[2], istart[2];
+    std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
     DevBuf<uint32_t> icount, ifill, tcount, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint4> tiles;
@@ -338,16 +339,22 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     const uint32_t np = (uint32_t)pat.size();
     hipStream_t st = ctx->st;
     DevBuf<uint32_t> &patterns = ctx->patterns[which], &tstart = ctx->tstart[which], &gbucket = ctx->gbucket[which], &istart = ctx->istart[which];
-    FFH_HIP(patterns.reserve(np));
-    FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+    if (ctx->patterns_key[which] != std::make_pair(width, std::min(radius, width)) || patterns.cap < np) {  // uploaded once per (width, radius)
+        FFH_HIP(patterns.reserve(np));
+        FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
+        ctx->patterns_key[which] = std::make_pair(width, std::min(radius, width));
+    }
     FFH_HIP(gbucket.reserve(ng));
     FFH_HIP(istart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->tcount.reserve((size_t)nb + 1));
     FFH_HIP(tstart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
     const uint64_t *gptr = ctx->guides.p + g0;
-    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p);
-    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p);
+    // the prefix-side launch also clears the guides' hit segments (one thread per guide anyway: saves the fill launches before k_segments)
+    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p,
+                                       ctx->seg_begin.p + g0, ctx->seg_end.p + g0);
+    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p, (uint32_t *)nullptr,
+                            (uint32_t *)nullptr);
     // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
     const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
@@ -364,10 +371,9 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
     FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
     uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
-    FFH_HIP(hipMemsetAsync(ctx->part_fill.p, 0, ((size_t)2 * ig.n_part + 2) * 4, st));
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
-    hipLaunchKernelGGL(k_guide_part_hist, dim3(1), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p);
+    hipLaunchKernelGGL(k_guide_part_hist, dim3(1), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
     hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 256)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
@@ -741,6 +747,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     ctx->max_mm = max_mm;
     ctx->tm = ffh_timings{};
     FFH_HIP(ctx->guides.reserve((size_t)n_guides + 1));
+    FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));  // cleared per batch by k_guide_keys, filled by k_segments
+    FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
     if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
     FFH_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
@@ -843,10 +851,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         while (gbits < 32 && (1ull << gbits) < std::max<uint64_t>(n_guides, 2)) ++gbits;
         ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
     }
-    FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));
-    FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
-    FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, ((size_t)n_guides + 1) * 4, st));
-    FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, ((size_t)n_guides + 1) * 4, st));
+    // seg_begin / seg_end were cleared by the prefix-side k_guide_keys of every batch
     if (ctx->n_raw)
         hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->seg_end.p);
     ctx->hit_t_ready = false;  // the target longs of the hits are gathered on demand (gather_hit_targets)

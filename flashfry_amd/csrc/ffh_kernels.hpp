@@ -89,9 +89,10 @@ __global__ void k_image_scatter(const uint64_t *__restrict__ targets, uint64_t n
 // ---------------------------------------------------------------------------------------------------------
 template <bool SUFFIX>
 __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Geometry geo, int width, uint64_t *__restrict__ gkey,
-                             uint32_t *__restrict__ gbucket) {
+                             uint32_t *__restrict__ gbucket, uint32_t *__restrict__ seg_begin /* nullable */, uint32_t *__restrict__ seg_end) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
+    if (seg_begin) { seg_begin[g] = 0u; seg_end[g] = 0u; }  // the hit segment of a guide without hits (k_segments only visits the others)
     const uint64_t pk = planar_key(guides[g], geo.c0, geo.lc);
     gkey[g] = pk;
     gbucket[g] = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
@@ -164,8 +165,9 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) 
 // over all n_guides x n_pat entries).
 // one block: LDS atomics only (100 000 device-scope atomics on 2048 counters took 47 us, this takes a few)
 __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
-                                                          uint32_t *__restrict__ ghist) {
+                                                          uint32_t *__restrict__ ghist, uint32_t *__restrict__ part_fill, uint32_t n_fill) {
     __shared__ uint32_t h[1 << kMaxPartBits];
+    for (uint32_t d = threadIdx.x; d < n_fill; d += blockDim.x) part_fill[d] = 0;  // the counters of the passes that follow (saves a fill launch)
     for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) h[d] = 0;
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < n_guides; g += blockDim.x) atomicAdd(&h[lds_slot(gbucket[g] >> low_bits)], 1u);
