@@ -412,11 +412,13 @@ struct WaveCtx {  // per-wave state shared by the chunk loops
 
 // one 64-lane step against W guides at once; `cnt` <= 64 / W targets, key_lds[koff ..], image position pos0 + ..
 // CHECK: max_mm is too large for the sentinel to be safe, test the candidate index explicitly
-template <int W, bool CHECK>
+// FULL: all 64 lanes have a target (W == 1 only): no validity mask, no substitute key
+template <int W, bool CHECK, bool FULL = false>
 __device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint32_t pos0, uint32_t cnt, uint32_t n) {
+    static_assert(!FULL || W == 1, "a full chunk is 64 targets wide");
     constexpr uint32_t SUB = 64 / W;
     const uint32_t tl = w.lane & (SUB - 1), gs = w.lane / SUB;
-    const bool valid = tl < cnt;
+    const bool valid = FULL ? true : tl < cnt;
     // lanes without a target carry the all-ones key: it differs from every candidate (real or sentinel) in >= 12 bits
     const uint64_t k = valid ? w.key_lds[koff + tl] : ~0ull;
     const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
@@ -581,10 +583,18 @@ __global__ __launch_bounds__(kCmpThreads, 7) void k_compare(const uint4 *__restr
                 const uint32_t n = min(ng - g0, 64u);
                 for (uint32_t c = 0; c < kcnt; c += 64) {
                     const uint32_t cnt = min(kcnt - c, 64u);
-                    if (cnt > 32) scan_chunk<1, CHECK>(w, c, cur.x + c, cnt, n);
-                    else if (cnt > 16) scan_chunk<2, CHECK>(w, c, cur.x + c, cnt, n);
-                    else if (cnt > 8) scan_chunk<4, CHECK>(w, c, cur.x + c, cnt, n);
-                    else scan_chunk<8, CHECK>(w, c, cur.x + c, cnt, n);
+                    if (cnt == 64) {
+                        scan_chunk<1, CHECK, true>(w, c, cur.x + c, cnt, n);
+                    } else {
+                        // the tail of a bucket: the candidate count goes through an opaque register so that the trip counts of the
+                        // four packings are worked out here, for the one that runs, and not hoisted in front of every item's chunk loop
+                        uint32_t nt = n;
+                        asm volatile("" : "+s"(nt));
+                        if (cnt > 32) scan_chunk<1, CHECK>(w, c, cur.x + c, cnt, nt);
+                        else if (cnt > 16) scan_chunk<2, CHECK>(w, c, cur.x + c, cnt, nt);
+                        else if (cnt > 8) scan_chunk<4, CHECK>(w, c, cur.x + c, cnt, nt);
+                        else scan_chunk<8, CHECK>(w, c, cur.x + c, cnt, nt);
+                    }
                 }
             }
             t += n_waves;
