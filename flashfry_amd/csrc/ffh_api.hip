@@ -169,7 +169,9 @@ struct ffh_ctx {
     ffh_load_stats load{};
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
-    unsigned compare_grid = 256 * 8 * 8;
+    // 6.5 rounds of the 2048 blocks that fit the device at once: every block start exposes the pipeline's three HBM round trips (65 536
+    // blocks: 3.4 ms instead of 1.9), too few rounds leave the end of the launch unbalanced (4096: 2.08 ms); 12-14k measured best
+    unsigned compare_grid = 256 * 52;
     bool scan_timing_pending = false, finalize_timing_pending = false, hit_t_ready = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
