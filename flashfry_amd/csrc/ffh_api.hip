@@ -379,7 +379,7 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
     hipLaunchKernelGGL(k_guide_part_hist, dim3(1), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
-    hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 256)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+    hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
     hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p);

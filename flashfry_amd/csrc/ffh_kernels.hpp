@@ -174,12 +174,16 @@ __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__rest
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) ghist[d] = h[lds_slot(d)];
 }
-__global__ void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t *__restrict__ part_count) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per partition, the lanes stride over the patterns (a thread per partition left 4096 threads walking 529 patterns each: 36 us)
+__global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig,
+                                                    uint32_t *__restrict__ part_count) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= ig.n_part) return;
     uint32_t n = 0;
-    for (uint32_t p = 0; p < ig.n_pat; ++p) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
-    part_count[q] = n;
+    for (uint32_t p = lane; p < ig.n_pat; p += 64) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if (lane == 0) part_count[q] = n;
 }
 
 template <bool WRITE>
