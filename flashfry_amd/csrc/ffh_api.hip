@@ -354,12 +354,6 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     FFH_HIP(ctx->tcount.reserve((size_t)nb + 1));
     FFH_HIP(tstart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
-    const uint64_t *gptr = ctx->guides.p + g0;
-    // the prefix-side launch also clears the guides' hit segments (one thread per guide anyway: saves the fill launches before k_segments)
-    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p,
-                                       ctx->seg_begin.p + g0, ctx->seg_end.p + g0);
-    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p, (uint32_t *)nullptr,
-                            (uint32_t *)nullptr);
     // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
     const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
@@ -372,13 +366,20 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     ig.n_part = 1u << part_bits;
     ig.item_base = item_base;
     ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
+    FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
+    const uint64_t *gptr = ctx->guides.p + g0;
+    // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
+    // saves the fill launches before k_guide_part_hist and k_segments)
+    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p,
+                                       ctx->seg_begin.p + g0, ctx->seg_end.p + g0, ctx->part_hist.p, ig.n_part);
+    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p, (uint32_t *)nullptr,
+                            (uint32_t *)nullptr, ctx->part_hist.p, ig.n_part);
     FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
     FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
     FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
     uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
-    FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
-    hipLaunchKernelGGL(k_guide_part_hist, dim3(1), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
+    hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
     hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);

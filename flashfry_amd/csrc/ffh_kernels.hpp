@@ -89,8 +89,10 @@ __global__ void k_image_scatter(const uint64_t *__restrict__ targets, uint64_t n
 // ---------------------------------------------------------------------------------------------------------
 template <bool SUFFIX>
 __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Geometry geo, int width, uint64_t *__restrict__ gkey,
-                             uint32_t *__restrict__ gbucket, uint32_t *__restrict__ seg_begin /* nullable */, uint32_t *__restrict__ seg_end) {
+                             uint32_t *__restrict__ gbucket, uint32_t *__restrict__ seg_begin /* nullable */, uint32_t *__restrict__ seg_end,
+                             uint32_t *__restrict__ zero_buf, uint32_t n_zero) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t d = g; d < n_zero; d += gridDim.x * blockDim.x) zero_buf[d] = 0u;  // the partition histogram k_guide_part_hist adds into
     if (g >= n) return;
     if (seg_begin) { seg_begin[g] = 0u; seg_end[g] = 0u; }  // the hit segment of a guide without hits (k_segments only visits the others)
     const uint64_t pk = planar_key(guides[g], geo.c0, geo.lc);
@@ -163,16 +165,24 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) 
 // entries whose high bits equal q is  sum over patterns p of  #guides whose high bits equal q ^ high(p)  -- an XOR
 // convolution of the guides' partition histogram with the patterns' (<= 4096 x n_pat additions instead of one pass
 // over all n_guides x n_pat entries).
-// one block: LDS atomics only (100 000 device-scope atomics on 2048 counters took 47 us, this takes a few)
+// a few blocks, each with an LDS histogram of its slice of the guides, merged with one global atomic per non-empty counter (100 000
+// device-scope atomics on 2048 counters took 47 us; one block walking all guides took 30 us; eight blocks take a few).  ghist was
+// cleared by k_guide_keys.
+constexpr int kPartHistBlocks = 8;
 __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
                                                           uint32_t *__restrict__ ghist, uint32_t *__restrict__ part_fill, uint32_t n_fill) {
     __shared__ uint32_t h[1 << kMaxPartBits];
-    for (uint32_t d = threadIdx.x; d < n_fill; d += blockDim.x) part_fill[d] = 0;  // the counters of the passes that follow (saves a fill launch)
+    if (blockIdx.x == 0)
+        for (uint32_t d = threadIdx.x; d < n_fill; d += blockDim.x) part_fill[d] = 0;  // the counters of the passes that follow (saves a fill launch)
     for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) h[d] = 0;
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < n_guides; g += blockDim.x) atomicAdd(&h[lds_slot(gbucket[g] >> low_bits)], 1u);
+    const uint32_t per = (n_guides + gridDim.x - 1) / gridDim.x, g_end = min(n_guides, (blockIdx.x + 1) * per);
+    for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) atomicAdd(&h[lds_slot(gbucket[g] >> low_bits)], 1u);
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) ghist[d] = h[lds_slot(d)];
+    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) {
+        const uint32_t c = h[lds_slot(d)];
+        if (c) atomicAdd(&ghist[d], c);
+    }
 }
 // one wave per partition, the lanes stride over the patterns (a thread per partition left 4096 threads walking 529 patterns each: 36 us)
 __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig,
