@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
 // One block per partition.  The partition's candidate ids are put in bucket order inside LDS and leave as one
 // contiguous, coalesced copy: scattering 4-byte stores straight to memory costs a partial-line write-back each once the
 // concurrently open output windows exceed the L2 (1.1 ms for the 5.3e7 entries of the hg38-scale prefix image).
-__global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
+__global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
                                                            uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid) {
     __shared__ uint32_t cnt[1 << kMaxLowBits];
     __shared__ uint32_t stage[kBinStage];
@@ -243,6 +243,46 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
     __syncthreads();
     const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
     const uint32_t *__restrict__ src = part_items + p0;
+    const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
+    const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
+    // exclusive scan of the nlow counters (every thread owns nlow / 1024 consecutive ones, at most 4): CSR offsets out, counters
+    // become scatter cursors
+    auto scan_counters = [&]() {
+        uint32_t mine = 0;
+        for (uint32_t k = 0; k < per; ++k)
+            if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
+        uint32_t tot;
+        uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
+        for (uint32_t k = 0; k < per; ++k)
+            if (l0 + k < nlow) {
+                const uint32_t c = cnt[lds_slot(l0 + k)];
+                istart[((uint64_t)d << ig.low_bits) + l0 + k] = gbase + off;
+                cnt[lds_slot(l0 + k)] = off;
+                off += c;
+            }
+        if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+    };
+    if (n <= (uint32_t)kBinStage) {
+        // the usual case: the whole partition sits in registers (14 records per thread, all loads in flight at once), is counted and
+        // placed from there -- one read of the records instead of two, one memory round trip instead of eight
+        constexpr int kR = kBinStage / kPartThreads;
+        static_assert(kR * kPartThreads == kBinStage, "kBinStage is a multiple of the block size");
+        uint32_t r[kR];
+#pragma unroll
+        for (int u = 0; u < kR; ++u) { const uint32_t k = u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < kR; ++u) if ((uint32_t)(u * kPartThreads) + threadIdx.x < n) atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
+        __syncthreads();
+        scan_counters();
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kR; ++u)
+            if ((uint32_t)(u * kPartThreads) + threadIdx.x < n) stage[atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u)] = r[u] & ((1u << kGidBits) - 1u);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) item_gid[gbase + k] = stage[k];
+        return;
+    }
+    // oversized partition (skewed guide sets): two passes over the records, scattered stores
     constexpr int kU = 4;  // records in flight per thread
     for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
         uint32_t r[kU];
@@ -252,40 +292,16 @@ __global__ __launch_bounds__(kPartThreads) void k_item_bin(const uint32_t *__res
         for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
     }
     __syncthreads();
-    // exclusive scan of the nlow counters: every thread owns nlow / 1024 consecutive ones (at most 2)
-    const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
-    uint32_t mine = 0;
-    for (uint32_t k = 0; k < per; ++k)
-        if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
-    uint32_t tot;
-    uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
-    const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
-    for (uint32_t k = 0; k < per; ++k)
-        if (l0 + k < nlow) {
-            const uint32_t c = cnt[lds_slot(l0 + k)];
-            istart[((uint64_t)d << ig.low_bits) + l0 + k] = gbase + off;
-            cnt[lds_slot(l0 + k)] = off;  // becomes the scatter cursor
-            off += c;
-        }
-    if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+    scan_counters();
     __syncthreads();
-    const bool staged = n <= (uint32_t)kBinStage;
     for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
         uint32_t r[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
-            if (k0 + u * kPartThreads + threadIdx.x < n) {
-                const uint32_t pos = atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
-                const uint32_t gid = r[u] & ((1u << kGidBits) - 1u);
-                if (staged) stage[pos] = gid;
-                else item_gid[gbase + pos] = gid;
-            }
+            if (k0 + u * kPartThreads + threadIdx.x < n) item_gid[gbase + atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u)] = r[u] & ((1u << kGidBits) - 1u);
     }
-    if (!staged) return;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) item_gid[gbase + k] = stage[k];
 }
 
 constexpr int kTileTargets = 256;  // targets per work item (a bucket, or a 256-target slice of a large bucket)
