@@ -208,18 +208,31 @@ class Result:
     def __init__(self, L, h, lists=True):
         own = _ResultOwner(L, h)
         n = L.ffh_result_n_guides(h)
-        H = L.ffh_result_n_hits(h)
-        P = L.ffh_result_n_positions(h)
-        self.n_guides, self.n_hits, self.n_positions = n, H, P
+        self._L, self._own, self.n_guides = L, own, n
         self.scores_valid = bool(L.ffh_result_scores_valid(h))
         self.summaries = _view(own, L.ffh_result_summaries(h), n, SUMMARY_DTYPE)
-        self.guide_offsets = _view(own, L.ffh_result_guide_offsets(h), n + 1, np.uint64)
+        if lists:
+            H = L.ffh_result_n_hits(h)
+            P = L.ffh_result_n_positions(h)
+            self.n_hits, self.n_positions = H, P
+            self.guide_offsets = _view(own, L.ffh_result_guide_offsets(h), n + 1, np.uint64)
+        else:
+            self.n_positions = 0  # n_hits / guide_offsets of an aggregates-only result are folded from the summaries on first use
         if lists:
             self.hit_targets = _view(own, L.ffh_result_hit_targets(h), H, np.uint64)
             self.hit_mismatches = _view(own, L.ffh_result_hit_mismatches(h), H, np.uint8)
             self.hit_cfd = _view(own, L.ffh_result_hit_cfd(h), H, np.float64)
             self.pos_offsets = _view(own, L.ffh_result_pos_offsets(h), H + 1, np.uint64)
             self.positions = _view(own, L.ffh_result_positions(h), P, np.uint64)
+
+    def __getattr__(self, name):  # only reached for attributes not set yet: the lazy pair of an aggregates-only result
+        if name == "n_hits":
+            self.n_hits = self._L.ffh_result_n_hits(self._own.h)
+            return self.n_hits
+        if name == "guide_offsets":
+            self.guide_offsets = _view(self._own, self._L.ffh_result_guide_offsets(self._own.h), self.n_guides + 1, np.uint64)
+            return self.guide_offsets
+        raise AttributeError(name)
 
     def hits(self, g):
         a, b = int(self.guide_offsets[g]), int(self.guide_offsets[g + 1])

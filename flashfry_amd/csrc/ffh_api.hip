@@ -116,6 +116,7 @@ struct PinnedPool {
 struct ffh_result {
     uint32_t n_guides = 0;
     uint64_t n_hits = 0, n_positions = 0;
+    bool offsets_pending = false;  // aggregates-only result: guide_offsets / n_hits are folded from the summaries when first asked for
     int scores_valid = 0;
     // all arrays live in one pinned block owned by the context's pool
     std::shared_ptr<PinnedPool> pool;
@@ -972,14 +973,14 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
                                   ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr);
-        exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
+        // no scan of the per-guide hit counts and no copy of the offsets: nobody needs them to read the aggregates, and whoever
+        // asks (ffh_result_guide_offsets / ffh_result_n_hits) gets them folded from the summaries' n_hits on the host
         hipError_t e = hipEventRecord(ctx->ev[1], st);
         if (e == hipSuccess) e = hipGetLastError();
         if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
-        r->n_hits = r->guide_offsets[G];
+        r->offsets_pending = true;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
         ctx->tm.finalize_ms = ms;
@@ -1122,11 +1123,20 @@ int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out) {
 }
 
 uint32_t ffh_result_n_guides(const ffh_result *r) { return r->n_guides; }
-uint64_t ffh_result_n_hits(const ffh_result *r) { return r->n_hits; }
+static void settle_offsets(const ffh_result *cr) {
+    ffh_result *r = const_cast<ffh_result *>(cr);
+    if (!r->offsets_pending) return;
+    r->offsets_pending = false;
+    uint64_t run = 0;
+    for (uint32_t g = 0; g < r->n_guides; ++g) { r->guide_offsets[g] = run; run += r->summaries[g].n_hits; }
+    r->guide_offsets[r->n_guides] = run;
+    r->n_hits = run;
+}
+uint64_t ffh_result_n_hits(const ffh_result *r) { settle_offsets(r); return r->n_hits; }
 uint64_t ffh_result_n_positions(const ffh_result *r) { return r->n_positions; }
 int ffh_result_scores_valid(const ffh_result *r) { return r->scores_valid; }
 const ffh_guide_summary *ffh_result_summaries(const ffh_result *r) { return r->summaries; }
-const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { return r->guide_offsets; }
+const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { settle_offsets(r); return r->guide_offsets; }
 const uint64_t *ffh_result_hit_targets(const ffh_result *r) { return r->hit_targets; }
 const uint8_t *ffh_result_hit_mismatches(const ffh_result *r) { return r->hit_mm; }
 const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd; }
