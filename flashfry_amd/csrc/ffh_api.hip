@@ -757,7 +757,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));  // cleared per batch by k_guide_keys, filled by k_segments
     FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
     if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
-    FFH_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
 
     ctx->tbits = 1;
@@ -785,7 +784,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
             FlushArgs fa;
             fa.hits = ctx->hits.p; fa.cap = (uint64_t)ctx->hits.cap; fa.tidx_p = ctx->img[0].tidx.p; fa.tidx_s = ctx->img[1].tidx.p;
             fa.guide_base = g0; fa.tbits = ctx->tbits;
-            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, fa);
+            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, fa, g0 == 0 ? 1 : 0);
         }
         const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
         if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }

@@ -380,7 +380,8 @@ struct CompareArgs {
 };
 
 // before every compare launch: clears the per-launch pair counters and stores the launch's FlushArgs (one launch in place of a memset)
-__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, FlushArgs f) {
+__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, FlushArgs f, int first_batch) {
+    if (first_batch && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // hit cursor and the zero word: once per scan, they run across batches
     if (threadIdx.x < 2 * kPairSlots) cursor[kPairSlotBase + threadIdx.x] = 0ull;
     if (threadIdx.x == 0) *reinterpret_cast<FlushArgs *>(cursor + kFlushArgBase) = f;
 }
