@@ -63,7 +63,7 @@ def measure_traffic(args):
                sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic",
                "--targets", str(args.targets), "--guides", str(args.guides), "--max-mismatch", str(args.max_mismatch), "--max-offtargets", str(args.max_offtargets)]
         env = dict(os.environ, TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=900)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=300)  # a pass takes ~40 s; a hung profiler must not hold the bench
         path = os.path.join(d, "pmc_counter_collection.csv")
         if r.returncode != 0 or not os.path.exists(path):
             return None
