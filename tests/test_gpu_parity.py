@@ -217,6 +217,20 @@ def test_guide_batches(capi, oracle, monkeypatch):
         assert_same_scores(oracle, 3, g, gpu, ora)
 
 
+def test_compare_grid_sizes(capi, oracle, monkeypatch):
+    """the work items are dealt to the waves of the compare launch round-robin; the result must not depend on how many there are
+    (one block: every wave walks thousands of items through the software pipeline; far more waves than items: most leave at once)"""
+    odb, t, p, g = dense_case(oracle, seed=10)
+    ora = odb.discover(g, 4, 60)
+    for grid in ("1", "3", "64", "100000"):
+        monkeypatch.setenv("FFH_COMPARE_GRID", grid)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            gpu = ctx.discover(g, 4, 60)
+        assert_same_hits(gpu, ora)
+        assert_same_scores(oracle, 3, g, gpu, ora)
+
+
 def test_edge_cases(capi, oracle):
     odb, t, p, g = make_case(oracle, 5000, 50, enzyme=3, seed=2)
     with capi.Context(3) as ctx:
