@@ -351,7 +351,10 @@ __global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t 
 //   <= r1 mismatches, so it is emitted from a suffix item only if the prefix part has MORE than r1.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCmpThreads = 256;
-constexpr int kStage = 192;  // staged hits per wave
+// staged hits per wave.  Every flush is one atomic on the one global hit cursor, and same-address atomics complete at ~88 per
+// microsecond on this part: at 5 mismatches (1.1e8 hits) the launch time WAS the flush count (11.6 ms with 192 entries, 7.8 ms with
+// 280).  280 is what still lets eight blocks share a CU's 160 KB of LDS (4 x 280 x 8 B + 11 KB of keys per block).
+constexpr int kStage = 280;
 
 constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
 constexpr uint32_t kTileStatBase = 13;  // cursor[13], cursor[14]: work items of the prefix / suffix image in this launch
