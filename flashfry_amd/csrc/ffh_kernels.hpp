@@ -353,8 +353,10 @@ __global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t 
 constexpr int kCmpThreads = 256;
 // staged hits per wave.  Every flush is one atomic on the one global hit cursor, and same-address atomics complete at ~88 per
 // microsecond on this part: at 5 mismatches (1.1e8 hits) the launch time WAS the flush count (11.6 ms with 192 entries, 7.8 ms with
-// 280).  280 is what still lets eight blocks share a CU's 160 KB of LDS (4 x 280 x 8 B + 11 KB of keys per block).
-constexpr int kStage = 280;
+// 280, 7.6 ms with 360).  360 entries leave room for seven blocks per CU (4 x 360 x 8 B + 11 KB of keys each, 160 KB of LDS);
+// same-box sweep at 4 / 5 mismatches: 192 -> 1.90 / 11.6 ms, 280 (eight blocks) -> 1.87 / 7.9, 360 -> 1.86 / 7.6, 480 (six blocks)
+// -> 1.98 / 8.0, 640 (five) -> 2.19 / 8.8.
+constexpr int kStage = 360;
 
 constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
 constexpr uint32_t kTileStatBase = 13;  // cursor[13], cursor[14]: work items of the prefix / suffix image in this launch
