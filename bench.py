@@ -10,9 +10,14 @@ as db_prepare_ms).  Inputs are synthetic and seeded (flashfry_amd/synth.py) -- t
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: every rank owns its own database shard of the same size (weak scaling: a genome N times larger, bins sharded
-statically); the only exchange is the per-guide totals all-gather (ordered cut-off across shards) and
-the per-guide aggregate all-reduce over RCCL.
+N > 1, --scaling strong (default, BASELINE.json configs[3]): ONE hg38-sized database, its 16384 bins split statically and
+contiguously over the ranks (balanced by targets per bin, the synthetic stand-in of BinaryHeader's uncompressedSize); --scaling weak:
+every rank owns its own hg38-sized shard (a genome N times larger).  Either way the only exchange is the per-guide totals
+all-gather (ordered cut-off across shards) and the per-guide aggregate reduction over RCCL.
+
+After the timed loop the bench verifies its own step (N = 1): the aggregates-only summaries must equal those of one list-delivering
+ffh_discover, whose hit lists are checked against an independent brute-force torch scan for sampled guides ("verified": true), and
+that complete discover (hit lists + positions on the host) is timed beside the step ("discover_with_lists_ms").
 """
 import argparse
 import json
@@ -38,6 +43,9 @@ def parse():
     ap.add_argument("--max-offtargets", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--workload", default="hg38-scale")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: split one hg38-sized database (strong) or give every rank its own (weak)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the self-verification and the list-delivering discover after the timed loop")
+    ap.add_argument("--no-skewed", action="store_true", help="skip the second workload (repeat-structured genome, guides sampled from it)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure the compare kernel's HBM traffic")
     ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"), help="where the PMC passes write their CSVs")
     return ap.parse_args()
@@ -55,33 +63,46 @@ def measure_traffic(args):
     if not os.path.exists(prof):
         return None
     out = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(args.traffic_dir, counter)
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+              "SQ": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]}
+    for tag, counters in passes.items():
+        d = os.path.join(args.traffic_dir, tag)
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d, exist_ok=True)
-        cmd = [prof, "--kernel-trace", "--pmc", counter, "--kernel-include-regex", "k_compare<|k_image_hist", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic",
+        cmd = [prof, "--kernel-trace", "--pmc"] + counters + ["--kernel-include-regex", "k_compare<|k_image_hist", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic", "--no-verify", "--no-skewed",
                "--targets", str(args.targets), "--guides", str(args.guides), "--max-mismatch", str(args.max_mismatch), "--max-offtargets", str(args.max_offtargets)]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=300)  # a pass takes ~40 s; a hung profiler must not hold the bench
         path = os.path.join(d, "pmc_counter_collection.csv")
         if r.returncode != 0 or not os.path.exists(path):
+            if tag == "SQ":
+                continue  # the instruction counters are an extra; the traffic figure stands without them
             return None
-        vals = {}
-        for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] == counter:
-                vals.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
-        out[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
+        for counter in counters:
+            vals = {}
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] == counter:
+                    vals.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+            out[counter] = {k: sum(v) / len(v) for k, v in vals.items()}
     try:
         cmp_fetch = [v for k, v in out["FETCH_SIZE"].items() if "k_compare" in k][0]
         cmp_write = [v for k, v in out["WRITE_SIZE"].items() if "k_compare" in k][0]
         cal = [v for k, v in out["FETCH_SIZE"].items() if "k_image_hist" in k][0]
     except (IndexError, KeyError):
         return None
-    return {"fetch_kib": cmp_fetch, "write_kib": cmp_write, "calibration_fetch_kib": cal}
+    res = {"fetch_kib": cmp_fetch, "write_kib": cmp_write, "calibration_fetch_kib": cal}
+    for counter in passes["SQ"]:
+        v = [v for k, v in out.get(counter, {}).items() if "k_compare" in k]
+        if v:
+            res[counter] = v[0]
+    return res
 
 
 _CPU_MT = None
+_CPU_JVM = None
+VALU_CYCLES = 4.0      # cycles an integer wave64 VALU instruction occupies its SIMD (tools/ubench/valu_ubench.hip)
+PAIR_TEST_VALU = 3.75  # v_xor + v_bitop3 + v_bcnt per pair row, + 3 v_min3 per 8 rows... and one v_cmp per 8 (the ubench loop)
 
 
 def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single_rate, filt, per_bin):
@@ -130,8 +151,14 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
     `nbins` of the 16384 database bins, all guides"""
     import torch
     from tests import oracle_lib
-    from flashfry_amd import synth
+    from flashfry_amd import capi, synth
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_legs
     oracle = oracle_lib.load()
+    # the single-thread leg runs pinned to one core, like the reference's own timing harness (`taskset -c 0`,
+    # paper/tools/flashfry_off_target.cwl:16-22); its peak RSS is reported as paper/run_timing_collection.py:17-24 does
+    core, unpin = bench_legs.pin_to_core()
+    sample_arrays = {}
 
     def build(nbins):
         limit = nbins << 32  # 7-base bin = bits [45:32] of a Cas9 23-mer
@@ -139,6 +166,7 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
         idx = int(torch.searchsorted(seq, torch.tensor([limit], device=seq.device, dtype=seq.dtype))[0])
         t = targets_dev[:idx].cpu().numpy().view(np.uint64)
         p = positions_dev[:int(pos_off_dev[idx])].cpu().numpy().view(np.uint64)
+        sample_arrays["t"], sample_arrays["p"] = t, p
         odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
         odb.sample_targets = idx
         return odb
@@ -174,8 +202,16 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
         per_bin = max(dt - filt, 1e-4) / nb
     full_run = filt + per_bin * n_bins
     single = G * (idx / nb) * n_bins / full_run
-    global _CPU_MT
+    rss = bench_legs.max_rss_kib()
+    unpin()
+    global _CPU_MT, _CPU_JVM
     _CPU_MT = None
+    _CPU_JVM = None
+    try:  # the real reference, when the box has a JVM and the jar; skipped cleanly otherwise
+        _CPU_JVM = bench_legs.jvm_leg(capi, sample_arrays["t"], sample_arrays["p"], synth.CONTIGS_24, guides_np, max_mm, max_ot,
+                                      "the first %d of %d bins of the synthetic database" % (nb, n_bins))
+    except Exception as e:
+        _CPU_JVM = {"value": None, "unit": "guide*target comparisons/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
     try:  # SURVEY.md section 8d also asks for the port on all host cores (bins are independent: one thread per bin range)
         _CPU_MT = cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single, filt, per_bin)
     except Exception as e:
@@ -186,7 +222,93 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
                       "database); value = the rate of a full run, targets per bin / (scan seconds per bin + filter seconds / %d)"
                       % (G, nb, n_bins, idx, dt, filt, n_bins, n_bins),
             "seconds": spent, "filter_seconds": filt, "scan_seconds_per_bin": per_bin, "projected_full_run_seconds": full_run,
-            "sample_only_rate": G * idx / dt, "executed_comparisons": int(res.all_comparisons), "sample_targets": idx}
+            "sample_only_rate": G * idx / dt, "executed_comparisons": int(res.all_comparisons), "sample_targets": idx,
+            "pinned_to_core": core, "max_rss_kib": rss}
+
+
+def torch_mismatches(torch, guide, targets):
+    """BitEncoding.mismatches (bitcoding/BitEncoding.scala:127-132) with torch integer ops over the whole database: an independent
+    restatement (no planar keys, no buckets) used to check the step's hit lists"""
+    x = (targets ^ guide) & 0x3FFFFFFFFFC0           # comparisonBitEncoding of spCas9-NGG, StandardScanParameters.scala:143
+    y = (x | (x << 1)) & 0xAAAAAAAAAAAA              # BitEncoding.scala:205
+    y = y - ((y >> 1) & 0x5555555555555555)
+    y = (y & 0x3333333333333333) + ((y >> 2) & 0x3333333333333333)
+    y = (y + (y >> 4)) & 0x0F0F0F0F0F0F0F0F
+    return (y * 0x0101010101010101) >> 56 & 0x7F
+
+
+def verify_step(torch, ctx, db, guides_np, step_result, args):
+    """The timed step only brings the per-guide aggregates to the host.  Here the same call is made once more with the hit lists and
+    positions delivered (timed: that is the complete `discover` product), its summaries must be the step's bit for bit, and for a
+    sample of guides the delivered hit list must be exactly what a brute-force scan of all targets + the ordered cut-off
+    (CRISPRSiteOT.scala:39-46) gives.  Raises on any difference."""
+    G = len(guides_np)
+    times = []
+    full = None
+    for _ in range(3):
+        full = None  # the previous result goes back to the page-locked pool first
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = ctx.discover(guides_np, args.max_mismatch, args.max_offtargets)
+        times.append((time.perf_counter() - t0) * 1e3)
+    if full.summaries.tobytes() != step_result.summaries.tobytes():
+        raise SystemExit("bench verification failed: aggregates-only summaries differ from the list-delivering discover")
+    sample = sorted(set(list(range(0, G, max(1, G // 12)))[:12] + [1, G // 3 + 1, G - 1]))
+    cnt_all = (db["targets"] >> 48) & 0xFFFF
+    for g in sample:
+        mm = torch_mismatches(torch, int(guides_np[g].astype(np.int64)), db["targets"])
+        idx = torch.nonzero(mm <= args.max_mismatch).flatten()
+        c = cnt_all[idx]
+        before = torch.cumsum(c, 0) - c
+        keep = idx[before < args.max_offtargets]                      # kept while the running total before the hit is below the limit
+        want = db["targets"][keep].cpu().numpy().view(np.uint64)
+        got = full.hits(g)
+        if not np.array_equal(got, want):
+            raise SystemExit("bench verification failed: hit list of guide %d differs from the brute-force scan" % g)
+        a = int(full.guide_offsets[g])
+        if len(keep):
+            po = full.pos_offsets[a:a + len(keep) + 1]
+            k = len(keep) - 1
+            src = int(db["pos_offsets"][keep[k]])
+            n = int(po[k + 1] - po[k])
+            if not np.array_equal(full.positions[int(po[k]):int(po[k + 1])], db["positions"][src:src + n].cpu().numpy().view(np.uint64)):
+                raise SystemExit("bench verification failed: positions of guide %d differ" % g)
+    note = ("summaries of the timed aggregates-only step == summaries of a list-delivering ffh_discover (bytes); hit lists and positions of %d "
+            "sampled guides == brute-force torch scan of all targets + ordered cut-off" % len(sample))
+    return True, float(np.median(times)), note
+
+
+def skewed_workload(torch, capi, synth, ctx_uniform, dev, local, args):
+    """The second workload: the same sizes on a repeat-structured genome (synth.make_repeat_database) with the guides sampled from the
+    genome by position, so that repeat families get their share of guides -- the heavy-tailed case real hg38 is, next to the uniform
+    one.  Reported beside the headline, never instead of it."""
+    T_req, G = int(args.targets), args.guides
+    db = synth.make_repeat_database(T_req, seed=synth.DB_SEED + 99, device=dev)
+    guides = synth.make_guides_from_database(db, G, device=dev).cpu().numpy().view(np.uint64)
+    T, P = db["T"], db["P"]
+    cnt = (db["targets"] >> 48) & 0xFFFF
+    stats = {"targets": T, "positions": P, "max_count": int(cnt.max()), "targets_with_count_ge_100": int((cnt >= 100).sum())}
+    with capi.Context(3, device=local) as ctx:
+        torch.cuda.synchronize()
+        ctx.load_soa_device(db["targets"].data_ptr(), T, db["positions"].data_ptr(), P)
+        del db, cnt
+        torch.cuda.empty_cache()
+        res = ctx.discover(guides, args.max_mismatch, args.max_offtargets, summaries_only=True)   # warm-up (buffers grow here)
+        times, tms = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = ctx.discover(guides, args.max_mismatch, args.max_offtargets, summaries_only=True)
+            times.append((time.perf_counter() - t0) * 1e3)
+            tms.append(ctx.timings().as_dict())
+        s = res.summaries
+        out = {"workload": "hg38-skewed: %d guides sampled by position from a repeat-structured genome of %d distinct targets (%d positions), <=%d mismatches, "
+                           "maximumOffTargets %d" % (len(guides), T, P, args.max_mismatch, args.max_offtargets),
+               "ms_per_step": float(np.median(times)), "value": len(guides) * T / (float(np.median(times)) * 1e-3), "unit": "comparisons/s",
+               "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
+               "raw_hits": int(tms[-1]["n_raw_hits"]), "raw_hits_per_guide": tms[-1]["n_raw_hits"] / max(len(guides), 1),
+               "overflowed_guides": int(s["overflow"].sum()), "kept_hits": int(s["n_hits"].sum()), "genome": stats}
+    return out
 
 
 def main():
@@ -221,7 +343,24 @@ def main():
     T_req, G = int(args.targets), args.guides
     # ---- synthetic inputs, generated on the device (same generator as the tests) ----
     guides_dev = synth.make_guides(G, device=dev)
-    db = synth.make_database(T_req, seed=synth.DB_SEED + rank, plant_guides=guides_dev, device=dev)
+    strong = world > 1 and args.scaling == "strong"
+    db = synth.make_database(T_req, seed=synth.DB_SEED + (0 if strong else rank), plant_guides=guides_dev, device=dev)
+    T_db = db["T"]
+    if strong:
+        # config C4: the SAME database, its 16384 bins (7-base prefix, bits 45:32 of a Cas9 23-mer) split contiguously over the ranks,
+        # balanced by the bins' payload (targets + positions longs = BinaryHeader's uncompressedSize without the block header)
+        bins = ((db["targets"] >> 32) & 0x3FFF)
+        per_bin_t = torch.bincount(bins, minlength=16384)
+        first = torch.cumsum(per_bin_t, 0) - per_bin_t
+        bin_pos = db["pos_offsets"][torch.clamp(first + per_bin_t, max=T_db)] - db["pos_offsets"][torch.clamp(first, max=T_db)]
+        payload = ((per_bin_t + bin_pos) * 8).cpu().numpy()
+        b0, b1 = ffdist.shard_bins(payload, world)[rank]
+        lo = int(first[b0]) if b0 < 16384 else T_db
+        hi = int(first[b1]) if b1 < 16384 else T_db
+        plo, phi = int(db["pos_offsets"][lo]), int(db["pos_offsets"][hi])
+        db = {"targets": db["targets"][lo:hi].contiguous(), "positions": db["positions"][plo:phi].contiguous(),
+              "pos_offsets": (db["pos_offsets"][lo:hi + 1] - plo).contiguous(), "T": hi - lo, "P": phi - plo}
+        torch.cuda.empty_cache()
     T, P = db["T"], db["P"]
     guides_np = guides_dev.cpu().numpy().view(np.uint64)
     ctx = capi.Context(3, device=local)
@@ -235,6 +374,9 @@ def main():
             cpu = cpu_baseline(db["targets"], db["pos_offsets"], db["positions"], guides_np, args.max_mismatch, args.max_offtargets, args.cpu_seconds)
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the measurement
             cpu = {"value": None, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    verify_db = None
+    if rank == 0 and world == 1 and not args.no_verify:
+        verify_db = {"targets": db["targets"], "pos_offsets": db["pos_offsets"], "positions": db["positions"]}
     del db
     torch.cuda.empty_cache()
     pmc = None
@@ -305,6 +447,26 @@ def main():
     else:
         T_total = T
 
+    verified, lists_ms, verify_note = None, None, None
+    if verify_db is not None:
+        verified, lists_ms, verify_note = verify_step(torch, ctx, verify_db, guides_np, res, args)
+        verify_db = None
+        torch.cuda.empty_cache()
+
+    skewed, real_genome = None, None
+    if rank == 0 and world == 1:
+        if not args.no_skewed:
+            try:
+                skewed = skewed_workload(torch, capi, synth, ctx, dev, local, args)
+            except Exception as e:  # a reported extra, never a reason to lose the measurement
+                skewed = {"error": repr(e)}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_legs
+            real_genome = bench_legs.fasta_leg(capi, G, args.max_mismatch, args.max_offtargets, device=local)
+        except Exception as e:
+            real_genome = {"error": repr(e)}
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         cmp_ms = float(np.mean([t["compare_ms"] for t in tms]))
@@ -323,24 +485,45 @@ def main():
             traffic = pmc["fetch_kib"] * 1024.0 * scale + pmc["write_kib"] * 1024.0
             traffic_note = {"fetch_size_kib": pmc["fetch_kib"], "write_size_kib": pmc["write_kib"], "fetch_scale_from_calibration": scale,
                             "calibration": "ffh::k_image_hist reads 8 B per target with the same coalesced 8-byte loads; WRITE_SIZE uncalibrated"}
+        sq = {k: pmc[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if pmc and k in pmc}
+        # issue model: an integer wave64 VALU instruction occupies its SIMD for VALU_CYCLES cycles (tools/ubench/valu_ubench.hip
+        # measures it); 256 CUs x 4 SIMDs issue slots.  valu_issue_frac = all VALU instructions of the launch against that peak,
+        # useful_valu_frac = the pair tests alone (PAIR_TEST_VALU instructions per 64 pairs).
+        simd_cycles = 1024 * 2.4e9 * cmp_ms * 1e-3
+        valu_issue = sq["SQ_INSTS_VALU"] * VALU_CYCLES / simd_cycles if "SQ_INSTS_VALU" in sq else None
+        useful_valu = pairs / 64.0 * PAIR_TEST_VALU * VALU_CYCLES / simd_cycles
         out = {
-            "metric": "guide x target comparisons/s (discover, <=%d mismatches, CFD+Hsu2013 aggregate)" % args.max_mismatch,
+            "metric": "guide x target comparisons/s, effective = nominal G x T per step (discover, <=%d mismatches, CFD+Hsu2013 aggregate)" % args.max_mismatch,
             "value": G * T_total * args.steps / dt,
             "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d random NGG guides vs %d unique targets per GPU (%d positions), <=%d mismatches, maximumOffTargets %d, spCas9-NGG"
-                                   % (args.workload, G, T, P, args.max_mismatch, args.max_offtargets),
+            "config": {"workload": "%s: %d random NGG guides vs %d unique targets %s (%d positions on this rank), <=%d mismatches, maximumOffTargets %d, spCas9-NGG; "
+                                   "N > 1 is %s" % (args.workload, G, T_total if strong else T, "in ONE database split by bins over the ranks" if strong else "per GPU", P,
+                                                    args.max_mismatch, args.max_offtargets,
+                                                    "strong scaling (BASELINE.json configs[3]: the same database, bins sharded)" if args.scaling == "strong" else
+                                                    "weak scaling (every rank its own hg38-sized shard)"),
                        "guides": G, "targets_per_gpu": T, "targets_total": T_total, "positions_per_gpu": P,
                        "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "ffh::k_compare", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            # executed full-length comparisons (the pigeonhole candidate generation visits ~1/4300 of the nominal G x T pairs): the figure
+            # comparable with the reference's BitEncoding.allComparisons counter
+            "executed_pair_tests_per_step": pairs, "executed_pair_tests_per_s": pairs * args.steps / dt,
+            "verified": verified, "verification": verify_note,
+            # the complete discover product: scan + cut-off + scores + retained hit lists and their positions copied to the host
+            "discover_with_lists_ms": lists_ms,
+            "roofline": {"bound": "valu-issue", "kernel": "ffh::k_compare",
+                         # SURVEY.md section 8d's HBM figure: algorithmic bytes of the launch against the 8 TB/s data-sheet peak
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
+                         "hbm_GBps_from_traffic": (traffic / (cmp_ms * 1e-3) / 1e9) if traffic else None,
                          "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3),
-                         # SURVEY.md section 8d's integer-VALU figure: 12 lane-ops per executed comparison against 256 CU x 64 lanes x 2.4 GHz
-                         "valu_frac_survey_formula": pairs * 12.0 / (cmp_ms * 1e-3 * 3.9e13),
+                         "valu_issue_frac": valu_issue, "useful_valu_frac": useful_valu,
+                         "valu_cycles_per_wave_instruction": VALU_CYCLES, "valu_instructions_per_64_pairs": PAIR_TEST_VALU,
+                         "sq_counters_per_launch": sq or None,
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
-            "cpu_baseline": cpu,
+            "cpu_baseline": _CPU_JVM if (_CPU_JVM and _CPU_JVM.get("value")) else cpu,
+            "cpu_baseline_port": cpu if (_CPU_JVM and _CPU_JVM.get("value")) else None,
             "cpu_baseline_all_cores": _CPU_MT,
             "breakdown_ms": {k: float(np.mean([t[k] for t in tms])) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
             "discover_wall_s": dt / args.steps,
@@ -348,8 +531,10 @@ def main():
             "plan": {"prefix_bases": tms[-1]["prefix_bases"], "prefix_radius": tms[-1]["prefix_radius"], "suffix_bases": info.suffix_bases,
                      "suffix_radius": tms[-1]["suffix_radius"], "items": tms[-1]["items_prefix"] + tms[-1]["items_suffix"],
                      "tiles": tms[-1]["tiles_prefix"] + tms[-1]["tiles_suffix"]},
-            "hits": {"raw": raw_hits, "kept_positions": kept_pos, "overflowed_guides": int(final["overflow"].sum())},
+            "hits": {"raw": raw_hits, "raw_per_guide": raw_hits / max(G, 1), "kept_positions": kept_pos, "overflowed_guides": int(final["overflow"].sum())},
             "algorithmic_bytes_survey": b_survey,
+            "skewed": skewed,
+            "real_genome": real_genome,
         }
     else:
         out = None

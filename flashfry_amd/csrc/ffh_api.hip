@@ -820,11 +820,15 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         const unsigned long long *slots = cnt + kPairSlotBase;
         const uint32_t stats[2] = {(uint32_t)cnt[kTileStatBase], (uint32_t)cnt[kTileStatBase + 1]};
         const unsigned long long cursor = cnt[0];
-        if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept)
-            std::vector<uint64_t> keep((size_t)cursor_before);
-            if (cursor_before) FFH_HIP(hipMemcpy(keep.data(), ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToHost));
-            FFH_HIP(ctx->hits.reserve((size_t)(cursor + cursor / 2)));
-            if (cursor_before) FFH_HIP(hipMemcpy(ctx->hits.p, keep.data(), (size_t)cursor_before * 8, hipMemcpyHostToDevice));
+        // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
+        // silently wrong result (the bulge path has the same guard)
+        if (cursor >= (1ull << 32) - 64) { ctx->err = "more than 2^32 raw hits in one scan: lower maxMismatch, split the guide set, or shard the bins over more GPUs"; return FFH_E_ARG; }
+        if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept, copied device to device)
+            DevBuf<uint64_t> bigger;
+            FFH_HIP(bigger.reserve((size_t)(cursor + cursor / 2)));
+            if (cursor_before) FFH_HIP(hipMemcpyAsync(bigger.p, ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToDevice, st));
+            FFH_HIP(hipStreamSynchronize(st));
+            ctx->hits = std::move(bigger);
             FFH_HIP(hipMemcpy(ctx->d_counters, &cursor_before, 8, hipMemcpyHostToDevice));  // the hit cursor goes back to where this batch began
             continue;
         }

@@ -29,7 +29,11 @@ namespace {
 struct Pack { int scan, pam; bool five_prime; };
 const Pack kPack[7] = {{0, 0, false}, {24, 4, true}, {23, 3, false}, {23, 3, false}, {23, 3, false}, {22, 3, false}, {22, 3, false}};  // StandardScanParameters.scala:84-215
 
-constexpr size_t kMember = 0xff00;  // BlockCompressedStreamConstants.DEFAULT_UNCOMPRESSED_BLOCK_SIZE
+// payload bytes per BGZF member: bgzip / htslib's 0xff00.  htsjdk (the reference's writer) cuts its members at a slightly larger payload
+// (its DEFAULT_UNCOMPRESSED_BLOCK_SIZE is 64 KiB minus the gzip overheads; htsjdk is not in the reference tree), so member boundaries
+// and with them the virtual pointers in <db>.header differ from a reference-written file of the same content.  Both are valid BGZF and
+// the pointers are self-consistent, so each side reads the other's files; byte parity of the container is NOT claimed.
+constexpr size_t kMember = 0xff00;
 constexpr int kMaxLinear = 500;     // BlockManager maxTargetsPerLinearBin, DatabaseWriter.scala:84-85
 constexpr int kSub = 256, kLookup = 4;
 

@@ -31,6 +31,22 @@ class _NP:
         return np.unique(x)
 
     @staticmethod
+    def unique_counts(x):
+        return np.unique(x, return_counts=True)
+
+    @staticmethod
+    def searchsorted(a, v):
+        return np.searchsorted(a, v, side="right")
+
+    @staticmethod
+    def argsort(x):
+        return np.argsort(x, kind="stable")
+
+    @staticmethod
+    def minimum(a, b):
+        return np.minimum(a, b)
+
+    @staticmethod
     def cat(xs):
         return np.concatenate(xs)
 
@@ -72,6 +88,22 @@ def _torch_ns():
         @staticmethod
         def unique(x):
             return torch.unique(x, sorted=True)
+
+        @staticmethod
+        def unique_counts(x):
+            return torch.unique(x, sorted=True, return_counts=True)
+
+        @staticmethod
+        def searchsorted(a, v):
+            return torch.searchsorted(a, v, right=True)
+
+        @staticmethod
+        def argsort(x):
+            return torch.argsort(x, stable=True)
+
+        @staticmethod
+        def minimum(a, b):
+            return torch.minimum(a, b)
 
         @staticmethod
         def cat(xs):
@@ -204,6 +236,112 @@ def make_database(n_targets, seed=DB_SEED, plant_guides=None, device=None, with_
         positions = (strand << 60) | (23 << 52) | (contig << 32) | pos
         out.update(positions=positions, pos_offsets=pos_off, P=P)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A repeat-structured genome (the published workload is real hg38, whose bucket occupancy is heavy-tailed: Alu / L1 / satellite
+# families, poly-A and other low-complexity tracts).  Three components, all counter-based hashes like the uniform generator:
+#   * uniform background: random 20-mers (the unique part of a genome);
+#   * repeat families: six levels, level l has 4^l families of cmax / 4^l copies each (at hg38 scale cmax ~ 1e6: one family of a
+#     million copies down to a thousand families of a thousand), every family a consensus of REPEAT_WINDOWS 20-mer windows; a copy of a
+#     window is the consensus with every base substituted independently at the family's divergence (14 % for the largest, oldest
+#     families down to 1 % for the youngest: Alu-like to segmental-duplication-like);
+#   * low-complexity tracts: period-1..6 tandem repeats with up to two substitutions (poly-A, (CA)n, (GGAA)n ...): few distinct
+#     sequences, very high counts.
+# Identical 20-mers collapse into one target whose count is the number of copies (capped at 32767 like BlockReader.scala:147-153).
+# Guides are sampled FROM the genome by position (make_guides_from_database), as a tiling library's are, so repeat families get
+# their share of guides and those guides collect thousands to hundreds of thousands of raw hits.
+# ---------------------------------------------------------------------------------------------------------------------
+REPEAT_WINDOWS = 16
+REPEAT_LEVELS = 6
+REPEAT_DIVERGENCE_64K = [9175, 7209, 5243, 3277, 1966, 655]  # 14, 11, 8, 5, 3, 1 % as thresholds on a 16-bit hash
+
+
+def _substitute(mers, rate_64k, salt, ids, xp, device):
+    """every base of every 20-mer substituted independently with probability rate_64k / 65536 (per-element rates allowed)"""
+    out = mers
+    for pos in range(20):
+        u = splitmix64(salt + pos, ids)
+        hit = (u & 0xFFFF) < rate_64k
+        delta = (_lsr(u, 16) % 3) + 1
+        out = xp.where(hit, out ^ (delta << (2 * (19 - pos))), out)
+    return out
+
+
+def make_repeat_database(n_targets, seed=DB_SEED, device=None, repeat_fraction=0.35, low_fraction=0.005, plant_guides=None):
+    """Sorted distinct targets (+counts) and positions of a repeat-structured synthetic genome of ~n_targets drawn 20-mers
+    (the number of DISTINCT targets is smaller: copies collapse).  Same return layout as make_database."""
+    xp = _ns(device)
+    n_rep = int(n_targets * repeat_fraction)
+    n_low = int(n_targets * low_fraction)
+    n_uni = max(n_targets - n_rep - n_low, 0)
+    parts = [splitmix64(seed, xp.arange(n_uni, device)) & MASK40]
+    # repeat families
+    per_level = max(n_rep // REPEAT_LEVELS, REPEAT_WINDOWS)
+    cmax = max(per_level // REPEAT_WINDOWS, 1)                 # copies of the single level-0 family
+    n_rep = per_level * REPEAT_LEVELS
+    e = xp.arange(n_rep, device)
+    level = e // per_level
+    r = e - level * per_level
+    rate = xp.zeros(n_rep, device)
+    fam = xp.zeros(n_rep, device)
+    for l in range(REPEAT_LEVELS):
+        copies = max(cmax >> (2 * l), 1)                        # cmax / 4^l copies per family, ~4^l families
+        fam = xp.where(level == l, r // (copies * REPEAT_WINDOWS), fam)
+        rate = xp.where(level == l, xp.scalar(REPEAT_DIVERGENCE_64K[l], e), rate)
+    window = r % REPEAT_WINDOWS
+    consensus = splitmix64(seed + 10, (level << 40) | (fam << 8) | window) & MASK40
+    parts.append(_substitute(consensus, rate, seed + 100, e, xp, device))
+    # low-complexity tracts
+    i = xp.arange(n_low, device)
+    h = splitmix64(seed + 11, i)
+    period_sel = h & 7
+    unit = _lsr(h, 8)
+    tract = xp.zeros(n_low, device)
+    for sel, period in enumerate([1, 1, 2, 2, 3, 4, 4, 6]):
+        u = unit & ((1 << (2 * period)) - 1)
+        rep = xp.zeros(n_low, device)
+        for k in range(0, 20, period):
+            rep = (rep << (2 * period)) | u
+        rep = _lsr(rep, 2 * ((-20) % period)) & MASK40 if 20 % period else rep & MASK40
+        tract = xp.where(period_sel == sel, rep, tract)
+    parts.append(_substitute(tract, xp.scalar(1966, i), seed + 200, i, xp, device))   # 3 % per base: most copies exact or one off
+    if plant_guides is not None and plant_guides.shape[0] > 0:
+        g = (_lsr(plant_guides, 6) & MASK40)[::100]
+        parts += [g] + [_mutate(g, lvl, seed + 17, xp, device) for lvl in (1, 2, 3, 4)]
+    mer, dup = xp.unique_counts(xp.cat(parts))
+    T = int(mer.shape[0])
+    h = splitmix64(seed + 2, mer)
+    pam_n = h & 3
+    count = xp.minimum(xp.asint(dup), xp.scalar(32767, mer))
+    targets = (mer << 6) | (pam_n << 4) | 0b1010 | (count << 48)
+    csum = xp.cumsum(count)
+    P = int(csum[-1]) if T else 0
+    pos_off = xp.cat([xp.zeros(1, device), csum])
+    owner = xp.repeat(xp.arange(T, device), count)
+    hp = splitmix64(seed + 3, xp.arange(P, device)) ^ splitmix64(seed + 4, owner)
+    contig = (_lsr(hp, 1) % 24) + 1
+    pos = _lsr(hp, 8) & ((1 << 27) - 1)
+    strand = _lsr(hp, 40) & 1
+    positions = (strand << 60) | (23 << 52) | (contig << 32) | pos
+    return {"targets": targets, "T": T, "positions": positions, "pos_offsets": pos_off, "P": P}
+
+
+def make_guides_from_database(db, n_guides, seed=GUIDE_SEED, device=None):
+    """n_guides distinct guides drawn from the database BY GENOMIC POSITION (a target with 1000 copies is 1000 times as likely as a
+    unique one -- what tiling a genome does), in a hash order that has nothing to do with the database order.  Guide long = the
+    target's 23-mer with count 1."""
+    xp = _ns(device)
+    P, T = db["P"], db["T"]
+    m = min(int(n_guides * 1.5) + 64, max(P, 1))
+    pick = splitmix64(seed + 7, xp.arange(m, device)) % max(P, 1)
+    pick = xp.where(pick < 0, pick + max(P, 1), pick)
+    owner = xp.searchsorted(db["pos_offsets"], pick) - 1
+    owner = xp.unique(owner)
+    order = xp.argsort(splitmix64(seed + 8, owner))
+    owner = owner[order][:n_guides]
+    t = db["targets"][owner]
+    return (t & ((1 << 48) - 1)) | (1 << 48)
 
 
 def as_u64(x):

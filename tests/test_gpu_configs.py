@@ -1,0 +1,104 @@
+"""BASELINE.json's configurations at their stated sizes, HIP path against the CPU oracle through the C ABI.
+
+  C1  one guide (EMX1) against a chr22-scale database (plumbing case of the reference's Quickstart)
+  C2  1 000 random NGG 20-mers against a chr22-scale database (4.5e6 unique targets), <= 4 mismatches: hit lists, positions,
+      otCount / OVERFLOW and the CFD / Hsu2013 / closest-hit aggregates of EVERY guide, bit for bit against the oracle
+      (BlockManager.scala:212-254 is the loop the oracle restates; the oracle needs ~6 s for it)
+  a 60-second slice of tools/stress_parity.py (randomised sizes x mismatch budgets x cut-offs), so that the driver's run sees it
+
+C3 (100 000 guides vs 3.0e8 targets) is tests/test_gpu_fullscale.py: the oracle would need ~17 min for it, so it is checked there
+through an independent brute-force scan of sampled guides and size-independent properties, and bench.py verifies its own step."""
+import time
+
+import numpy as np
+import pytest
+
+from flashfry_amd import synth
+from tests.helpers import assert_same_hits, assert_same_scores, make_case
+
+pytestmark = pytest.mark.gpu
+
+T_CHR22 = 4_500_000   # chr22 NGG ~ 4-5e6 unique targets
+EMX1 = "GAGTCCGAGCAGAAGAAGAAGGG"  # the Quickstart guide (README.md of the reference), 20-mer + NGG
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from flashfry_amd import capi
+    assert capi.load_library().ffh_device_count() >= 1, "no GPU visible: the gpu tests must run on the MI355X box"
+    return capi
+
+
+@pytest.fixture(scope="module")
+def chr22(oracle):
+    odb, t, p, g = make_case(oracle, T_CHR22, 1000, enzyme=3, seed=22)
+    return odb, t, p, g
+
+
+def test_config_c2_1000_guides_vs_chr22_scale_is_bit_identical_to_the_oracle(capi, oracle, chr22):
+    odb, t, p, g = chr22
+    assert len(t) >= T_CHR22 and len(g) == 1000
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        gpu = ctx.discover(g, 4, 2000, jost=True)
+        only = ctx.finalize(2000, summaries_only=True, jost=True)
+        assert only.summaries.tobytes() == gpu.summaries.tobytes()
+    ora = odb.discover(g, 4, 2000)
+    assert_same_hits(gpu, ora)                              # hit lists in database order, positions, otCount, OVERFLOW
+    assert_same_scores(oracle, 3, g, gpu, ora, jost=True)   # per-hit CFD and the per-guide aggregates, f64 bit for bit
+    assert gpu.n_hits > 1000
+
+
+def test_config_c2_with_a_tight_cutoff_and_five_mismatches(capi, oracle, chr22):
+    odb, t, p, g = chr22
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for max_mm, max_ot in ((5, 25), (3, 2000)):
+            gpu = ctx.discover(g[:300], max_mm, max_ot)
+            ora = odb.discover(g[:300], max_mm, max_ot)
+            assert_same_hits(gpu, ora)
+            assert_same_scores(oracle, 3, g[:300], gpu, ora)
+            if max_mm == 5:
+                assert gpu.summaries["overflow"].sum() > 0
+
+
+def test_config_c1_one_guide_vs_chr22_scale(capi, oracle, chr22):
+    odb, t, p, _ = chr22
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    v = 0
+    for ch in EMX1:
+        v = (v << 2) | code[ch]
+    g = np.array([v | (1 << 48)], dtype=np.uint64)          # BitEncoding.bitEncodeString: count 1 in bits 63:48
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        gpu = ctx.discover(g, 4, 2000)
+    ora = odb.discover(g, 4, 2000)
+    assert_same_hits(gpu, ora)
+    assert_same_scores(oracle, 3, g, gpu, ora)
+
+
+def test_randomised_parity_slice(capi, oracle):
+    """tools/stress_parity.py for a bounded time: seeds x database sizes x guide counts x 0-6 mismatches x cut-offs"""
+    from tests.test_gpu_parity import dense_case
+    rng = np.random.default_rng(20260928)
+    t0, n = time.time(), 0
+    while time.time() - t0 < 60.0:
+        seed = int(rng.integers(0, 1 << 30))
+        max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
+        max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
+        if int(rng.integers(0, 2)) == 0:
+            odb, t, p, g = make_case(oracle, int(rng.integers(100, 400000)), int(rng.integers(1, 600)), enzyme=3, seed=seed)
+        else:
+            ng = int(rng.integers(10, 500))
+            odb, t, p, g = dense_case(oracle, n_random=int(rng.integers(1000, 120000)), n_guides=ng,
+                                      n_dense=int(rng.integers(1, min(60, ng))), variants=int(rng.integers(10, 200)), seed=seed)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            gpu = ctx.discover(g, max_mm, max_ot, jost=True)
+            only = ctx.finalize(max_ot, summaries_only=True, jost=True)
+            assert only.summaries.tobytes() == gpu.summaries.tobytes()
+        ora = odb.discover(g, max_mm, max_ot)
+        assert_same_hits(gpu, ora)
+        assert_same_scores(oracle, 3, g, gpu, ora)
+        n += 1
+    assert n >= 20, "the slice should get through a few dozen cases in a minute (%d)" % n

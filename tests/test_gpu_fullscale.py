@@ -1,4 +1,5 @@
-"""The hot path at BASELINE.json's full size (3.0e8 targets, hg38 scale) checked through size-independent properties:
+"""The hot path at BASELINE.json's full size -- config C3: 100 000 guides against 3.0e8 targets (hg38 scale), <= 4 mismatches --
+checked through size-independent properties:
 an independent brute-force torch scan of all targets for a sample of guides, database order, the cut-off rule, planted
 copies at every mismatch level, invariance under the candidate split and under bin sharding.  No oracle here: it would
 need hours at this size (it is the checker at the small sizes in test_gpu_parity.py)."""
@@ -12,7 +13,7 @@ from flashfry_amd import synth
 pytestmark = pytest.mark.gpu
 
 T_FULL = int(3.0e8)
-G = 4000
+G = 100000                       # BASELINE.json configs[2]
 MAX_OT = 2000
 CMP_MASK = 0x3FFFFFFFFFC0          # StandardScanParameters.scala:143
 UPPER = 0xAAAAAAAAAAAA             # BitEncoding.scala:205
@@ -53,7 +54,10 @@ def world():
 
 def test_every_hit_of_sampled_guides_matches_a_brute_force_torch_scan(world):
     torch, ctx, db = world["torch"], world["ctx"], world["db"]
-    sample = list(range(0, G, 100))[:12] + [1, 2, 3]           # planted guides (every 100th) and plain ones
+    # 40 guides: planted ones (every 100th guide has copies at 0..4 mismatches in the database) and plain ones, spread over the
+    # whole guide range so that every part of the candidate lists / every guide batch is sampled
+    sample = list(range(0, G, 100))[::50] + [1, 2, 3, 777, 4999, 50001, 65537, 99998, 99999] + list(range(12345, G, 9973))
+    assert len(set(sample)) >= 32
     res = ctx.discover(world["guides"], 4, 2 ** 31 - 1)         # no cut-off: the complete hit sets
     for g in sample:
         mm = torch_mismatches(torch, int(world["guides"][g].astype(np.int64)), db["targets"])
@@ -122,7 +126,7 @@ def test_result_does_not_depend_on_the_candidate_split_or_on_sharding(world):
         r1 = c1.finalize(MAX_OT, prior_totals=c0.shard_totals(MAX_OT))
     n0, n1 = np.diff(r0.guide_offsets.astype(np.int64)), np.diff(r1.guide_offsets.astype(np.int64))
     assert np.array_equal(n0 + n1, np.diff(whole.guide_offsets.astype(np.int64)))
-    merged = np.concatenate([np.concatenate([r0.hits(g), r1.hits(g)]) for g in range(0, G, 7)])
-    assert np.array_equal(merged, np.concatenate([whole.hits(g) for g in range(0, G, 7)]))
+    merged = np.concatenate([np.concatenate([r0.hits(g), r1.hits(g)]) for g in range(0, G, 97)])
+    assert np.array_equal(merged, np.concatenate([whole.hits(g) for g in range(0, G, 97)]))
     assert np.array_equal(r0.summaries["ot_count"] + r1.summaries["ot_count"], whole.summaries["ot_count"])
     assert np.array_equal(r0.summaries["overflow"] | r1.summaries["overflow"], whole.summaries["overflow"])
