@@ -63,6 +63,7 @@ int main() {
     uint32_t *out;
     CHECK(hipMalloc(&out, 64));
 #define RUN(K) run(#K, K, out);
+    RUN(k_xor) RUN(k_xor_s) RUN(k_add) RUN(k_lshr) RUN(k_bcnt) RUN(k_bitop3) RUN(k_min) RUN(k_min3) RUN(k_and_or) RUN(k_or_sdwa) RUN(k_cmp)
     RUN(k_alignbit) RUN(k_perm) RUN(k_sad) RUN(k_mad24) RUN(k_fma) RUN(k_pk_add_u16) RUN(k_dot4) RUN(k_lshl_or) RUN(k_mov_dpp)
     return 0;
 }
