@@ -22,6 +22,7 @@
 #include "ffh_ingest.hpp"
 #include "ffh_inflate.hpp"
 #include "ffh_kernels.hpp"
+#include "ffh_compare.hpp"
 #include "cfd_table.inc"
 #include "jost_table.inc"
 
@@ -71,9 +72,11 @@ struct DevBuf {  // device allocation that grows on demand and frees itself (on 
 
 struct Image {  // one bucketed scan image of the database
     int width = -1;
-    DevBuf<uint32_t> bstart;  // 4^width + 1
-    DevBuf<uint64_t> keys;    // planar keys grouped by bucket
-    DevBuf<uint32_t> tidx;    // database index of each key
+    DevBuf<uint32_t> bstart;  // 4^width + 1: first target of every bucket
+    DevBuf<uint32_t> gstart;  // 4^width + 1: first group of every bucket
+    DevBuf<uint32_t> gwords;  // the bucket's targets in bit-sliced groups of 32 (ffh_compare.hpp), padded by kKW + 64 words
+    DevBuf<uint32_t> tidx;    // database index of every slot (32 per group)
+    int rest = 0;             // bases in the rest key (the ones the bucket id does not hold)
 };
 
 struct Plan { int a, r1, s, r2; };  // prefix width/radius, suffix width/radius (r2 < 0: no suffix pass)
@@ -170,9 +173,8 @@ struct ffh_ctx {
     ffh_load_stats load{};
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
-    // 6.5 rounds of the 2048 blocks that fit the device at once: every block start exposes the pipeline's three HBM round trips (65 536
-    // blocks: 3.4 ms instead of 1.9), too few rounds leave the end of the launch unbalanced (4096: 2.08 ms); 12-14k measured best
-    unsigned compare_grid = 256 * 52;
+    // persistent waves: four 256-thread blocks per CU (LDS-limited), every wave walks its share of the batches
+    unsigned compare_grid = 256 * 4;
     bool scan_timing_pending = false, finalize_timing_pending = false, hit_t_ready = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
 
@@ -189,12 +191,11 @@ struct ffh_ctx {
     unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] load-time check counter
 
     // per-pass scratch
-    DevBuf<uint64_t> gkey;                                  // planar guide keys of the current batch (L2-resident)
-    DevBuf<uint32_t> gbucket[2], patterns[2], tstart[2], istart[2];
+    DevBuf<uint2> gtab[2];                                  // {rest key, bucket} of every guide of the current batch, per side (L2-resident)
+    DevBuf<uint32_t> gbucket[2], patterns[2], istart[2];
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
-    DevBuf<uint32_t> icount, ifill, tcount, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
+    DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
     DevBuf<uint64_t> scan_tmp64;
-    DevBuf<uint4> tiles;
     DevBuf<uint32_t> sort_table, sort_offs;
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
 
@@ -274,9 +275,18 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     Image &im = ctx->img[which];
     const uint32_t nb = 1u << (2 * width);
     im.width = width;
+    im.rest = ctx->geo.lc - width;
+    const uint32_t R = (uint32_t)im.rest, GW = (uint32_t)group_words(im.rest);
+    // every bucket rounds its targets up to whole groups of 32: at most T / 32 + nb groups (no host round trip for the exact number)
+    const uint64_t max_groups = ctx->T / 32 + nb;
+    if (max_groups * 32 >= (1ull << 31) - 64) { ctx->err = "too many target slots in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
+    DevBuf<uint32_t> keys, tidx_in;   // the counting sort's output, bit-sliced below and then dropped
     FFH_HIP(im.bstart.reserve((size_t)nb + 1));
-    FFH_HIP(im.keys.reserve(ctx->T));
-    FFH_HIP(im.tidx.reserve(ctx->T));
+    FFH_HIP(im.gstart.reserve((size_t)nb + 1));
+    FFH_HIP(keys.reserve(ctx->T + 1));
+    FFH_HIP(tidx_in.reserve(ctx->T + 1));
+    FFH_HIP(im.gwords.reserve((size_t)max_groups * GW + kKW + 64));
+    FFH_HIP(im.tidx.reserve((size_t)max_groups * 32 + 64));
     FFH_HIP(ctx->icount.reserve((size_t)nb + 1));
     FFH_HIP(ctx->ifill.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
@@ -289,10 +299,14 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     }
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.bstart.p, ctx->scan_tmp32.p, ctx->st);
     if (ctx->T) {
-        if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, im.keys.p, im.tidx.p);
-        else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, im.keys.p, im.tidx.p);
+        if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
+        else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
     }
+    hipLaunchKernelGGL(k_group_count, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, ctx->icount.p);
+    exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.gstart.p, ctx->scan_tmp32.p, ctx->st);
+    hipLaunchKernelGGL(k_group_build, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, keys.p, tidx_in.p, nb, R, GW, im.gwords.p, im.tidx.p);
     FFH_HIP(hipGetLastError());
+    FFH_HIP(hipStreamSynchronize(ctx->st));   // the temporaries go away here
     return FFH_OK;
 }
 
@@ -337,23 +351,22 @@ static int prepare_database(ffh_ctx *ctx) {
 }
 
 // ---- candidate lists (CSR) + work items of one image (no host synchronisation: counts stay on the device) ------
-static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, uint32_t item_base, const uint32_t *tile_base) {
+static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, uint32_t item_base) {
     Image &im = ctx->img[which];
     const int width = im.width;
     const uint32_t nb = 1u << (2 * width);
     const std::vector<uint32_t> &pat = patterns_for(ctx, width, radius);
     const uint32_t np = (uint32_t)pat.size();
     hipStream_t st = ctx->st;
-    DevBuf<uint32_t> &patterns = ctx->patterns[which], &tstart = ctx->tstart[which], &gbucket = ctx->gbucket[which], &istart = ctx->istart[which];
+    DevBuf<uint32_t> &patterns = ctx->patterns[which], &gbucket = ctx->gbucket[which], &istart = ctx->istart[which];
     if (ctx->patterns_key[which] != std::make_pair(width, std::min(radius, width)) || patterns.cap < np) {  // uploaded once per (width, radius)
         FFH_HIP(patterns.reserve(np));
         FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
         ctx->patterns_key[which] = std::make_pair(width, std::min(radius, width));
     }
     FFH_HIP(gbucket.reserve(ng));
+    FFH_HIP(ctx->gtab[which].reserve((size_t)ng + 64));
     FFH_HIP(istart.reserve((size_t)nb + 1));
-    FFH_HIP(ctx->tcount.reserve((size_t)nb + 1));
-    FFH_HIP(tstart.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
     // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
     const uint64_t n_enum = (uint64_t)ng * np;
@@ -371,9 +384,9 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     const uint64_t *gptr = ctx->guides.p + g0;
     // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
     // saves the fill launches before k_guide_part_hist and k_segments)
-    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p,
+    if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[0].p, gbucket.p,
                                        ctx->seg_begin.p + g0, ctx->seg_end.p + g0, ctx->part_hist.p, ig.n_part);
-    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gkey.p, gbucket.p, (uint32_t *)nullptr,
+    else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[1].p, gbucket.p, (uint32_t *)nullptr,
                             (uint32_t *)nullptr, ctx->part_hist.p, ig.n_part);
     FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
     FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
@@ -385,9 +398,6 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
     hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p);
-    hipLaunchKernelGGL(k_tile_count, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, nb, ctx->tcount.p);
-    exclusive_scan<uint32_t, uint32_t>(ctx->tcount.p, nb, tstart.p, ctx->scan_tmp32.p, st);
-    hipLaunchKernelGGL(k_tile_fill, dim3(blocks_for(nb, 256)), dim3(256), 0, st, im.bstart.p, istart.p, tstart.p, nb, tile_base, (uint32_t)which, ctx->tiles.p);
     FFH_HIP(hipGetLastError());
     return FFH_OK;
 }
@@ -764,53 +774,59 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     const Plan plan = choose_plan(ctx, std::min(max_mm, ctx->geo.lc));
     ctx->tm.prefix_bases = plan.a; ctx->tm.prefix_radius = plan.r1; ctx->tm.suffix_radius = plan.r2;
     const double np_p = ball_size(plan.a, plan.r1), np_s = ball_size(plan.s, plan.r2);
-    const uint64_t nbp = 1ull << (2 * plan.a), nbs = 1ull << (2 * plan.s);
     // batch size: the candidate CSR of both images must stay addressable with 32 bits (and a sane size)
     double max_batch = (double)std::max<uint32_t>(n_guides, 1);
     max_batch = std::min(max_batch, (double)(1ull << 30) / (np_p + np_s));
     max_batch = std::min(max_batch, (double)((1u << kGidBits) - 1u));
     if (ctx->max_guide_batch) max_batch = std::min(max_batch, (double)ctx->max_guide_batch);
     uint32_t batch = (uint32_t)std::max(1.0, std::floor(max_batch));
-    const uint64_t tile_cap = std::min<uint64_t>(nbp, ctx->T) + std::min<uint64_t>(nbs, ctx->T) + 2 * (ctx->T / kTileTargets) + 4;
-    const uint32_t *zero = (const uint32_t *)(ctx->d_counters + 3);
-    FFH_HIP(ctx->tiles.reserve(tile_cap));
+    // how each image is cut into batches for the compare kernel (ffh_compare.hpp): runs of NB small buckets, or 2^k slices of one large
+    // bucket, sized so that a typical batch fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); whatever exceeds
+    // the strip takes the kernel's piecewise path
+    auto side_plan = [&](int which, int width, int r_far, double n_patterns, uint32_t ng) -> SideArgs {
+        SideArgs S{};
+        const Image &im = ctx->img[which];
+        S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.istart = ctx->istart[which].p; S.bstart = im.bstart.p; S.gtab = ctx->gtab[which].p;
+        S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
+        const double cap_g = std::floor((double)kKW / group_words(im.rest));
+        const double avg_t = (double)ctx->T / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
+        S.NB = 1; S.sl_shift = 0; S.KS = 0;
+        if (avg_g * 1.1 <= cap_g) {
+            const double by_groups = std::floor(0.75 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.7 * kKC / std::max(avg_c, 0.05));
+            S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
+        } else {
+            while (avg_g * 1.1 / (double)(1u << S.sl_shift) > cap_g && S.sl_shift < 20) ++S.sl_shift;
+            S.KS = (uint32_t)std::ceil(avg_g * 1.05 / (double)(1u << S.sl_shift));
+        }
+        const uint64_t nbat = (((uint64_t)S.nb + S.NB - 1) / S.NB) << S.sl_shift;
+        S.n_batches = (uint32_t)std::min<uint64_t>(nbat, 0xFFFFFFFFu);
+        return S;
+    };
     FFH_HIP(hipEventRecord(ctx->ev[0], st));
     float ms_cmp = 0, ms_prep = 0;
     unsigned long long cursor_before = 0;
     for (uint32_t g0 = 0; g0 < n_guides;) {
         const uint32_t ng = std::min(batch, n_guides - g0);
         // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
-        {
-            FlushArgs fa;
-            fa.hits = ctx->hits.p; fa.cap = (uint64_t)ctx->hits.cap; fa.tidx_p = ctx->img[0].tidx.p; fa.tidx_s = ctx->img[1].tidx.p;
-            fa.guide_base = g0; fa.tbits = ctx->tbits;
-            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, fa, g0 == 0 ? 1 : 0);
-        }
+        hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, g0 == 0 ? 1 : 0);
         const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
         if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
         FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
-        FFH_HIP(ctx->gkey.reserve((size_t)ng + 64));
         FFH_HIP(hipEventRecord(ctx->ev[2], st));
-        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, 0u, zero);
+        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, 0u);
         if (rc) return rc;
-        const uint32_t *n_tiles0 = ctx->tstart[0].p + nbp, *n_tiles1 = zero;
         if (plan.r2 >= 0) {
-            rc = prepare_side(ctx, 1, plan.r2, g0, ng, (uint32_t)n_items_p, n_tiles0);
+            rc = prepare_side(ctx, 1, plan.r2, g0, ng, (uint32_t)n_items_p);
             if (rc) return rc;
-            n_tiles1 = ctx->tstart[1].p + nbs;
         }
         FFH_HIP(hipEventRecord(ctx->ev[3], st));
-        CompareArgs ca;
-        ca.tiles = ctx->tiles.p; ca.n_tiles_a = n_tiles0; ca.n_tiles_b = n_tiles1;
-        ca.keys[0] = ctx->img[0].keys.p; ca.keys[1] = ctx->img[1].keys.p;
-        ca.slots = ctx->item_gid.p; ca.gkey = ctx->gkey.p; ca.max_mm = max_mm;
-        ca.prefix_mask = plan.a > 0 ? (((1u << plan.a) - 1u) << (ctx->geo.lc - plan.a)) : 0u;
-        ca.r1 = plan.r1; ca.cursor = ctx->d_counters;
-        // many more blocks than can be resident: the hardware dispatcher then balances the load (a grid sized to the
-        // "occupancy" runs a second, mostly empty round when the SGPR budget admits fewer blocks than assumed)
-        const unsigned cmp_grid = ctx->compare_grid;
-        if (max_mm < 12) hipLaunchKernelGGL(k_compare<false>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
-        else hipLaunchKernelGGL(k_compare<true>, dim3(cmp_grid), dim3(kCmpThreads), 0, st, ca.tiles, ca.keys[0], ca.keys[1], ca.slots, ca.gkey, ca);
+        CompareArgs ca{};
+        ca.side[0] = side_plan(0, plan.a, -1, np_p, ng);
+        if (plan.r2 >= 0) ca.side[1] = side_plan(1, plan.s, plan.r1, np_s, ng);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+        else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
+        ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
+        const uint32_t stats[2] = {ca.side[0].n_batches, ca.side[1].n_batches};
+        hipLaunchKernelGGL(k_compare<0>, dim3(ctx->compare_grid), dim3(kCmpThreads), 0, st, ca, ctx->d_counters);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
         unsigned long long cnt[kPairSlotBase + 2 * kPairSlots];  // one read-back: hit cursor, work-item counts, pair counters
@@ -818,7 +834,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(hipStreamSynchronize(st));
         FFH_HIP(hipGetLastError());
         const unsigned long long *slots = cnt + kPairSlotBase;
-        const uint32_t stats[2] = {(uint32_t)cnt[kTileStatBase], (uint32_t)cnt[kTileStatBase + 1]};
         const unsigned long long cursor = cnt[0];
         // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
         // silently wrong result (the bulge path has the same guard)

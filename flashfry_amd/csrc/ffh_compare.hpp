@@ -1,0 +1,502 @@
+// ffh_compare.hpp -- THE HOT KERNEL of the discover scan (gfx950, wave64): candidate guides x bucketed targets.
+//
+// Replaces the inner loops of BlockManager.compareBlock / compareLinearBlock / compareIndexedBlock (blocks/BlockManager.scala:63-254)
+// and the bin traversals that feed them (OrderedBinTraversalFactory.scala:146-177, LinearTraversal.scala:64-97); the unit of work is
+// BitEncoding.mismatches (bitcoding/BitEncoding.scala:127-132).  What reaches this kernel is, per scan image,
+// a join of two streams that are both sorted by bucket: the targets of every bucket and the bucket's candidate guides (CSR).
+//
+// BIT-SLICED TARGETS.  A pair test done one pair per lane costs v_xor + v_bitop3 + v_bcnt + a share of a reduction = ~12.6 SIMD cycles
+// per 64 pairs (v_bcnt, v_min*, v_cmp run at half rate on gfx950: tools/ubench/op_rate.hip), and that is what binds the scan.  Here a
+// lane tests ONE candidate guide against THIRTY-TWO targets per step: the image stores the targets of a bucket in GROUPS of 32, a
+// group being 2R + 1 words -- for each of the R bases the bucket id does not fix, bit t of word 2i / word 2i + 1 is the high / low
+// plane bit of base i of target t, plus a word of valid bits.  With the guide's own plane bits spread into all-zero / all-one masks GH_i,
+// GL_i (once per candidate),
+//     mismatch_i = (H_i ^ GH_i) | (L_i ^ GL_i)             32 pairs in two full-rate instructions (v_xor, v_bitop3)
+//     count      = carry-save adder tree over the R words  (v_bitop3 does a full adder's sum or carry in one instruction)
+//     hit        = count <= maxMismatch - d  (& count > r1 on the suffix image) & valid        four to eight v_bitop3
+// ~37 (R = 9) / ~46 (R = 11) full-rate instructions per 64 lanes x 32 pairs: ~1.2 instructions per 64 pairs instead of 3.75, none of
+// them half rate, and no per-pair popcount at all.  d = the mismatches inside the bucket key, per (guide, bucket).
+//
+// WORK LAYOUT.  A wave owns a BATCH at a time: a run of consecutive small buckets (prefix image: ~72 targets = 3 groups per bucket) or a
+// slice of one large bucket (suffix image: ~36 groups).  Both streams of a batch are contiguous in memory: the batch is fetched with a
+// few wide coalesced loads one batch ahead of its use (bucket boundaries three, candidate ids two batches ahead), parked in the wave's
+// LDS strip and computed out of LDS.  The batch's (candidate, group range) JOBS are dealt to the lanes, 64 to a row: a candidate of a
+// small bucket is one job, a candidate of a large bucket is split into P jobs of ~6 groups, so a row's lanes run the same number of
+// steps and every lane is busy whatever the bucket sizes are.  There are no per-bucket work items, no bucket tails, no sub-wave
+// packing.  A lane with a hit (a non-zero 32-bit mask, rare) stages (guide, slot) per set bit; the stage leaves as sort keys
+// (guide << tbits | database index) with one global atomic per ~250 hits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ffh_prims.hpp"
+
+namespace ffh {
+
+// (the FFH_* macros exist for same-box A/B builds with tools/build_variant.sh; the defaults are the product)
+#ifndef FFH_KW
+#define FFH_KW 1024
+#endif
+#ifndef FFH_KC
+#define FFH_KC 256
+#endif
+#ifndef FFH_STAGE
+#define FFH_STAGE 256
+#endif
+#ifndef FFH_WAVES_PER_SIMD
+#define FFH_WAVES_PER_SIMD 4
+#endif
+#ifndef FFH_GPL
+#define FFH_GPL 6
+#endif
+constexpr int kCmpThreads = 256;           // four waves, each with its own LDS strip: no block-level synchronisation in the kernel
+constexpr int kCmpWaves = kCmpThreads / 64;
+constexpr int kKW = FFH_KW;                // group words parked per wave (4 KB: 51 groups of 20 words, 42 of 24)
+constexpr int kKC = FFH_KC;                // candidates parked per wave
+constexpr int kStage = FFH_STAGE;          // staged hits per wave
+constexpr int kMaxNB = 15;                 // buckets per batch: lanes 0..15 (one DPP row) hold the batch's bucket boundaries
+constexpr int kKeyRegs = kKW / 256;        // 16-byte loads per lane and batch
+constexpr int kGidRegs = kKC / 64;
+constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is split into jobs of about this many groups
+constexpr int kMaxParts = 16;
+
+constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
+
+__host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 + 3) & ~3; }   // words per group of 32 targets (16-byte multiple)
+
+struct SideArgs {
+    const uint32_t *gstart;   // [nb + 1] first group of every bucket
+    const uint32_t *gwords;   // [groups * GW + kKW + 64] bit-sliced groups (padded: a batch is fetched in whole 16-byte pieces)
+    const uint32_t *tidx;     // [groups * 32] database index of every slot (looked up when a hit leaves the wave)
+    const uint32_t *istart;   // [nb + 1] first candidate of every bucket (absolute index into gids)
+    const uint32_t *bstart;   // [nb + 1] first target of every bucket (the executed-pair statistics)
+    const uint2 *gtab;        // [guides of this batch] {rest key H << 16 | L, bucket id} of every guide on this side
+    uint32_t nb;              // buckets
+    uint32_t width;           // bases in the bucket id (= bits per plane of it)
+    uint32_t rest;            // R: bases in the rest key
+    uint32_t NB;              // buckets per batch (1 when sl_shift > 0)
+    uint32_t sl_shift;        // log2(slices per bucket)
+    uint32_t KS;              // groups per slice; the last slice takes whatever is left
+    uint32_t n_batches;       // ceil(nb / NB) << sl_shift
+    int r_far;                // suffix side: r1 -- a pair is reported here only with MORE than r1 mismatches in its rest key (the
+                              // prefix image reports the others); prefix side: -1
+};
+struct CompareArgs {
+    SideArgs side[2];         // 0 prefix image, 1 suffix image
+    const uint32_t *gids;     // candidate CSR of both sides
+    uint64_t *hits;
+    uint64_t cap;
+    uint32_t guide_base;      // first guide of this batch of guides
+    int tbits;                // hit key = (global guide << tbits) | database index
+    int max_mm;
+    uint32_t pad;
+};
+
+// before every compare launch: clears the per-launch pair counters (one launch in place of a memset)
+__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int first_batch) {
+    if (first_batch && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // hit cursor and the zero word: once per scan, they run across batches
+    if (threadIdx.x < 2 * kPairSlots) cursor[kPairSlotBase + threadIdx.x] = 0ull;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_c4;   // 32-bit LDS addresses
+
+__device__ __forceinline__ void wave_lds_fence() {  // this wave's LDS writes are visible to its own later reads, in program order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// lane l gets lane l + 1's value / lane l - k's value inside its row of 16 lanes (0 past the row's end): DPP, no LDS round trip
+__device__ __forceinline__ uint32_t row_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }   // row_shl:1
+template <int K>
+__device__ __forceinline__ uint32_t row_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, true); }  // row_shr:K
+
+#define BITOP3(a, b, c, lut) __builtin_amdgcn_bitop3_b32((a), (b), (c), (lut))   // result bit = lut[(a << 2) | (b << 1) | c]
+
+// number of set planes among n one-bit-per-target words: a carry-save adder tree, one v_bitop3 per sum / per carry
+template <int N>
+__device__ __forceinline__ void count_planes(const uint32_t (&m)[N], uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3) {
+    static_assert(N >= 2 && N <= 15, "a four-bit count");
+    uint32_t w[4][N];
+    int n[4] = {N, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[0][i] = m[i];
+    uint32_t c[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) {
+        int cnt = n[lv];
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+            if (cnt >= 3) {   // full adder: three words of this weight -> one of this weight, one of the next
+                const uint32_t a = w[lv][cnt - 1], b = w[lv][cnt - 2], d = w[lv][cnt - 3];
+                cnt -= 3;
+                w[lv][cnt++] = BITOP3(a, b, d, 0x96);
+                if (lv < 3) w[lv + 1][n[lv + 1]++] = BITOP3(a, b, d, 0xE8);
+            }
+        }
+        if (cnt == 2) {      // half adder
+            const uint32_t a = w[lv][1], b = w[lv][0];
+            w[lv][0] = a ^ b;
+            cnt = 1;
+            if (lv < 3) w[lv + 1][n[lv + 1]++] = a & b;
+        }
+        c[lv] = cnt ? w[lv][0] : 0u;
+    }
+    c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
+}
+
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+struct HitStage {
+    lds_u64 *my;             // this wave's staged hits: guide of this batch << 32 | side << 31 | slot in the side's image
+    uint32_t fill;
+    uint32_t lane;
+    const CompareArgs *A;    // the kernel's argument block (scalar loads from the kernarg segment at flush time)
+    unsigned long long *cursor;
+
+    // ONE global atomic per flush (same-address atomics complete at ~90 per microsecond on this part: a flush per ~250 hits keeps them
+    // off the critical path).  A record leaves as the sort key (global guide << tbits) | database index -- the index lookup rides on
+    // the flush instead of a pass of its own over all hits
+    __device__ __forceinline__ void flush() {
+        wave_lds_fence();
+        uint64_t *__restrict__ hits = A->hits;
+        const uint64_t cap = A->cap;
+        const uint32_t *__restrict__ tidx_p = A->side[0].tidx, *__restrict__ tidx_s = A->side[1].tidx;
+        const uint32_t guide_base = A->guide_base;
+        const int tbits = A->tbits;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)fill);
+        base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+        for (uint32_t i = lane; i < fill; i += 64)
+            if (base + i < cap) {
+                const uint64_t h = my[i];
+                const uint32_t lo = (uint32_t)h, slot = lo & 0x7FFFFFFFu;
+                const uint32_t ti = (lo >> 31) ? tidx_s[slot] : tidx_p[slot];
+                hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
+            }
+        wave_lds_fence();
+        fill = 0;
+    }
+    // wave-uniform call: `lanes` = ballot of `hit`
+    __device__ __forceinline__ void push(uint64_t lanes, bool hit, uint32_t gid, uint32_t slot) {
+        if (hit) my[fill + mbcnt(lanes)] = ((uint64_t)gid << 32) | slot;
+        fill += (uint32_t)__popcll(lanes);
+        if (fill > kStage - 64) flush();  // always leave room for one more wave-wide batch
+    }
+};
+
+// what a row's lanes share
+struct RowCtx {
+    HitStage *hs;
+    int max_mm, r_far;
+    uint32_t side_bit, width;
+};
+
+// One row: 64 jobs, one per lane -- one candidate guide against `trips` consecutive groups of its bucket.
+//   rest: the guide's rest key (H << 16 | L), d: its mismatches inside the bucket key, gid: its id; strip: the wave's parked group
+//   words; gword: strip word of the lane's first group; gabs: absolute index of that group (for the hit's slot)
+template <int R>
+__device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t gabs,
+                                         const uint32_t *strip) {
+    constexpr int GW = group_words(R);
+    // the guide's plane bits as masks, its mismatch budget inside this bucket as threshold masks
+    uint32_t GH[R], GL[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        GH[i] = (uint32_t)__builtin_amdgcn_sbfe((int)rest, 16 + i, 1);   // 0 or ~0
+        GL[i] = (uint32_t)__builtin_amdgcn_sbfe((int)rest, i, 1);
+    }
+    const int thr = c.max_mm - (int)d;                 // rest mismatches allowed
+    if (thr < 0) trips = 0;
+    const uint32_t tcl = (uint32_t)min(max(thr, 0), 15);
+    const uint32_t t0 = 0u - (tcl & 1u), t1 = 0u - ((tcl >> 1) & 1u), t2 = 0u - ((tcl >> 2) & 1u), t3 = 0u - ((tcl >> 3) & 1u);
+    const uint32_t far = (uint32_t)(c.r_far + 1);      // suffix image: at least this many rest mismatches (0: no condition)
+    const uint32_t f0 = 0u - (far & 1u), f1 = 0u - ((far >> 1) & 1u), f2 = 0u - ((far >> 2) & 1u), f3 = 0u - ((far >> 3) & 1u);
+    lds_c4 *gp = (lds_c4 *)(strip + gword);            // per lane, 16-byte aligned (GW is a multiple of 4)
+    for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < trips); ++t, gp += GW / 4) {
+        uint32_t w[GW];
+#pragma unroll
+        for (int q = 0; q < GW / 4; ++q) {
+            const u32x4 v = gp[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        uint32_t m[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) m[i] = BITOP3(w[2 * i + 1], GL[i], w[2 * i] ^ GH[i], 0xBE);   // (L ^ GL) | (H ^ GH): base i differs
+        uint32_t c0, c1, c2, c3;
+        count_planes<R>(m, c0, c1, c2, c3);
+        // count <= thr, bit-serially from the low end: e_k = "the low k + 1 bits of count <= those of thr"
+        uint32_t e = BITOP3(c0, t0, t0, 0xCF);          // ~c0 | t0
+        e = BITOP3(c1, t1, e, 0x8E);                    // (~c & t) | (~(c ^ t) & e)
+        e = BITOP3(c2, t2, e, 0x8E);
+        e = BITOP3(c3, t3, e, 0x8E);
+        uint32_t hit = e & w[2 * R];                    // & valid
+        if (c.r_far >= 0) {                             // uniform: count >= far, the same way
+            uint32_t g = BITOP3(c0, f0, f0, 0xF3);      // c0 | ~f0
+            g = BITOP3(c1, f1, g, 0xB2);                // (c & ~f) | (~(c ^ f) & g)
+            g = BITOP3(c2, f2, g, 0xB2);
+            g = BITOP3(c3, f3, g, 0xB2);
+            hit &= g;
+        }
+        if (t >= trips) hit = 0;                        // a lane that is done (its reads ran into a neighbour's groups)
+#ifdef FFH_EXP_NOHIT   // timing experiment: no pair ever hits (results wrong)
+        const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit == 0x12345u && c0 == 77u);
+#else
+        const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit != 0u);
+#endif
+        if (lanes) {   // rare: the lanes with a non-zero mask stage one record per set bit (almost always one)
+            const uint32_t slot0 = ((gabs + t) << 5) | c.side_bit;
+            uint64_t more = lanes;
+            do {
+                c.hs->push(more, hit != 0u, gid, slot0 + (uint32_t)__ffs((int)hit) - 1u);
+                hit &= hit - 1u;
+                more = __builtin_amdgcn_ballot_w64(hit != 0u);
+            } while (more);
+        }
+    }
+}
+
+// batch qq of a side: buckets [b0, b0 + NB) (slice sl of bucket b0 when the side slices its buckets)
+struct BatchId { uint32_t b0, sl; };
+__device__ __forceinline__ BatchId decode_batch(const SideArgs &S, uint32_t qq) {
+    BatchId b;
+    b.sl = qq & ((1u << S.sl_shift) - 1u);
+    b.b0 = (qq >> S.sl_shift) * S.NB;
+    return b;
+}
+
+template <int UNUSED>
+__global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(const CompareArgs A, unsigned long long *__restrict__ cursor) {
+    __shared__ __attribute__((aligned(16))) uint32_t strip_lds[kCmpWaves][kKW + 64];
+    __shared__ __attribute__((aligned(16))) uint2 cand_lds[kCmpWaves][kKC];
+    __shared__ uint32_t gid_lds[kCmpWaves][kKC];
+    __shared__ __attribute__((aligned(16))) uint4 tab_lds[kCmpWaves][2][16];
+    __shared__ uint64_t stage[kCmpWaves][kStage];
+    __shared__ uint32_t inv_lds[kMaxParts + 1];    // ceil(65536 / P): x / P == (x * inv) >> 16 for x < 4096, P <= 16
+    __shared__ unsigned long long blk_pairs[2];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kCmpWaves;
+    const uint32_t *__restrict__ gids = A.gids;
+    if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
+    if (threadIdx.x >= 1 && threadIdx.x <= kMaxParts) inv_lds[threadIdx.x] = (65536u + threadIdx.x - 1u) / threadIdx.x;
+    __syncthreads();
+    HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor};
+    RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
+    unsigned long long pairs[2] = {0, 0};   // per lane (lane i adds bucket i of every batch), reduced once at the end
+
+    // what a batch covers: nbv buckets from b0 on, groups [g0, g1), candidates [c0, c1)
+    struct Extent { uint32_t nbv, b0, g0, g1, c0, c1; };
+
+    // The suffix image's batches come first (they are the heavier ones), then the prefix image's; inside a side the wave takes the
+    // batches q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
+    // describes it stays in scalar registers.
+    for (int side = 1; side >= 0; --side) {
+        const SideArgs S = A.side[side];
+        const uint32_t n_total = S.n_batches;
+        uint32_t q = blockIdx.x * kCmpWaves + wave;
+        if (q >= n_total) continue;
+        const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ bstart = S.bstart, *__restrict__ gwords = S.gwords;
+        const uint2 *__restrict__ gtab = S.gtab;
+        const uint32_t n_slices = 1u << S.sl_shift, GW = (uint32_t)group_words((int)S.rest);
+        rc.r_far = S.r_far;
+        rc.side_bit = (uint32_t)side << 31;
+        rc.width = S.width;
+
+        // ---- the loads of the pipeline.  A batch past the end is an empty one (its loads are skipped). ----
+        // bucket boundaries of batch qq: lane l <= NB holds gstart / istart of bucket b0 + l (clamped to the image's last entry)
+        auto load_desc = [&](uint32_t qq, uint32_t &dG, uint32_t &dI) {
+            dG = 0; dI = 0;
+            if (qq < n_total) {
+                const BatchId b = decode_batch(S, qq);
+                const uint32_t idx = min(b.b0 + min(lane, S.NB), S.nb);
+                dG = gstart[idx];
+                dI = istart[idx];
+            }
+        };
+        auto extent_of = [&](uint32_t qq, uint32_t dG, uint32_t dI) -> Extent {
+            Extent e{0, 0, 0, 0, 0, 0};
+            if (qq < n_total) {
+                const BatchId b = decode_batch(S, qq);
+                e.b0 = b.b0;
+                e.nbv = min(S.NB, S.nb - b.b0);
+                const uint32_t gs = lane_of(dG, 0), ge = lane_of(dG, e.nbv);
+                e.g0 = gs; e.g1 = ge;
+                if (S.sl_shift) {  // one bucket, slice b.sl of it; the last slice takes whatever is left
+                    e.g0 = min(ge, gs + b.sl * S.KS);
+                    e.g1 = (b.sl == n_slices - 1u) ? ge : min(ge, gs + (b.sl + 1) * S.KS);
+                }
+                e.c0 = lane_of(dI, 0); e.c1 = lane_of(dI, e.nbv);
+                if (e.g1 == e.g0) e.c1 = e.c0;   // nothing to compare the candidates with
+            }
+            return e;
+        };
+        // groups [g0, g1) of the image: g * GW words each, contiguous, fetched in 16-byte pieces (the array is padded by kKW + 64 words)
+        auto load_groups = [&](uint32_t g0, uint32_t g1, uint4 (&kreg)[kKeyRegs]) {
+            const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(gwords + (size_t)g0 * GW);
+            const uint32_t nw = (g1 - g0) * GW;
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j)
+                if ((uint32_t)j * 256u < nw) kreg[j] = src[j * 64 + lane];   // uniform predicate
+        };
+        auto load_gids = [&](uint32_t c0, uint32_t c1, uint32_t (&greg)[kGidRegs]) {
+#pragma unroll
+            for (int j = 0; j < kGidRegs; ++j) {
+                const uint32_t c = c0 + (uint32_t)j * 64u + lane;
+                greg[j] = 0;
+                if (c < c1) greg[j] = gids[c];
+            }
+        };
+        auto load_entries = [&](uint32_t c0, uint32_t c1, const uint32_t (&greg)[kGidRegs], uint2 (&ereg)[kGidRegs]) {
+#pragma unroll
+            for (int j = 0; j < kGidRegs; ++j) {
+                const uint32_t c = c0 + (uint32_t)j * 64u + lane;
+                if (c < c1) ereg[j] = gtab[greg[j]];
+            }
+        };
+
+        // parks a piece of the batch -- groups [g0, g1), candidates [c0, c1) -- in the wave's LDS strip and deals its jobs; returns the
+        // number of jobs.  Lane i < nbv: bucket i of the batch (dG / dI: its first group / first candidate, all buckets of the batch)
+        auto park = [&](const Extent &e, uint32_t g0, uint32_t g1, uint32_t c0, uint32_t c1, const uint4 (&kreg)[kKeyRegs], const uint32_t (&greg)[kGidRegs],
+                        const uint2 (&ereg)[kGidRegs], uint32_t dG, uint32_t dI) -> uint32_t {
+            wave_lds_fence();  // the previous piece's reads are done
+            const uint32_t nw = (g1 - g0) * GW;
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j)
+                if ((uint32_t)j * 256u < nw) reinterpret_cast<uint4 *>(strip_lds[wave])[j * 64 + lane] = kreg[j];
+#pragma unroll
+            for (int j = 0; j < kGidRegs; ++j) {
+                const uint32_t c = c0 + (uint32_t)j * 64u + lane;
+                if (c < c1) {
+                    cand_lds[wave][(uint32_t)j * 64u + lane] = ereg[j];
+                    gid_lds[wave][(uint32_t)j * 64u + lane] = greg[j];
+                }
+            }
+            // bucket i: its groups and candidates clipped to the piece; P jobs per candidate
+            const uint32_t nG = row_next(dG), nI = row_next(dI);
+            uint32_t bg0 = dG, bg1 = nG;
+            if (S.sl_shift) { bg0 = e.g0; bg1 = e.g1; }   // (one bucket: its slice)
+            const uint32_t lo_g = min(max(bg0, g0), g1), hi_g = min(max(bg1, g0), g1);
+            const uint32_t lo_c = min(max(dI, c0), c1), hi_c = min(max(nI, c0), c1);
+            const bool act = lane < e.nbv;
+            const uint32_t ngr = act ? hi_g - lo_g : 0u, ng = (act && ngr) ? hi_c - lo_c : 0u;
+            uint32_t P = (ngr + (uint32_t)kGroupsPerLane / 2u) / (uint32_t)kGroupsPerLane;   // ~ ngr / 6, rounded
+            P = min(max(P, 1u), (uint32_t)kMaxParts);
+            const uint32_t per = ngr ? (ngr + P - 1u) / P : 0u;                                // (small integer divisions, once per batch)
+            const uint32_t jobs = ng * P;
+            uint32_t incl = jobs;   // inclusive scan over the row of 16 lanes
+            incl += row_prev<1>(incl);
+            incl += row_prev<2>(incl);
+            incl += row_prev<4>(incl);
+            incl += row_prev<8>(incl);
+            if (lane < 16) {
+                tab_lds[wave][0][lane] = make_uint4(incl - jobs, lo_c - c0, ng, P);
+                tab_lds[wave][1][lane] = make_uint4((lo_g - g0) * GW, ngr, per, lo_g);
+            }
+            wave_lds_fence();
+            return lane_of(incl, 15);
+        };
+
+        // every row of the parked piece's jobs
+        auto rows = [&](const Extent &e, uint32_t n_jobs) {
+            const uint32_t js = lane < 16 ? tab_lds[wave][0][lane].x : 0xFFFFFFFFu;   // first job of bucket `lane`
+            for (uint32_t j0 = 0; j0 < n_jobs; j0 += 64) {
+                const uint32_t J = j0 + lane;
+                uint32_t i = 0;
+                for (uint32_t k = 1; k < e.nbv; ++k) i += (J >= lane_of(js, k)) ? 1u : 0u;   // the bucket of job J
+                const uint4 ta = tab_lds[wave][0][i], tb = tab_lds[wave][1][i];
+                const uint32_t jj = J - ta.x, P = ta.w;
+                const uint32_t k = (jj * inv_lds[P]) >> 16, p = jj - k * P;                   // candidate k of the bucket, part p of it
+                const bool valid = J < n_jobs;
+                const uint32_t slot = min(ta.y + k, (uint32_t)kKC - 1u);
+                const uint2 cand = cand_lds[wave][slot];
+                const uint32_t gid = gid_lds[wave][slot];
+                const uint32_t g_lo = p * tb.z;
+                uint32_t trips = 0;
+                if (valid && g_lo < tb.y) trips = min(tb.z, tb.y - g_lo);
+                const uint32_t x = cand.y ^ (e.b0 + i);
+                const uint32_t d = (uint32_t)__popc(((x >> rc.width) | x) & ((1u << rc.width) - 1u));   // mismatches inside the bucket key
+                const uint32_t gword = tb.x + g_lo * GW, gabs = tb.w + g_lo;
+                switch (S.rest) {   // uniform
+                    case 8: scan_row<8>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    case 9: scan_row<9>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    case 10: scan_row<10>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    case 11: scan_row<11>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    default: scan_row<12>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                }
+            }
+        };
+
+        // ---- prologue: boundaries of three batches, candidate ids of two, groups and guide entries of the first ----
+        uint32_t dG0, dI0, dG1, dI1, dG2, dI2;
+        load_desc(q, dG0, dI0);
+        load_desc(q + n_waves, dG1, dI1);
+        load_desc(q + 2 * n_waves, dG2, dI2);
+        uint4 kreg[kKeyRegs];
+        uint32_t greg_a[kGidRegs], greg_b[kGidRegs];
+        uint2 ereg[kGidRegs];
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) kreg[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < kGidRegs; ++j) { ereg[j] = make_uint2(0, 0); greg_a[j] = 0; greg_b[j] = 0; }
+        const uint32_t cap_g = (uint32_t)kKW / GW;   // groups the strip holds
+        {
+            const Extent e0 = extent_of(q, dG0, dI0), e1 = extent_of(q + n_waves, dG1, dI1);
+            load_gids(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a);
+            load_gids(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_b);
+            load_groups(e0.g0, min(e0.g1, e0.g0 + cap_g), kreg);
+            load_entries(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a, ereg);
+        }
+        for (; q < n_total; q += n_waves) {
+            const Extent e = extent_of(q, dG0, dI0);
+            // the targets of the batch's buckets, for the executed-pair statistics (used at the end of the batch)
+            uint32_t dB = 0;
+            { const BatchId b = decode_batch(S, q); dB = bstart[min(b.b0 + min(lane, S.NB), S.nb)]; }
+            const bool fits = e.g1 - e.g0 <= cap_g && e.c1 - e.c0 <= (uint32_t)kKC, work = e.c1 > e.c0;
+            uint32_t n_jobs = 0;
+            // everything requested a batch ago has arrived (the compiler's waits cover it): park it
+            if (fits && work) n_jobs = park(e, e.g0, e.g1, e.c0, e.c1, kreg, greg_a, ereg, dG0, dI0);
+            if (!fits && work) {
+                // A batch that does not fit the strip (a repeat family's bucket, a skewed guide set) is done in pieces of cap_g groups x kKC
+                // candidates fetched on the spot, through the same registers: correct for any input, the common case never does it.
+                for (uint32_t t0 = e.g0; t0 < e.g1; t0 += cap_g) {
+                    const uint32_t t1 = min(e.g1, t0 + cap_g);
+                    load_groups(t0, t1, kreg);
+                    for (uint32_t c0 = e.c0; c0 < e.c1; c0 += kKC) {
+                        const uint32_t c1 = min(e.c1, c0 + (uint32_t)kKC);
+                        load_gids(c0, c1, greg_a);
+                        load_entries(c0, c1, greg_a, ereg);
+                        const uint32_t nj = park(e, t0, t1, c0, c1, kreg, greg_a, ereg, dG0, dI0);
+                        rows(e, nj);
+                    }
+                }
+            }
+            // ---- request what the next batches need: boundaries of batch +3, candidate ids of +2, guide entries and groups of +1 ----
+            uint32_t dG3, dI3;
+            load_desc(q + 3 * n_waves, dG3, dI3);
+            const Extent e1 = extent_of(q + n_waves, dG1, dI1), e2 = extent_of(q + 2 * n_waves, dG2, dI2);
+#pragma unroll
+            for (int j = 0; j < kGidRegs; ++j) greg_a[j] = greg_b[j];
+            load_gids(e2.c0, min(e2.c1, e2.c0 + (uint32_t)kKC), greg_b);
+            load_entries(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_a, ereg);
+            load_groups(e1.g0, min(e1.g1, e1.g0 + cap_g), kreg);
+            // ---- compute this batch out of LDS ----
+            if (n_jobs) rows(e, n_jobs);
+            {   // executed pair tests: every target of a bucket against every candidate of it (lane i: bucket i; a sliced bucket
+                // counts in its first slice)
+                const uint32_t nt = row_next(dB) - dB, ng = row_next(dI0) - dI0;
+                if (lane < e.nbv && (!S.sl_shift || (q & (n_slices - 1u)) == 0)) pairs[side] += (unsigned long long)nt * ng;
+            }
+            dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
+        }
+    }
+    if (hs.fill) hs.flush();
+    if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);   // lanes 0 .. NB - 1 carry something
+    if (pairs[1]) atomicAdd(&blk_pairs[1], pairs[1]);
+    __syncthreads();
+    // 64 x 2 counters instead of 2: atomics on ONE address complete at ~90 per microsecond
+    if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(cursor + kPairSlotBase + (blockIdx.x & (kPairSlots - 1)) * 2 + threadIdx.x, blk_pairs[threadIdx.x]);
+}
+
+}  // namespace ffh

@@ -40,6 +40,16 @@ __host__ __device__ __forceinline__ uint64_t planar_key(uint64_t enc, int c0, in
     return ((uint64_t)hi << 32) | lo;
 }
 
+// rest key of a target / guide on one side: the planes of the bases its bucket id does NOT hold, H << 16 | L (<= 12 bases each).
+// Prefix image (bucket = first a bases): the last lc - a bases; suffix image (bucket = last s bases): the first lc - s bases.
+__host__ __device__ __forceinline__ uint32_t prefix_rest_key(uint64_t pk, int lc, int a) {
+    const uint32_t m = (1u << (lc - a)) - 1u;
+    return ((((uint32_t)(pk >> 32)) & m) << 16) | ((uint32_t)pk & m);
+}
+__host__ __device__ __forceinline__ uint32_t suffix_rest_key(uint64_t pk, int s) {
+    return (((uint32_t)(pk >> 32) >> s) << 16) | ((uint32_t)pk >> s);
+}
+
 // bucket id over the first `a` compared bases / over the last `s` compared bases
 __host__ __device__ __forceinline__ uint32_t prefix_bucket(uint64_t pk, int lc, int a) {
     if (a == 0) return 0;
@@ -73,22 +83,56 @@ __global__ void k_image_hist(const uint64_t *__restrict__ targets, uint64_t n, G
 
 template <bool SUFFIX>
 __global__ void k_image_scatter(const uint64_t *__restrict__ targets, uint64_t n, Geometry geo, int width,
-                                const uint32_t *__restrict__ bstart, uint32_t *__restrict__ bfill, uint64_t *__restrict__ keys,
+                                const uint32_t *__restrict__ bstart, uint32_t *__restrict__ bfill, uint32_t *__restrict__ keys,
                                 uint32_t *__restrict__ tidx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t pk = planar_key(targets[i], geo.c0, geo.lc);
     const uint32_t b = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
     const uint32_t pos = bstart[b] + atomicAdd(&bfill[b], 1u);
-    keys[pos] = pk;
+    keys[pos] = SUFFIX ? suffix_rest_key(pk, width) : prefix_rest_key(pk, geo.lc, width);   // the bucket holds the other bases
     tidx[pos] = (uint32_t)i;
+}
+
+// The image the compare kernel reads: the targets of a bucket in GROUPS of 32, bit-sliced (ffh_compare.hpp).  A group is GW words:
+// word 2i = the high plane bit of rest base i of its 32 targets, word 2i + 1 = the low plane bit, word 2R = which of the 32
+// slots hold a target; the database index of slot s of group g is tidx[32 g + s].
+__global__ void k_group_count(const uint32_t *__restrict__ bstart, uint32_t nb, uint32_t *__restrict__ gcount) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) gcount[b] = (bstart[b + 1] - bstart[b] + 31u) >> 5;
+}
+// one wave per bucket; 64 targets (two groups) per step, transposed with ballots
+__global__ __launch_bounds__(256) void k_group_build(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ keys,
+                                                     const uint32_t *__restrict__ tidx_in, uint32_t nb, uint32_t R, uint32_t GW, uint32_t *__restrict__ gwords,
+                                                     uint32_t *__restrict__ tidx_out) {
+    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const uint32_t k0 = bstart[b], nt = bstart[b + 1] - k0, g0 = gstart[b], ngr = gstart[b + 1] - g0;
+    for (uint32_t c = 0; 2 * c < ngr; ++c) {
+        const uint32_t k = c * 64 + lane;
+        const bool valid = k < nt;
+        const uint32_t key = valid ? keys[k0 + k] : 0u;
+        if (2 * c + (lane >> 5) < ngr) tidx_out[(size_t)(g0 + 2 * c) * 32 + lane] = valid ? tidx_in[k0 + k] : 0xFFFFFFFFu;
+        uint64_t mine = 0;   // lane w collects word w of the two groups (low / high half of the ballot)
+        for (uint32_t i = 0; i < R; ++i) {
+            const uint64_t h = __ballot((key >> (16 + i)) & 1u), l = __ballot((key >> i) & 1u);
+            if (lane == 2 * i) mine = h;
+            if (lane == 2 * i + 1) mine = l;
+        }
+        const uint64_t v = __ballot(valid);
+        if (lane == 2 * R) mine = v;
+        if (lane < GW) {
+            gwords[(size_t)(g0 + 2 * c) * GW + lane] = (uint32_t)mine;
+            if (2 * c + 1 < ngr) gwords[(size_t)(g0 + 2 * c + 1) * GW + lane] = (uint32_t)(mine >> 32);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // candidate lists: every guide visits the buckets inside its Hamming ball (key ^ pattern)
 // ---------------------------------------------------------------------------------------------------------
 template <bool SUFFIX>
-__global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Geometry geo, int width, uint64_t *__restrict__ gkey,
+__global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Geometry geo, int width, uint2 *__restrict__ gtab,
                              uint32_t *__restrict__ gbucket, uint32_t *__restrict__ seg_begin /* nullable */, uint32_t *__restrict__ seg_end,
                              uint32_t *__restrict__ zero_buf, uint32_t n_zero) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,12 +140,13 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
     if (g >= n) return;
     if (seg_begin) { seg_begin[g] = 0u; seg_end[g] = 0u; }  // the hit segment of a guide without hits (k_segments only visits the others)
     const uint64_t pk = planar_key(guides[g], geo.c0, geo.lc);
-    gkey[g] = pk;
-    gbucket[g] = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
+    const uint32_t b = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
+    gbucket[g] = b;
+    gtab[g] = make_uint2(SUFFIX ? suffix_rest_key(pk, width) : prefix_rest_key(pk, geo.lc, width), b);  // what the compare kernel gathers per candidate
 }
 
-// Candidate lists in CSR form: for every bucket the ids of the guides whose Hamming ball reaches it (the 8-byte planar
-// guide keys stay in a table small enough to live in L2 and are gathered by the compare kernel).  The
+// Candidate lists in CSR form: for every bucket the ids of the guides whose Hamming ball reaches it (the guides' {rest key,
+// bucket} entries stay in a table small enough to live in L2 and are gathered by the compare kernel).  The
 // (bucket, guide) entries are enumerated implicitly (bucket = guide bucket ^ pattern) and binned EXACTLY -- no
 // capacity guess, so skewed guide sets (tiling libraries, repeats) cost nothing extra -- and without per-entry global
 // atomics (device-scope atomics on random addresses run at ~1.3e10/s on MI355X: 4 ms for the 5.6e7 entries of the
@@ -304,349 +349,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__
     }
 }
 
-constexpr int kTileTargets = 256;  // targets per work item (a bucket, or a 256-target slice of a large bucket)
-constexpr int kTileChunks = kTileTargets / 64;
-
-__global__ void k_tile_count(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, uint32_t n_buckets,
-                             uint32_t *__restrict__ tcount) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_buckets) return;
-    const uint32_t nt = bstart[b + 1] - bstart[b];
-    tcount[b] = (istart[b + 1] != istart[b]) ? (nt + kTileTargets - 1) / kTileTargets : 0;
-}
-
-// work item ("tile") = {first key, #keys | side << 31, first candidate, #candidates}; the items of both images share
-// one list so that ONE compare launch covers the prefix and the suffix pass
-__global__ void k_tile_fill(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ istart, const uint32_t *__restrict__ tstart,
-                            uint32_t n_buckets, const uint32_t *__restrict__ tile_base, uint32_t side, uint4 *__restrict__ tiles) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_buckets) return;
-    const uint32_t t0 = tstart[b], nt = tstart[b + 1] - t0;
-    if (!nt) return;
-    const uint32_t k0 = bstart[b], kn = bstart[b + 1] - k0, g0 = istart[b], gn = istart[b + 1] - g0;
-    uint4 *out = tiles + *tile_base + t0;
-    for (uint32_t c = 0; c < nt; ++c) {
-        const uint32_t kb = c * kTileTargets;
-        out[c] = make_uint4(k0 + kb, min(kn - kb, (uint32_t)kTileTargets) | (side << 31), g0, gn);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// THE HOT KERNEL.  One wave owns one work item at a time: <= 256 targets of one bucket (streamed coalesced from the
-// scan image) against that bucket's candidate guides.  The kernel is latency-, not bandwidth-bound unless every
-// load is issued a whole item ahead (HBM round trips under load are ~10x the compute of one item), hence the
-// three-deep software pipeline:
-//      item i+3: descriptor (scalar load)           item i+2: slot row = candidate guide ids (one coalesced load)
-//      item i+1: planar guide keys (gather from the L2-resident table) + all target keys (<= 4 coalesced loads)
-//      item i  : computed entirely out of the wave's LDS strip -- no global access in the loops at all.
-//   * candidates are read back as LDS broadcasts: 4 VALU per (guide, 64 targets): v_xor, v_bitop3 (xor|or), v_bcnt,
-//     v_cmp -- no readlane, no memory wait;
-//   * short chunks (the <= 32 / 16 / 8 target tail of a bucket) are replicated 2 / 4 / 8 times across the wave and
-//     tested against 2 / 4 / 8 different guides per step, so the tail does not waste the lanes;
-//   * a hit is staged as (guide, side, position in the image), so the hot loop never waits on memory even when it hits;
-//   * hits are compacted with ballot + mbcnt into a per-wave LDS staging buffer and flushed with ONE global atomic
-//     per ~200 hits (a single global cursor saturates far below the hit rate); the flush looks the database index up and
-//     writes the final sort key (guide << tbits) | index.
-//   Suffix-image items: the same pair can only also be found through the prefix image when its prefix part has
-//   <= r1 mismatches, so it is emitted from a suffix item only if the prefix part has MORE than r1.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kCmpThreads = 256;
-// staged hits per wave.  Every flush is one atomic on the one global hit cursor, and same-address atomics complete at ~88 per
-// microsecond on this part: at 5 mismatches (1.1e8 hits) the launch time WAS the flush count (11.6 ms with 192 entries, 7.8 ms with
-// 280, 7.6 ms with 360).  360 entries leave room for seven blocks per CU (4 x 360 x 8 B + 11 KB of keys each, 160 KB of LDS);
-// same-box sweep at 4 / 5 mismatches: 192 -> 1.90 / 11.6 ms, 280 (eight blocks) -> 1.87 / 7.9, 360 -> 1.86 / 7.6, 480 (six blocks)
-// -> 1.98 / 8.0, 640 (five) -> 2.19 / 8.8.
-constexpr int kStage = 360;
-
-constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
-constexpr uint32_t kTileStatBase = 13;  // cursor[13], cursor[14]: work items of the prefix / suffix image in this launch
-constexpr uint32_t kFlushArgBase = kPairSlotBase + 2 * kPairSlots;  // FlushArgs of the current launch live behind them
-// What a wave needs only when it empties its staged hits (once per ~130 hits).  It is read from device memory at that point
-// instead of being kernel arguments: as arguments the twelve scalars stay live through the whole hot loop, and the register
-// allocator pays for them by spilling the item descriptors of the software pipeline to VGPR lanes on every item.
-struct FlushArgs {
-    uint64_t *hits;
-    uint64_t cap;
-    const uint32_t *tidx_p, *tidx_s;
-    uint32_t guide_base;  // first guide of this batch
-    int tbits;            // hit key = (global guide << tbits) | database index
-};
-static_assert(sizeof(FlushArgs) == 40, "FlushArgs is stored as five 64-bit words");
-struct CompareArgs {
-    const uint4 *tiles;
-    const uint32_t *n_tiles_a, *n_tiles_b;
-    const uint64_t *keys[2];
-    const uint32_t *slots;
-    const uint64_t *gkey;
-    int max_mm;
-    uint32_t prefix_mask;
-    int r1;
-    unsigned long long *cursor;  // [0] hit cursor; [kPairSlotBase + 2 * slot + side] executed pair tests, summed by the host; [kFlushArgBase ..] FlushArgs
-};
-
-// before every compare launch: clears the per-launch pair counters and stores the launch's FlushArgs (one launch in place of a memset)
-__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, FlushArgs f, int first_batch) {
-    if (first_batch && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // hit cursor and the zero word: once per scan, they run across batches
-    if (threadIdx.x < 2 * kPairSlots) cursor[kPairSlotBase + threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) *reinterpret_cast<FlushArgs *>(cursor + kFlushArgBase) = f;
-}
-
-struct HitStage {
-    uint64_t *my;
-    uint32_t fill;
-    uint32_t lane;
-    unsigned long long *cursor;
-
-    __device__ __forceinline__ void flush() {
-        // five wave-uniform words, moved to scalar registers so they do not raise the vector register count of the hot loop
-        const unsigned long long *q = cursor + kFlushArgBase;
-        auto uni = [](unsigned long long v) -> unsigned long long {
-            return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);  // the builtin returns int
-        };
-        FlushArgs f;
-        f.hits = (uint64_t *)uni(q[0]); f.cap = uni(q[1]); f.tidx_p = (const uint32_t *)uni(q[2]); f.tidx_s = (const uint32_t *)uni(q[3]);
-        const unsigned long long gb = uni(q[4]);
-        f.guide_base = (uint32_t)gb; f.tbits = (int)(gb >> 32);
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)fill);
-        base = __shfl(base, 0, 64);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // staged record = (batch-local guide << 32) | side << 31 | position in that side's image; it leaves as the sort key
-        // (global guide << tbits) | database index -- the lookup rides on the flush instead of a pass of its own over all hits
-        for (uint32_t i = lane; i < fill; i += 64)
-            if (base + i < f.cap) {
-                const uint64_t h = my[i];
-                const uint32_t lo = (uint32_t)h, pos = lo & 0x7FFFFFFFu;
-                const uint32_t ti = (lo >> 31) ? f.tidx_s[pos] : f.tidx_p[pos];
-                f.hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + f.guide_base) << f.tbits) | ti;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        fill = 0;
-    }
-    // wave-uniform call: `mask` = ballot of `hit`; every hitting lane records (candidate guide id, position)
-    __device__ __forceinline__ void push(uint64_t mask, bool hit, const uint32_t *gid_lds, uint32_t idx, uint32_t pos) {
-        if (hit) my[fill + mbcnt(mask)] = ((uint64_t)gid_lds[idx] << 32) | pos;
-        fill += (uint32_t)__popcll(mask);
-        if (fill > kStage - 64) flush();  // always leave room for one more wave-wide batch (the predicate never lives across the flush)
-    }
-};
-
-struct WaveCtx {  // per-wave state shared by the chunk loops
-    const CompareArgs *a;
-    HitStage *hs;
-    const uint64_t *key_lds;  // the item's target keys
-    const uint64_t *gk_lds;   // 64 candidate keys (sentinel beyond n)
-    const uint32_t *gid_lds;  // 64 candidate guide ids
-    uint32_t lane;
-    uint32_t side_bit;         // side << 31, or'ed into the recorded position
-    uint32_t pm;               // suffix item: the prefix part of the comparison mask; prefix item: 0
-    int r1s;                   // suffix item: r1; prefix item: -1
-};
-
-// one 64-lane step against W guides at once; `cnt` <= 64 / W targets, key_lds[koff ..], image position pos0 + ..
-// CHECK: max_mm is too large for the sentinel to be safe, test the candidate index explicitly
-// FULL: all 64 lanes have a target (W == 1 only): no validity mask, no substitute key
-template <int W, bool CHECK, bool FULL = false>
-__device__ __forceinline__ void scan_chunk(const WaveCtx &w, uint32_t koff, uint32_t pos0, uint32_t cnt, uint32_t n) {
-    static_assert(!FULL || W == 1, "a full chunk is 64 targets wide");
-    constexpr uint32_t SUB = 64 / W;
-    const uint32_t tl = w.lane & (SUB - 1), gs = w.lane / SUB;
-    const bool valid = FULL ? true : tl < cnt;
-    // lanes without a target carry the all-ones key: it differs from every candidate (real or sentinel) in >= 12 bits
-    const uint64_t k = valid ? w.key_lds[koff + tl] : ~0ull;
-    const uint32_t kh = (uint32_t)(k >> 32), kl = (uint32_t)k;
-    const uint32_t max_mm = (uint32_t)w.a->max_mm;
-    const uint32_t iters = (n + W - 1) / W;
-    // the hit predicate stays a lane mask from the compare to the staged store: a candidate without a hit costs one vector
-    // compare and one scalar branch
-    auto report = [&](uint32_t p, uint32_t y, uint32_t idx) {
-        bool h = p <= max_mm;
-        if (CHECK) h = h && valid && idx < n;  // the sentinels are not safe for max_mm >= 12
-        const uint64_t m1 = __builtin_amdgcn_ballot_w64(h);
-        if (!m1) return;
-        // suffix items keep a pair only if its prefix part has more than r1 mismatches; prefix items run the same three
-        // instructions with pm = 0, r1s = -1 (always true) instead of a branch that would park the predicate in a VGPR
-        const bool far = (int)__popc(y & w.pm) > w.r1s;
-        const uint64_t m = m1 & __builtin_amdgcn_ballot_w64(far);  // the two lane masks meet on the scalar side
-        if (m) w.hs->push(m, h && far, w.gid_lds, idx, (pos0 + tl) | w.side_bit);
-    };
-    // four candidates per step; ONE vector compare and ONE scalar branch decide whether any of the 256 pairs is within
-    // max_mm (the scalar unit is shared by the CU's four SIMDs: mask algebra per pair would make it the bottleneck)
-    // the loop variable is the LDS address of the group's first candidate key (one add, one compare, one branch of loop control
-    // per group of four); the candidate index is only derived from it when something hit
-    typedef __attribute__((address_space(3))) const uint64_t lds_key;  // 32-bit LDS addresses: the loop control stays in single registers
-    auto dist_at = [&](lds_key *gp, uint32_t &y) -> uint32_t {
-        const uint64_t g = *gp;
-        y = __builtin_amdgcn_bitop3_b32((uint32_t)g, kh ^ (uint32_t)(g >> 32), kl, 0xde);  // (gl ^ kl) | (gh ^ kh)
-        return (uint32_t)__popc(y);
-    };
-    if constexpr (W == 1) {
-        // full-width chunks (all of the suffix image, the first chunk of most prefix buckets): the candidate address is wave-uniform,
-        // so it is the loop variable itself -- one add, one compare, one branch of loop control per group of four
-        lds_key *const gbase = (lds_key *)w.gk_lds;
-        lds_key *gp = gbase, *const g4 = gbase + (iters & ~3u), *const ge = gbase + iters;
-        for (; gp != g4; gp += 4) {
-            uint32_t y0, y1, y2, y3;
-            const uint32_t p0 = dist_at(gp, y0), p1 = dist_at(gp + 1, y1), p2 = dist_at(gp + 2, y2), p3 = dist_at(gp + 3, y3);
-            const uint32_t best = min(min(p0, p1), min(p2, p3));
-            if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
-                const uint32_t i0 = (uint32_t)(gp - gbase);
-                report(p0, y0, i0);
-                report(p1, y1, i0 + 1);
-                report(p2, y2, i0 + 2);
-                report(p3, y3, i0 + 3);
-            }
-        }
-        for (; gp != ge; ++gp) {
-            uint32_t y;
-            const uint32_t p = dist_at(gp, y);
-            if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, (uint32_t)(gp - gbase));
-        }
-    } else {
-        lds_key *const gbase = (lds_key *)w.gk_lds;
-        uint32_t j = 0;
-        for (; j + 4 <= iters; j += 4) {
-            uint32_t y0, y1, y2, y3;
-            const uint32_t i0 = j * W + gs, i1 = i0 + W, i2 = i0 + 2 * W, i3 = i0 + 3 * W;
-            const uint32_t p0 = dist_at(gbase + i0, y0), p1 = dist_at(gbase + i1, y1), p2 = dist_at(gbase + i2, y2), p3 = dist_at(gbase + i3, y3);
-            const uint32_t best = min(min(p0, p1), min(p2, p3));
-            if (__builtin_amdgcn_ballot_w64(best <= max_mm)) {
-                report(p0, y0, i0);
-                report(p1, y1, i1);
-                report(p2, y2, i2);
-                report(p3, y3, i3);
-            }
-        }
-        for (; j < iters; ++j) {
-            uint32_t y;
-            const uint32_t i0 = j * W + gs;
-            const uint32_t p = dist_at(gbase + i0, y);
-            if (__builtin_amdgcn_ballot_w64(p <= max_mm)) report(p, y, i0);
-        }
-    }
-}
-
-// the read-only streams are separate __restrict__ kernel parameters (noalias lets the compiler keep the descriptor
-// loads on the scalar unit and reorder the vector loads around the hit stores)
-template <bool CHECK>
-__global__ __launch_bounds__(kCmpThreads, 7) void k_compare(const uint4 *__restrict__ tiles, const uint64_t *__restrict__ keys_p,
-                                                         const uint64_t *__restrict__ keys_s, const uint32_t *__restrict__ slots,
-                                                         const uint64_t *__restrict__ gkey, const CompareArgs a) {
-    __shared__ uint64_t stage[kCmpThreads / 64][kStage];
-    __shared__ uint64_t key_lds[kCmpThreads / 64][kTileTargets];
-    __shared__ uint64_t gk_lds[kCmpThreads / 64][64];
-    __shared__ uint32_t gid_lds[kCmpThreads / 64][64];
-    __shared__ unsigned long long blk_pairs[2];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kCmpThreads / 64);
-    const uint32_t n_tiles = *a.n_tiles_a + *a.n_tiles_b;
-    if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
-    // the work-item counts ride back to the host in the counter block (one copy after the launch instead of three)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { a.cursor[kTileStatBase] = *a.n_tiles_a; a.cursor[kTileStatBase + 1] = *a.n_tiles_b; }
-    __syncthreads();
-    HitStage hs{stage[wave], 0u, lane, a.cursor};
-    unsigned long long pairs[2] = {0, 0};
-    // padding candidate: the 12 unused high bits of both planes set, the 20 used ones clear.  It differs from every real
-    // key in those 12 bits and from the all-ones key of an idle lane in the 20 low ones: never within max_mm < 12
-    const uint64_t sentinel = 0xFFF00000FFF00000ull;
-    WaveCtx w{&a, &hs, key_lds[wave], gk_lds[wave], gid_lds[wave], lane, 0u, 0u, -1};
-
-    uint32_t t = blockIdx.x * (kCmpThreads / 64) + wave;
-    if (t >= n_tiles) goto done;
-    {
-        // every load below is unconditional with a clamped index (straight-line code lets the compiler count
-        // outstanding loads exactly instead of draining the queue)
-        // descriptors past the end are replaced by the last one (its loads are harmless and never consumed)
-        auto load_desc = [&](uint32_t ti) -> uint4 { return tiles[min(ti, n_tiles - 1)]; };
-        // uniform base pointer + small per-lane index: the loads use the scalar-base addressing form
-        auto load_gid = [&](const uint4 &d) -> uint32_t { return (slots + d.z)[min(lane, max(d.w, 1u) - 1u)]; };
-        auto load_key = [&](const uint4 &d, uint32_t c) -> uint64_t {
-            const uint32_t kc = d.y & 0x7FFFFFFFu;
-            const uint64_t *__restrict__ kp = ((d.y >> 31) ? keys_s : keys_p) + d.x;
-            return kp[min(c * 64u + lane, max(kc, 1u) - 1u)];
-        };
-        // prologue
-        uint4 d0 = load_desc(t), d1 = load_desc(t + n_waves), d2 = load_desc(t + 2 * n_waves);
-        uint32_t gid0 = load_gid(d0), gid1 = load_gid(d1);
-        uint64_t gk0 = gkey[gid0];
-        uint64_t k0[kTileChunks];
-#pragma unroll
-        for (int c = 0; c < kTileChunks; ++c) k0[c] = load_key(d0, c);
-
-        while (t < n_tiles) {
-            const uint4 cur = d0;
-            const uint32_t side = cur.y >> 31;  // wave-uniform
-            const uint32_t kcnt = cur.y & 0x7FFFFFFFu, ng = cur.w;
-            // ---- stage A: park item i in the LDS strip (waits for everything requested one item ago) ----
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            gk_lds[wave][lane] = (lane < ng) ? gk0 : sentinel;
-            gid_lds[wave][lane] = gid0;
-#pragma unroll
-            for (int c = 0; c < kTileChunks; ++c) key_lds[wave][c * 64 + lane] = k0[c];
-            // ---- stage B: request item i+1 (guide keys, target keys), i+2 (slot row), i+3 (descriptor) ----
-            const uint4 d3 = load_desc(t + 3 * n_waves);
-            const uint32_t gid2 = load_gid(d2);
-            gk0 = gkey[gid1];
-#pragma unroll
-            for (int c = 0; c < kTileChunks; ++c) k0[c] = load_key(d1, c);
-            gid0 = gid1; gid1 = gid2;
-            d0 = d1; d1 = d2; d2 = d3;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- stage C: compute item i out of LDS ----
-            w.pm = side ? a.prefix_mask : 0u;
-            w.r1s = side ? a.r1 : -1;
-            w.side_bit = side << 31;
-            pairs[side] += (unsigned long long)kcnt * ng;
-            for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
-                if (g0) {  // rows longer than 64 candidates (rare): fetch the next 64 in place
-                    const uint32_t gi = slots[cur.z + min(g0 + lane, ng - 1)];
-                    const uint64_t gk = gkey[gi];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    gk_lds[wave][lane] = (g0 + lane < ng) ? gk : sentinel;
-                    gid_lds[wave][lane] = gi;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                const uint32_t n = min(ng - g0, 64u);
-                for (uint32_t c = 0; c < kcnt; c += 64) {
-                    const uint32_t cnt = min(kcnt - c, 64u);
-                    if (cnt == 64) {
-                        scan_chunk<1, CHECK, true>(w, c, cur.x + c, cnt, n);
-                    } else {
-                        // the tail of a bucket: the candidate count goes through an opaque register so that the trip counts of the
-                        // four packings are worked out here, for the one that runs, and not hoisted in front of every item's chunk loop
-                        uint32_t nt = n;
-                        asm volatile("" : "+s"(nt));
-                        if (cnt > 32) scan_chunk<1, CHECK>(w, c, cur.x + c, cnt, nt);
-                        else if (cnt > 16) scan_chunk<2, CHECK>(w, c, cur.x + c, cnt, nt);
-                        else if (cnt > 8) scan_chunk<4, CHECK>(w, c, cur.x + c, cnt, nt);
-                        else scan_chunk<8, CHECK>(w, c, cur.x + c, cnt, nt);
-                    }
-                }
-            }
-            t += n_waves;
-        }
-    }
-done:
-    if (hs.fill) hs.flush();
-    if (lane == 0) {
-        if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);
-        if (pairs[1]) atomicAdd(&blk_pairs[1], pairs[1]);
-    }
-    __syncthreads();
-    // 64 x 2 counters instead of 2: atomics on ONE address complete at ~90 per microsecond, and 16 384 blocks reporting to the
-    // same two words held every launch for ~0.2 ms after its last block had finished (visible as the whole compare time of small calls)
-    if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(a.cursor + kPairSlotBase + (blockIdx.x & (kPairSlots - 1)) * 2 + threadIdx.x, blk_pairs[threadIdx.x]);
-}
+// (the compare kernel lives in ffh_compare.hpp)
 
 // ---------------------------------------------------------------------------------------------------------
 // epilogue: ordered cut-off (crispr/CRISPRSiteOT.scala:39-46) + per-hit scores + per-guide aggregates.
