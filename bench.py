@@ -101,8 +101,31 @@ def measure_traffic(args):
 
 _CPU_MT = None
 _CPU_JVM = None
-VALU_CYCLES = 4.0      # cycles an integer wave64 VALU instruction occupies its SIMD (tools/ubench/valu_ubench.hip)
-PAIR_TEST_VALU = 3.75  # v_xor + v_bitop3 + v_bcnt per pair row, + 3 v_min3 per 8 rows... and one v_cmp per 8 (the ubench loop)
+# Issue model of the compare kernel (tools/ubench/op_rate.hip measures the rates): a wave64 VALU instruction
+# occupies its SIMD for ~2.8 cycles if it is one of the full-rate integer operations (v_xor, v_or, v_add, shifts, v_bitop3) and for
+# ~4.4 otherwise (v_bcnt, v_min*, v_cmp, SDWA / DPP forms, scalar-register operands).  The bit-sliced pair test is made of
+# full-rate operations only.
+VALU_CYCLES_FULL_RATE = 2.8
+VALU_CYCLES_HALF_RATE = 4.4
+
+
+def pair_step_valu(rest_bases, far):
+    """VALU instructions of one bit-sliced step (64 lanes x 32 targets = 2048 pair tests) with `rest_bases` bases outside the bucket
+    id: two per base for the mismatch words, the carry-save adder tree (one v_bitop3 per sum / per carry), four for count <= budget,
+    one for the valid word, four more for count > r1 on the suffix image"""
+    n, ops = [rest_bases, 0, 0, 0], 0
+    for lv in range(4):
+        while n[lv] >= 3:
+            n[lv] -= 2
+            ops += 2 if lv < 3 else 1
+            if lv < 3:
+                n[lv + 1] += 1
+        if n[lv] == 2:
+            n[lv] = 1
+            ops += 2 if lv < 3 else 1
+            if lv < 3:
+                n[lv + 1] += 1
+    return 2 * rest_bases + ops + 5 + (5 if far else 0)
 
 
 def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single_rate, filt, per_bin):
@@ -486,12 +509,18 @@ def main():
             traffic_note = {"fetch_size_kib": pmc["fetch_kib"], "write_size_kib": pmc["write_kib"], "fetch_scale_from_calibration": scale,
                             "calibration": "ffh::k_image_hist reads 8 B per target with the same coalesced 8-byte loads; WRITE_SIZE uncalibrated"}
         sq = {k: pmc[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if pmc and k in pmc}
-        # issue model: an integer wave64 VALU instruction occupies its SIMD for VALU_CYCLES cycles (tools/ubench/valu_ubench.hip
-        # measures it); 256 CUs x 4 SIMDs issue slots.  valu_issue_frac = all VALU instructions of the launch against that peak,
-        # useful_valu_frac = the pair tests alone (PAIR_TEST_VALU instructions per 64 pairs).
+        # 256 CUs x 4 SIMDs issue VALU instructions.  valu_issue_frac: ALL VALU instructions of the launch (PMC) against that peak, priced
+        # at the half-rate cost (an upper bound) and at the full-rate cost (a lower bound: most of them are full-rate operations);
+        # useful_valu_frac: only the instructions the executed pair tests need when every lane and every slot of a step is used.
         simd_cycles = 1024 * 2.4e9 * cmp_ms * 1e-3
-        valu_issue = sq["SQ_INSTS_VALU"] * VALU_CYCLES / simd_cycles if "SQ_INSTS_VALU" in sq else None
-        useful_valu = pairs / 64.0 * PAIR_TEST_VALU * VALU_CYCLES / simd_cycles
+        valu_issue = sq["SQ_INSTS_VALU"] * VALU_CYCLES_HALF_RATE / simd_cycles if "SQ_INSTS_VALU" in sq else None
+        valu_issue_lo = sq["SQ_INSTS_VALU"] * VALU_CYCLES_FULL_RATE / simd_cycles if "SQ_INSTS_VALU" in sq else None
+        lc = 20
+        ops_p, ops_s = pair_step_valu(lc - tms[-1]["prefix_bases"], False), pair_step_valu(tms[-1]["prefix_bases"], True)
+        pairs_p = float(np.mean([t["pairs_prefix"] for t in tms]))
+        pairs_s = float(np.mean([t["pairs_suffix"] for t in tms]))
+        useful_instr = pairs_p / 2048.0 * ops_p + pairs_s / 2048.0 * ops_s
+        useful_valu = useful_instr * VALU_CYCLES_FULL_RATE / simd_cycles
         out = {
             "metric": "guide x target comparisons/s, effective = nominal G x T per step (discover, <=%d mismatches, CFD+Hsu2013 aggregate)" % args.max_mismatch,
             "value": G * T_total * args.steps / dt,
@@ -518,8 +547,10 @@ def main():
                          "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
                          "hbm_GBps_from_traffic": (traffic / (cmp_ms * 1e-3) / 1e9) if traffic else None,
                          "valu_pairs_per_launch": pairs, "pairs_per_s": pairs / (cmp_ms * 1e-3),
-                         "valu_issue_frac": valu_issue, "useful_valu_frac": useful_valu,
-                         "valu_cycles_per_wave_instruction": VALU_CYCLES, "valu_instructions_per_64_pairs": PAIR_TEST_VALU,
+                         "valu_issue_frac": valu_issue, "valu_issue_frac_if_all_full_rate": valu_issue_lo, "useful_valu_frac": useful_valu,
+                         "useful_valu_instructions_per_launch": useful_instr,
+                         "valu_model": {"cycles_full_rate": VALU_CYCLES_FULL_RATE, "cycles_half_rate": VALU_CYCLES_HALF_RATE,
+                                        "instructions_per_2048_pairs_prefix": ops_p, "instructions_per_2048_pairs_suffix": ops_s},
                          "sq_counters_per_launch": sq or None,
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
             "cpu_baseline": _CPU_JVM if (_CPU_JVM and _CPU_JVM.get("value")) else cpu,

@@ -1,0 +1,88 @@
+/*
+ * flashfry_jni.c -- the JNI side of reference.traverser.GPUTraverser (jni/GPUTraverser.scala): one thin function per native method,
+ * no logic of its own.  Every function forwards to the C ABI of include/flashfry_hip.h; the call sequence a scan makes
+ *     create -> dbOpen -> discover -> resultOffsets / resultTargets / resultPosOffsets / resultPositions -> resultFree -> destroy
+ * is exercised without a JVM by tests/test_jni_sequence.c (same order, same arguments, checked against the oracle).
+ *
+ * Build (needs a JDK for jni.h; this repository's image has none, so the file is compiled only where JAVA_HOME is set):
+ *     make -C jni            -> jni/libflashfry_jni.so
+ * The Scala object is `object GPUTraverser` in package reference.traverser: its methods are mangled with the module class suffix
+ * "$" = _00024.
+ */
+#include <jni.h>
+#include <stdint.h>
+
+#include "../include/flashfry_hip.h"
+
+#define FN(name) Java_reference_traverser_GPUTraverser_00024_##name
+#define CTX(h) ((ffh_ctx *)(intptr_t)(h))
+#define RES(h) ((const ffh_result *)(intptr_t)(h))
+
+/* ffh_create: Traverser.scan has no GPU argument; device 0 unless the property flashfry.gpu.device says otherwise (read on the Scala side) */
+JNIEXPORT jlong JNICALL FN(create)(JNIEnv *e, jobject self, jint device, jint enzyme_index) {
+    (void)e; (void)self;
+    return (jlong)(intptr_t)ffh_create((int)device, (int)enzyme_index);
+}
+
+JNIEXPORT void JNICALL FN(destroy)(JNIEnv *e, jobject self, jlong ctx) {
+    (void)e; (void)self;
+    ffh_destroy(CTX(ctx));
+}
+
+/* ffh_db_open: header + BGZF body; bins [bin_begin, bin_end), 0 = to the last bin */
+JNIEXPORT jint JNICALL FN(dbOpen)(JNIEnv *e, jobject self, jlong ctx, jstring path, jint bin_begin, jint bin_end) {
+    (void)self;
+    const char *p = (*e)->GetStringUTFChars(e, path, 0);
+    if (!p) return FFH_E_NOMEM;
+    const int rc = ffh_db_open(CTX(ctx), p, (uint32_t)bin_begin, (uint32_t)bin_end);
+    (*e)->ReleaseStringUTFChars(e, path, p);
+    return (jint)rc;
+}
+
+/* ffh_discover: the guides' longs are GuideIndex.guide unchanged (bitcoding/BitEncoding.scala:46-67); returns the ffh_result handle or 0 */
+JNIEXPORT jlong JNICALL FN(discover)(JNIEnv *e, jobject self, jlong ctx, jlongArray guides, jint max_mismatch, jint max_offtargets) {
+    (void)self;
+    const jsize n = (*e)->GetArrayLength(e, guides);
+    jlong *g = (*e)->GetLongArrayElements(e, guides, 0);
+    if (!g) return 0;
+    ffh_result *r = 0;
+    const int rc = ffh_discover(CTX(ctx), (const uint64_t *)g, (uint32_t)n, (int)max_mismatch, (int)max_offtargets, 0u, &r);
+    (*e)->ReleaseLongArrayElements(e, guides, g, JNI_ABORT);
+    return rc ? 0 : (jlong)(intptr_t)r;
+}
+
+static jlongArray to_jlongs(JNIEnv *e, const uint64_t *p, uint64_t n) {
+    if (n > 0x7FFFFFF0ull) return 0;   /* a Java array holds < 2^31 elements: the caller splits the guide set before that */
+    jlongArray a = (*e)->NewLongArray(e, (jsize)n);
+    if (a && n) (*e)->SetLongArrayRegion(e, a, 0, (jsize)n, (const jlong *)p);
+    return a;
+}
+
+JNIEXPORT jlongArray JNICALL FN(resultOffsets)(JNIEnv *e, jobject self, jlong res) {      /* [n_guides + 1] into the hit arrays */
+    (void)self;
+    return to_jlongs(e, ffh_result_guide_offsets(RES(res)), (uint64_t)ffh_result_n_guides(RES(res)) + 1);
+}
+JNIEXPORT jlongArray JNICALL FN(resultTargets)(JNIEnv *e, jobject self, jlong res) {      /* [n_hits] target longs incl. count */
+    (void)self;
+    return to_jlongs(e, ffh_result_hit_targets(RES(res)), ffh_result_n_hits(RES(res)));
+}
+JNIEXPORT jlongArray JNICALL FN(resultPosOffsets)(JNIEnv *e, jobject self, jlong res) {   /* [n_hits + 1] into positions */
+    (void)self;
+    return to_jlongs(e, ffh_result_pos_offsets(RES(res)), ffh_result_n_hits(RES(res)) + 1);
+}
+JNIEXPORT jlongArray JNICALL FN(resultPositions)(JNIEnv *e, jobject self, jlong res) {    /* [n_positions] BitPosition longs */
+    (void)self;
+    return to_jlongs(e, ffh_result_positions(RES(res)), ffh_result_n_positions(RES(res)));
+}
+
+JNIEXPORT void JNICALL FN(resultFree)(JNIEnv *e, jobject self, jlong res) {
+    (void)e; (void)self;
+    ffh_result_free((ffh_result *)(intptr_t)res);
+}
+
+/* ffh_last_error: ctx == 0 asks for the message of a failed create (kept per calling thread) */
+JNIEXPORT jstring JNICALL FN(lastError)(JNIEnv *e, jobject self, jlong ctx) {
+    (void)self;
+    const char *m = ffh_last_error(CTX(ctx));
+    return (*e)->NewStringUTF(e, m ? m : "");
+}
