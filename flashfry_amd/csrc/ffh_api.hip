@@ -77,6 +77,7 @@ struct Image {  // one bucketed scan image of the database
     DevBuf<uint32_t> gwords;  // the bucket's targets in bit-sliced groups of 32 (ffh_compare.hpp), padded by kKW + 64 words
     DevBuf<uint32_t> tidx;    // database index of every slot (32 per group)
     int rest = 0;             // bases in the rest key (the ones the bucket id does not hold)
+    DevBuf<uint32_t> range;   // {first, last} non-empty bucket
 };
 
 struct Plan { int a, r1, s, r2; };  // prefix width/radius, suffix width/radius (r2 < 0: no suffix pass)
@@ -302,6 +303,13 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
         if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
         else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
     }
+    {   // the buckets that hold a target: candidate entries outside them are dropped while they are binned
+        FFH_HIP(im.range.reserve(2));
+        const uint32_t init[2] = {nb, 0u};
+        FFH_HIP(hipMemcpyAsync(im.range.p, init, sizeof init, hipMemcpyHostToDevice, ctx->st));
+        FFH_HIP(hipStreamSynchronize(ctx->st));   // (init lives on this stack frame)
+        hipLaunchKernelGGL(k_bucket_range, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, im.range.p);
+    }
     hipLaunchKernelGGL(k_group_count, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, ctx->icount.p);
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.gstart.p, ctx->scan_tmp32.p, ctx->st);
     hipLaunchKernelGGL(k_group_build, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, keys.p, tidx_in.p, nb, R, GW, im.gwords.p, im.tidx.p);
@@ -380,6 +388,7 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     ig.n_part = 1u << part_bits;
     ig.item_base = item_base;
     ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
+    ig.range = im.range.p;
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
     const uint64_t *gptr = ctx->guides.p + g0;
     // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
@@ -804,7 +813,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     };
     FFH_HIP(hipEventRecord(ctx->ev[0], st));
     float ms_cmp = 0, ms_prep = 0;
-    unsigned long long cursor_before = 0;
+    unsigned long long cursor_before = 0, n_real_hits = 0;
     for (uint32_t g0 = 0; g0 < n_guides;) {
         const uint32_t ng = std::min(batch, n_guides - g0);
         // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
@@ -844,7 +853,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
             if (cursor_before) FFH_HIP(hipMemcpyAsync(bigger.p, ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToDevice, st));
             FFH_HIP(hipStreamSynchronize(st));
             ctx->hits = std::move(bigger);
-            FFH_HIP(hipMemcpy(ctx->d_counters, &cursor_before, 8, hipMemcpyHostToDevice));  // the hit cursor goes back to where this batch began
+            const unsigned long long back[2] = {cursor_before, n_real_hits};
+            FFH_HIP(hipMemcpy(ctx->d_counters, back, 16, hipMemcpyHostToDevice));  // the hit cursor and the hit count go back to where this batch began
             continue;
         }
         for (uint32_t k = 0; k < kPairSlots; ++k) { ctx->tm.pairs_prefix += slots[2 * k]; ctx->tm.pairs_suffix += slots[2 * k + 1]; }
@@ -856,6 +866,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
         ctx->tm.compare_launches++;
         cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
+        n_real_hits = cnt[1];    // the waves' own count (the cursor includes the padding of their last chunks)
         g0 += ng;
     }
     ctx->n_raw = cursor_before;
@@ -872,19 +883,19 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
         SortScratch ss;
         ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        int gbits = 1;
-        while (gbits < 32 && (1ull << gbits) < std::max<uint64_t>(n_guides, 2)) ++gbits;
+        int gbits = 1;   // 2^gbits > n_guides: the all-ones padding of the compare waves' chunks sorts behind every guide
+        while (gbits < 32 && (1ull << gbits) <= (uint64_t)n_guides) ++gbits;
         ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
     }
     // seg_begin / seg_end were cleared by the prefix-side k_guide_keys of every batch
     if (ctx->n_raw)
-        hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->seg_end.p);
+        hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
     ctx->hit_t_ready = false;  // the target longs of the hits are gathered on demand (gather_hit_targets)
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
     FFH_HIP(hipGetLastError());
     // no synchronisation here: the ordering kernels run while the caller comes back with ffh_finalize / ffh_shard_totals (same
     // stream); their timings are read when somebody asks for them (finish_scan_timings)
-    ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp; ctx->tm.n_raw_hits = ctx->n_raw;
+    ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp; ctx->tm.n_raw_hits = n_real_hits;
     ctx->scan_timing_pending = true;
     ctx->scanned = true;
     return FFH_OK;
@@ -896,7 +907,7 @@ static int gather_hit_targets(ffh_ctx *ctx) {
     if (ctx->hit_t_ready) return FFH_OK;
     FFH_HIP(ctx->hit_t.reserve(ctx->n_raw + 1));
     if (ctx->n_raw)
-        hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, ctx->st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->targets.p, ctx->hit_t.p);
+        hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, ctx->st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->n_guides, ctx->targets.p, ctx->hit_t.p);
     FFH_HIP(hipGetLastError());
     ctx->hit_t_ready = true;
     return FFH_OK;
@@ -1023,7 +1034,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     if (flags & FFH_FINALIZE_JOST) { FFH_HIP(ctx->out_jost.reserve(Hr + 1)); d_jost = ctx->out_jost.p; }
     FFH_HIP(ctx->out_posoff.reserve(Hr + 2));
     if (ctx->n_raw)
-        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
+        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, G, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
                            ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
                            ctx->out_hsu.p, d_jost);
     exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, Hr, ctx->out_posoff.p, ctx->scan_tmp64.p, st);

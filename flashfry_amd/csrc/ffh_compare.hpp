@@ -148,16 +148,21 @@ __device__ __forceinline__ void count_planes(const uint32_t (&m)[N], uint32_t &c
 }
 
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
+constexpr uint32_t kChunkMax = 8192;   // hit-buffer slots a wave reserves at a time, at most
 struct HitStage {
     lds_u64 *my;             // this wave's staged hits: guide of this batch << 32 | side << 31 | slot in the side's image
     uint32_t fill;
     uint32_t lane;
     const CompareArgs *A;    // the kernel's argument block (scalar loads from the kernarg segment at flush time)
     unsigned long long *cursor;
+    // The wave owns a CHUNK of the hit buffer and fills it flush by flush; only a new chunk costs an atomic on the one global cursor
+    // (same-address atomics complete at ~90 per microsecond on this part: with one per flush a 5-mismatch or repeat-rich scan spent
+    // most of its time queueing there).  Chunks grow with the wave's own hit count, so a wave with few hits wastes little and a wave
+    // with many asks rarely; what is left of the last chunk is filled with all-ones keys, which sort behind every hit.
+    unsigned long long chunk_pos;
+    uint32_t chunk_left;
+    unsigned long long n_real;
 
-    // ONE global atomic per flush (same-address atomics complete at ~90 per microsecond on this part: a flush per ~250 hits keeps them
-    // off the critical path).  A record leaves as the sort key (global guide << tbits) | database index -- the index lookup rides on
-    // the flush instead of a pass of its own over all hits
     __device__ __forceinline__ void flush() {
         wave_lds_fence();
         uint64_t *__restrict__ hits = A->hits;
@@ -165,18 +170,46 @@ struct HitStage {
         const uint32_t *__restrict__ tidx_p = A->side[0].tidx, *__restrict__ tidx_s = A->side[1].tidx;
         const uint32_t guide_base = A->guide_base;
         const int tbits = A->tbits;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)fill);
-        base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
-        for (uint32_t i = lane; i < fill; i += 64)
-            if (base + i < cap) {
+        const unsigned long long old_pos = chunk_pos;
+        const uint32_t old_left = chunk_left;
+        unsigned long long new_pos = 0;
+        if (fill > old_left) {
+            // a wave with few hits (the usual <= 4-mismatch scan: ~3000 per wave) reserves exactly what it holds -- no padding, an
+            // atomic per flush is harmless there; past 4096 hits it reserves an eighth of what it has produced so far (at most
+            // kChunkMax): the padding left at the end stays ~6 % of its hits, the number of atomics logarithmic in them
+            const uint32_t need = fill - old_left;
+            const uint32_t want = n_real < 4096 ? need : max(min((uint32_t)(n_real >> 3), kChunkMax), need);
+            if (lane == 0) new_pos = atomicAdd(cursor, (unsigned long long)want);
+            new_pos = ((unsigned long long)uni((uint32_t)(new_pos >> 32)) << 32) | uni((uint32_t)new_pos);
+            chunk_pos = new_pos + (fill - old_left);
+            chunk_left = want - (fill - old_left);
+        } else {
+            chunk_pos = old_pos + fill;
+            chunk_left = old_left - fill;
+        }
+        // a record leaves as the sort key (global guide << tbits) | database index -- the index lookup rides on the flush instead of
+        // a pass of its own over all hits
+        for (uint32_t i = lane; i < fill; i += 64) {
+            const unsigned long long dst = i < old_left ? old_pos + i : new_pos + (i - old_left);
+            if (dst < cap) {
                 const uint64_t h = my[i];
                 const uint32_t lo = (uint32_t)h, slot = lo & 0x7FFFFFFFu;
                 const uint32_t ti = (lo >> 31) ? tidx_s[slot] : tidx_p[slot];
-                hits[base + i] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
+                hits[dst] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
             }
+        }
         wave_lds_fence();
+        n_real += fill;
         fill = 0;
+    }
+    // end of the kernel: the rest of the stage, the padding of the last chunk, the wave's count of real hits
+    __device__ __forceinline__ void finish() {
+        if (fill) flush();
+        uint64_t *__restrict__ hits = A->hits;
+        const uint64_t cap = A->cap;
+        for (uint32_t i = lane; i < chunk_left; i += 64)
+            if (chunk_pos + i < cap) hits[chunk_pos + i] = ~0ull;
+        if (lane == 0 && n_real) atomicAdd(cursor + 1, n_real);
     }
     // wave-uniform call: `lanes` = ballot of `hit`
     __device__ __forceinline__ void push(uint64_t lanes, bool hit, uint32_t gid, uint32_t slot) {
@@ -282,7 +315,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
     if (threadIdx.x >= 1 && threadIdx.x <= kMaxParts) inv_lds[threadIdx.x] = (65536u + threadIdx.x - 1u) / threadIdx.x;
     __syncthreads();
-    HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor};
+    HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor, 0ull, 0u, 0ull};
     RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
     unsigned long long pairs[2] = {0, 0};   // per lane (lane i adds bucket i of every batch), reduced once at the end
 
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
         }
     }
-    if (hs.fill) hs.flush();
+    hs.finish();
     if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);   // lanes 0 .. NB - 1 carry something
     if (pairs[1]) atomicAdd(&blk_pairs[1], pairs[1]);
     __syncthreads();

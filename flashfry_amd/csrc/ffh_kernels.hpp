@@ -170,7 +170,19 @@ struct ItemGeom {
     uint32_t n_part;
     uint32_t item_base;      // first CSR slot of this image (the two images share the item array)
     uint64_t pat_magic;      // ceil(2^40 / n_pat) when n_pat < 2^18 (then x / n_pat == (x * pat_magic) >> 40 for x < 2^19), else 0
+    const uint32_t *range;   // {first, last} bucket of this image that holds a target: entries outside it are dropped while they are
+                             // binned (a bin shard of a multi-GPU run holds a contiguous eighth of the prefix buckets: seven eighths
+                             // of the (bucket, guide) entries would meet no target)
 };
+
+// first and last non-empty bucket of an image (range[0] starts at the bucket count, range[1] at 0)
+__global__ void k_bucket_range(const uint32_t *__restrict__ bstart, uint32_t nb, uint32_t *__restrict__ range) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || bstart[b + 1] == bstart[b]) return;
+    const bool first = b == 0 || bstart[b] == bstart[0], last = b == nb - 1 || bstart[b + 1] == bstart[nb];
+    if (first) atomicMin(&range[0], b);
+    if (last) atomicMax(&range[1], b);
+}
 
 // entry number -> guide number inside a block's window: a 32-bit division costs ~30 instructions per entry and pass
 __device__ __forceinline__ uint32_t div_pat(uint32_t x, const ItemGeom &ig) {
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__
     for (uint32_t p = lane; p < ig.n_pat; p += 64) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
-    if (lane == 0) part_count[q] = n;
+    if (lane == 0) part_count[q] = (q >= (ig.range[0] >> ig.low_bits) && q <= (ig.range[1] >> ig.low_bits)) ? n : 0u;   // partitions without a target take no entries
 }
 
 template <bool WRITE>
@@ -254,10 +266,11 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     // entry i = guide (i / n_pat), pattern (i % n_pat); 32-bit arithmetic relative to the block's first entry
     const uint32_t g_first = (uint32_t)(begin / ig.n_pat), j_first = (uint32_t)(begin - (uint64_t)g_first * ig.n_pat);
     const uint32_t n_here = (uint32_t)(end - begin);
+    const uint32_t part_lo = ig.range[0] >> ig.low_bits, part_hi = ig.range[1] >> ig.low_bits;
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig);
-        const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat];
-        atomicAdd(&cur[lds_slot(b >> ig.low_bits)], 1u);
+        const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
+        if (part >= part_lo && part <= part_hi) atomicAdd(&cur[lds_slot(part)], 1u);
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
@@ -269,8 +282,9 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     __syncthreads();
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig), g = g_first + q;
-        const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat];
-        const uint32_t pos = atomicAdd(&cur[lds_slot(b >> ig.low_bits)], 1u);
+        const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
+        if (part < part_lo || part > part_hi) continue;
+        const uint32_t pos = atomicAdd(&cur[lds_slot(part)], 1u);
         part_items[pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
     }
 }
@@ -355,19 +369,22 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__
 // epilogue: ordered cut-off (crispr/CRISPRSiteOT.scala:39-46) + per-hit scores + per-guide aggregates.
 // The hits are sorted by (guide, database index); one WAVE works on one guide's segment.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_segments(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
+// (the hit buffer ends with the all-ones padding of the compare waves' last chunks: guide field >= n_guides, skipped everywhere)
+__global__ void k_segments(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t n_guides, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t g = (uint32_t)(hits[i] >> tbits);
-    if (i == 0 || (uint32_t)(hits[i - 1] >> tbits) != g) seg_begin[g] = (uint32_t)i;
-    if (i == n - 1 || (uint32_t)(hits[i + 1] >> tbits) != g) seg_end[g] = (uint32_t)(i + 1);
+    const uint64_t g = hits[i] >> tbits;
+    if (g >= n_guides) return;
+    if (i == 0 || (hits[i - 1] >> tbits) != g) seg_begin[g] = (uint32_t)i;
+    if (i == n - 1 || (hits[i + 1] >> tbits) != g) seg_end[g] = (uint32_t)(i + 1);
 }
 
 // the target long of every raw hit, in sorted order (the one random gather of the epilogue)
-__global__ void k_hit_targets(const uint64_t *__restrict__ hits, uint64_t n, int tbits, const uint64_t *__restrict__ targets, uint64_t *__restrict__ st) {
+__global__ void k_hit_targets(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t n_guides, const uint64_t *__restrict__ targets, uint64_t *__restrict__ st) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    st[i] = targets[hits[i] & ((1ull << tbits) - 1ull)];
+    const uint64_t key = hits[i];
+    st[i] = (key >> tbits) < n_guides ? targets[key & ((1ull << tbits) - 1ull)] : 0ull;
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v, uint32_t lane) {
@@ -495,7 +512,7 @@ __device__ __forceinline__ double jost_pair(uint64_t gd, uint64_t t, const Geome
 }
 
 // per retained hit of a discover scan: target long, mismatches, position count, database index and the two scores
-__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, int tbits, const uint32_t *__restrict__ seg_begin,
+__global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits, int tbits, uint32_t n_guides, const uint32_t *__restrict__ seg_begin,
                              const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ st,
                              const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
                              uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
@@ -503,6 +520,7 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint64_t key = hits[i];
+    if ((key >> tbits) >= n_guides) return;   // chunk padding
     const uint32_t g = (uint32_t)(key >> tbits), ti = (uint32_t)(key & ((1ull << tbits) - 1ull));
     const uint32_t local = (uint32_t)i - seg_begin[g];
     if (local >= n_ret[g]) return;
