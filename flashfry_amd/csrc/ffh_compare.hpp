@@ -326,6 +326,9 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     // batches q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
     // describes it stays in scalar registers.
     for (int side = 1; side >= 0; --side) {
+#ifdef FFH_EXP_ONLY_SIDE   // timing experiment: one image only (results wrong)
+        if (side != FFH_EXP_ONLY_SIDE) continue;
+#endif
         const SideArgs S = A.side[side];
         const uint32_t n_total = S.n_batches;
         uint32_t q = blockIdx.x * kCmpWaves + wave;

@@ -102,3 +102,28 @@ def test_randomised_parity_slice(capi, oracle):
         assert_same_scores(oracle, 3, g, gpu, ora)
         n += 1
     assert n >= 20, "the slice should get through a few dozen cases in a minute (%d)" % n
+
+
+@pytest.mark.parametrize("max_mm,max_ot", [(4, 2000), (4, 100), (5, 2000)])
+def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_mm, max_ot):
+    """The heavy-tailed case a real genome is (synth.make_repeat_database: repeat families of thousands of near-copies at 1-14 %
+    divergence, low-complexity tracts with counts in the hundreds) with the guides drawn FROM the genome by position, so that many
+    guides sit inside a family: hundreds to thousands of raw hits per such guide, most of them beyond the ordered cut-off, buckets
+    and candidate lists far larger than a compare batch (the kernel's piecewise path).  Bit for bit against the oracle."""
+    db = synth.make_repeat_database(1_500_000, seed=synth.DB_SEED + 7)
+    g = synth.as_u64(synth.make_guides_from_database(db, 700, seed=synth.GUIDE_SEED + 7))
+    t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
+    odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        gpu = ctx.discover(g, max_mm, max_ot, jost=True)
+        only = ctx.finalize(max_ot, summaries_only=True, jost=True)
+        assert only.summaries.tobytes() == gpu.summaries.tobytes()
+        tm = ctx.timings()
+    ora = odb.discover(g, max_mm, max_ot)
+    assert_same_hits(gpu, ora)
+    assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
+    n_over = int(gpu.summaries["overflow"].sum())
+    assert n_over >= 20 and n_over < len(g), n_over                       # many guides reach the cut-off, most do not
+    assert tm.n_raw_hits > 3 * gpu.n_hits or max_ot == 2000              # far more raw hits than retained ones under a tight cut-off
+    assert int((t >> np.uint64(48)).max()) >= 100                        # multi-copy targets (low-complexity tracts) are in play
