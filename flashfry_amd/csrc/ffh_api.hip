@@ -132,23 +132,24 @@ struct ffh_result {
     uint8_t *hit_mm = nullptr;
 
     // lays the arrays out in one block; lists == false keeps only summaries + guide offsets
-    bool allocate(const std::shared_ptr<PinnedPool> &p, uint32_t G, uint64_t H, uint64_t P, bool lists) {
+    bool allocate(const std::shared_ptr<PinnedPool> &p, uint32_t G, uint64_t H, uint64_t P, bool lists, bool with_positions = true) {
         pool = p;
-        n_guides = G; n_hits = H; n_positions = lists ? P : 0;
+        n_guides = G; n_hits = H; n_positions = (lists && with_positions) ? P : 0;
         auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
         size_t o_sum = 0, o_goff = o_sum + up((size_t)G * sizeof(ffh_guide_summary)), o_ht = o_goff + up(((size_t)G + 1) * 8);
         size_t o_cfd = o_ht, o_poff = o_ht, o_pos = o_ht, o_mm = o_ht, total = o_ht;
         if (lists) {
-            o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + up((size_t)H * 8); o_pos = o_poff + up(((size_t)H + 1) * 8);
-            o_mm = o_pos + up((size_t)P * 8); total = o_mm + up((size_t)H);
+            o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + up((size_t)H * 8);
+            o_pos = o_poff + (with_positions ? up(((size_t)H + 1) * 8) : 0);
+            o_mm = o_pos + (with_positions ? up((size_t)P * 8) : 0); total = o_mm + up((size_t)H);
         }
         block = pool->get(total + 64, block_cap);
         if (!block) return false;
         char *b = (char *)block;
         summaries = (ffh_guide_summary *)(b + o_sum); guide_offsets = (uint64_t *)(b + o_goff);
         if (lists) {
-            hit_targets = (uint64_t *)(b + o_ht); hit_cfd = (double *)(b + o_cfd); pos_offsets = (uint64_t *)(b + o_poff);
-            positions = (uint64_t *)(b + o_pos); hit_mm = (uint8_t *)(b + o_mm);
+            hit_targets = (uint64_t *)(b + o_ht); hit_cfd = (double *)(b + o_cfd); hit_mm = (uint8_t *)(b + o_mm);
+            if (with_positions) { pos_offsets = (uint64_t *)(b + o_poff); positions = (uint64_t *)(b + o_pos); }
         }
         return true;
     }
@@ -1043,8 +1044,8 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
                               ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)d_jost, G, ctx->summ.p);
     FFH_HIP(hipStreamSynchronize(st));
-    const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY);
-    if (want_lists) {
+    const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY), want_pos = want_lists && !(flags & FFH_FINALIZE_NO_POSITIONS);
+    if (want_pos) {
         FFH_HIP(ctx->out_pos.reserve(Pr + 1));
         if (Hr) hipLaunchKernelGGL(k_gather_positions, dim3(blocks_for(Hr, 256)), dim3(256), 0, st, ctx->out_tidx.p, ctx->out_cnt.p, ctx->out_posoff.p, Hr, ctx->pos_off.p,
                                    ctx->positions.p, ctx->out_pos.p);
@@ -1052,7 +1053,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     FFH_HIP(hipEventRecord(ctx->ev[1], st));
     FFH_HIP(hipGetLastError());
     ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r || !r->allocate(ctx->pool, G, Hr, Pr, want_lists)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+    if (!r || !r->allocate(ctx->pool, G, Hr, Pr, want_lists, want_pos)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
     r->scores_valid = ctx->geo.cas9_23;
     hipError_t e = hipSuccess;
     if (G) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
@@ -1061,8 +1062,8 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_targets, ctx->out_target.p, Hr * 8, hipMemcpyDeviceToHost, st);
         if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm, ctx->out_mm.p, Hr, hipMemcpyDeviceToHost, st);
         if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd, ctx->out_cfd.p, Hr * 8, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets, ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
-        if (Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions, ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
+        if (want_pos && e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets, ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (want_pos && Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions, ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }

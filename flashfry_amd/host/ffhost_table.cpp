@@ -333,7 +333,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     for (size_t d = 1; d < nd; ++d)
         for (size_t g = 0; g < ng; ++g) prior[d][g] = (uint32_t)std::min<uint64_t>((uint64_t)prior[d - 1][g] + totals[d - 1][g], (uint64_t)std::max(maximumOffTargets, 0));
     parallel([&](size_t d) {
-        if (ffh_finalize(ctx[d], d ? prior[d].data() : nullptr, maximumOffTargets, 0, &res[d])) errs[d] = abiError(ctx[d]);
+        // without --positionOutput the table prints sequence_count_mismatches only: the position arrays stay on the device
+        if (ffh_finalize(ctx[d], d ? prior[d].data() : nullptr, maximumOffTargets, wantPositions ? 0u : FFH_FINALIZE_NO_POSITIONS, &res[d])) errs[d] = abiError(ctx[d]);
     });
     auto t3 = clk::now();
     // deliver the hits in database order = shard order (what aggregator.updateOT would have received)
@@ -354,11 +355,11 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
             for (uint64_t h = go[g]; h < go[g + 1]; ++h) {
                 CRISPRHit hit;
                 hit.sequence = ht[h];
-                hit.nCoordinates = (uint32_t)(po[h + 1] - po[h]);
+                hit.nCoordinates = (uint32_t)(ht[h] >> 48);   // the occurrence count rides in bits 63:48 (BitEncoding.scala:46-67)
                 if (wantPositions) hit.coordinates.assign(pp + po[h], pp + po[h + 1]);
                 hit.hasCfd = cfd[h] == cfd[h];
                 hit.cfd = cfd[h];
-                ot.currentTotal += (long)(po[h + 1] - po[h]);
+                ot.currentTotal += (long)hit.nCoordinates;
                 ot.offTargets.push_back(std::move(hit));
             }
             sum.n_hits += s.n_hits; sum.ot_count += s.ot_count; sum.overflow |= s.overflow;
@@ -366,7 +367,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
             if (s.closest < sum.closest) { sum.closest = s.closest; sum.closest_count = s.closest_count; }
             else if (s.closest == sum.closest && s.closest != 0xFFFFFFFFu) sum.closest_count += s.closest_count;
             sum.in_genome += s.in_genome; sum.n_scored += s.n_scored;
-            sum.cfd_max = std::max(sum.cfd_max, s.cfd_max); sum.cfd_sum += s.cfd_sum; sum.hsu_sum += s.hsu_sum;
+            sum.cfd_max = std::max(sum.cfd_max, s.cfd_max); sum.cfd_sum += s.cfd_sum; sum.hsu_sum += s.hsu_sum;   // shard order = database order
+            sum.jost_max = std::max(sum.jost_max, s.jost_max); sum.jost_sum += s.jost_sum;
         }
         ot.summary = sum;
     }

@@ -177,6 +177,10 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t cla
 #define FFH_FINALIZE_SUMMARIES_ONLY 1u /* do not copy hit lists / positions to the host */
 #define FFH_FINALIZE_JOST 2u           /* also fill ffh_guide_summary.jost_max / jost_sum (Cas9 enzymes) */
 #define FFH_FINALIZE_PRIOR_ON_DEVICE 4u /* prior_totals is a device pointer (multi-GPU exchange without a host round trip) */
+#define FFH_FINALIZE_NO_POSITIONS 8u   /* hit lists without the position arrays: ffh_result_positions / _pos_offsets return NULL and
+                                          nothing is gathered or copied for them.  What `discover` needs unless --positionOutput is
+                                          given (modules/OffTargetDiscovery.scala:51-53): its table prints sequence_count_mismatches,
+                                          and the count is in bits 63:48 of the hit's target long */
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
                  unsigned flags, ffh_result **out);
 

@@ -606,3 +606,17 @@ def test_cas12a_bulge_search_matches_the_brute_force_specification(capi, oracle)
         ctx.load_soa(np.zeros(0, np.uint64), np.zeros(0, np.uint64))
         with pytest.raises(capi.FlashFryHipError, match="Cas12a"):
             ctx.discover_bulge(guides, 3, 1)
+
+
+def test_hit_lists_without_positions(capi, oracle):
+    """FFH_FINALIZE_NO_POSITIONS: same lists, scores and aggregates, no position arrays (the count of a hit is in its target long)"""
+    odb, t, p, g = dense_case(oracle, seed=5)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        full = ctx.discover(g, 4, 60, jost=True)
+        lean = ctx.finalize(60, jost=True, positions=False)
+    assert lean.positions is None and lean.pos_offsets is None and lean.n_positions == 0
+    assert np.array_equal(lean.guide_offsets, full.guide_offsets) and np.array_equal(lean.hit_targets, full.hit_targets)
+    assert np.array_equal(lean.hit_mismatches, full.hit_mismatches)
+    assert lean.hit_cfd.tobytes() == full.hit_cfd.tobytes() and lean.summaries.tobytes() == full.summaries.tobytes()
+    assert np.array_equal((lean.hit_targets >> np.uint64(48)).astype(np.int64), np.diff(full.pos_offsets.astype(np.int64)))
