@@ -197,6 +197,8 @@ struct ffh_ctx {
     DevBuf<uint32_t> gbucket[2], patterns[2], istart[2];
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
     DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
+    DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
+    DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint32_t> sort_table, sort_offs;
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
@@ -464,7 +466,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_st, hipStreamNonBlocking);
     ctx->st = ctx->own_st;
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, (16 + 2 * kPairSlots + 8) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
     if (e == hipSuccess) {
         ScoreTables h;
@@ -790,27 +792,34 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     max_batch = std::min(max_batch, (double)((1u << kGidBits) - 1u));
     if (ctx->max_guide_batch) max_batch = std::min(max_batch, (double)ctx->max_guide_batch);
     uint32_t batch = (uint32_t)std::max(1.0, std::floor(max_batch));
-    // how each image is cut into batches for the compare kernel (ffh_compare.hpp): runs of NB small buckets, or 2^k slices of one large
-    // bucket, sized so that a typical batch fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); whatever exceeds
-    // the strip takes the kernel's piecewise path
-    auto side_plan = [&](int which, int width, int r_far, double n_patterns, uint32_t ng) -> SideArgs {
-        SideArgs S{};
+    // How each image is cut into work entries for the compare kernel (ffh_compare.hpp): runs of NB small buckets sized so that a
+    // typical run fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); k_work_count / k_work_fill then list the
+    // runs that have candidates, a bucket larger than the strip as several strip-sized group ranges.  Candidate lists larger than the
+    // strip take the kernel's piecewise path.
+    auto side_plan = [&](int which, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S) -> int {
+        S = SideArgs{};
         const Image &im = ctx->img[which];
-        S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.istart = ctx->istart[which].p; S.bstart = im.bstart.p; S.gtab = ctx->gtab[which].p;
+        S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
         S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
         const double cap_g = std::floor((double)kKW / group_words(im.rest));
         const double avg_t = (double)ctx->T / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
-        S.NB = 1; S.sl_shift = 0; S.KS = 0;
-        if (avg_g * 1.1 <= cap_g) {
-            const double by_groups = std::floor(0.75 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.7 * kKC / std::max(avg_c, 0.05));
-            S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
-        } else {
-            while (avg_g * 1.1 / (double)(1u << S.sl_shift) > cap_g && S.sl_shift < 20) ++S.sl_shift;
-            S.KS = (uint32_t)std::ceil(avg_g * 1.05 / (double)(1u << S.sl_shift));
-        }
-        const uint64_t nbat = (((uint64_t)S.nb + S.NB - 1) / S.NB) << S.sl_shift;
-        S.n_batches = (uint32_t)std::min<uint64_t>(nbat, 0xFFFFFFFFu);
-        return S;
+        const double by_groups = std::floor(0.75 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.7 * kKC / std::max(avg_c, 0.05));
+        S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
+        S.split = (uint32_t)cap_g;
+        const uint32_t n_bat = (S.nb + S.NB - 1) / S.NB;
+        const uint64_t max_entries = (uint64_t)n_bat + (ctx->T / 32 + S.nb) / S.split + 2;
+        FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
+        FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
+        FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
+        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_bat)));
+        hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, im.bstart.p, S.nb, S.NB, S.split, n_bat,
+                           ctx->wl_count[which].p, ctx->d_counters + kStatPairs + which);
+        exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->scan_tmp32.p, st);
+        hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
+                           ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which);
+        S.list = ctx->wl_list[which].p;
+        S.n_list = ctx->wl_off[which].p + n_bat;
+        return FFH_OK;
     };
     FFH_HIP(hipEventRecord(ctx->ev[0], st));
     float ms_cmp = 0, ms_prep = 0;
@@ -818,7 +827,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     for (uint32_t g0 = 0; g0 < n_guides;) {
         const uint32_t ng = std::min(batch, n_guides - g0);
         // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
-        hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(2 * kPairSlots), 0, st, ctx->d_counters, g0 == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(64), 0, st, ctx->d_counters, g0 == 0 ? 1 : 0);
         const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
         if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
         FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
@@ -831,19 +840,18 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         }
         FFH_HIP(hipEventRecord(ctx->ev[3], st));
         CompareArgs ca{};
-        ca.side[0] = side_plan(0, plan.a, -1, np_p, ng);
-        if (plan.r2 >= 0) ca.side[1] = side_plan(1, plan.s, plan.r1, np_s, ng);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+        rc = side_plan(0, plan.a, -1, np_p, ng, ca.side[0]);
+        if (rc) return rc;
+        if (plan.r2 >= 0) { rc = side_plan(1, plan.s, plan.r1, np_s, ng, ca.side[1]); if (rc) return rc; }   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
         else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
         ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
-        const uint32_t stats[2] = {ca.side[0].n_batches, ca.side[1].n_batches};
         hipLaunchKernelGGL(k_compare<0>, dim3(ctx->compare_grid), dim3(kCmpThreads), 0, st, ca, ctx->d_counters);
         FFH_HIP(hipGetLastError());
         FFH_HIP(hipEventRecord(ctx->ev[4], st));
-        unsigned long long cnt[kPairSlotBase + 2 * kPairSlots];  // one read-back: hit cursor, work-item counts, pair counters
+        unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
         FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipStreamSynchronize(st));
         FFH_HIP(hipGetLastError());
-        const unsigned long long *slots = cnt + kPairSlotBase;
         const unsigned long long cursor = cnt[0];
         // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
         // silently wrong result (the bulge path has the same guard)
@@ -858,13 +866,13 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
             FFH_HIP(hipMemcpy(ctx->d_counters, back, 16, hipMemcpyHostToDevice));  // the hit cursor and the hit count go back to where this batch began
             continue;
         }
-        for (uint32_t k = 0; k < kPairSlots; ++k) { ctx->tm.pairs_prefix += slots[2 * k]; ctx->tm.pairs_suffix += slots[2 * k + 1]; }
+        ctx->tm.pairs_prefix += cnt[kStatPairs]; ctx->tm.pairs_suffix += cnt[kStatPairs + 1];
         float a = 0, b = 0;
         FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
         FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
         ms_prep += a; ms_cmp += b;
-        ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += stats[0];
-        ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += stats[1];
+        ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += cnt[kStatEntries];
+        ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += cnt[kStatEntries + 1];
         ctx->tm.compare_launches++;
         cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
         n_real_hits = cnt[1];    // the waves' own count (the cursor includes the padding of their last chunks)

@@ -60,7 +60,7 @@ constexpr int kGidRegs = kKC / 64;
 constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is split into jobs of about this many groups
 constexpr int kMaxParts = 16;
 
-constexpr uint32_t kPairSlotBase = 16, kPairSlots = 64;  // pair counters live at cursor[16 .. 16 + 2 * 64)
+constexpr uint32_t kStatPairs = 4, kStatEntries = 6;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
 
 __host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 + 3) & ~3; }   // words per group of 32 targets (16-byte multiple)
 
@@ -69,15 +69,16 @@ struct SideArgs {
     const uint32_t *gwords;   // [groups * GW + kKW + 64] bit-sliced groups (padded: a batch is fetched in whole 16-byte pieces)
     const uint32_t *tidx;     // [groups * 32] database index of every slot (looked up when a hit leaves the wave)
     const uint32_t *istart;   // [nb + 1] first candidate of every bucket (absolute index into gids)
-    const uint32_t *bstart;   // [nb + 1] first target of every bucket (the executed-pair statistics)
     const uint2 *gtab;        // [guides of this batch] {rest key H << 16 | L, bucket id} of every guide on this side
     uint32_t nb;              // buckets
     uint32_t width;           // bases in the bucket id (= bits per plane of it)
     uint32_t rest;            // R: bases in the rest key
-    uint32_t NB;              // buckets per batch (1 when sl_shift > 0)
-    uint32_t sl_shift;        // log2(slices per bucket)
-    uint32_t KS;              // groups per slice; the last slice takes whatever is left
-    uint32_t n_batches;       // ceil(nb / NB) << sl_shift
+    uint32_t NB;              // buckets per batch
+    uint32_t split;           // groups per work entry at most (= what the LDS strip holds)
+    const uint4 *list;        // work entries {first bucket, buckets, first group, end group}: a batch that has candidates, or -- for a
+                              // bucket larger than the strip (a repeat family) -- one strip-sized range of its groups, so that such a
+                              // bucket is spread over many waves instead of pinning one
+    const uint32_t *n_list;   // their number (device memory: built on the stream, no host round trip)
     int r_far;                // suffix side: r1 -- a pair is reported here only with MORE than r1 mismatches in its rest key (the
                               // prefix image reports the others); prefix side: -1
 };
@@ -92,10 +93,10 @@ struct CompareArgs {
     uint32_t pad;
 };
 
-// before every compare launch: clears the per-launch pair counters (one launch in place of a memset)
+// before every compare launch: clears the per-launch statistics words (one launch in place of a memset)
 __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int first_batch) {
-    if (first_batch && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // hit cursor and the zero word: once per scan, they run across batches
-    if (threadIdx.x < 2 * kPairSlots) cursor[kPairSlotBase + threadIdx.x] = 0ull;
+    if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
+    if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -290,13 +291,42 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
     }
 }
 
-// batch qq of a side: buckets [b0, b0 + NB) (slice sl of bucket b0 when the side slices its buckets)
-struct BatchId { uint32_t b0, sl; };
-__device__ __forceinline__ BatchId decode_batch(const SideArgs &S, uint32_t qq) {
-    BatchId b;
-    b.sl = qq & ((1u << S.sl_shift) - 1u);
-    b.b0 = (qq >> S.sl_shift) * S.NB;
-    return b;
+// ---------------------------------------------------------------------------------------------------------
+// The work list of one image for one compare launch, built from the bucket boundaries and the candidate CSR offsets:
+//   k_work_count  per batch of NB consecutive buckets: 0 entries if it has no candidate or no target, else ceil(groups / split);
+//                 the launch also adds up the executed-pair statistic (targets x candidates of every bucket)
+//   (scan)
+//   k_work_fill   the entries.  A call with a handful of guides lists a few hundred batches instead of making every wave walk all
+//                 4^11 buckets' boundaries; a bucket of 1e5 targets becomes ~100 entries dealt to ~100 waves.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, const uint32_t *__restrict__ bstart,
+                                                    uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, uint32_t *__restrict__ counts,
+                                                    unsigned long long *__restrict__ pairs_out) {
+    __shared__ unsigned long long red[4];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long pairs = 0;
+    if (t < n_bat) {
+        const uint32_t b0 = t * NB, b1 = min(nb, b0 + NB);
+        const uint32_t ngr = gstart[b1] - gstart[b0], nc = istart[b1] - istart[b0];
+        counts[t] = (ngr && nc) ? (ngr + split - 1u) / split : 0u;
+        if (nc)
+            for (uint32_t b = b0; b < b1; ++b) pairs += (unsigned long long)(bstart[b + 1] - bstart[b]) * (istart[b + 1] - istart[b]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pairs;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned long long s = red[0] + red[1] + red[2] + red[3]; if (s) atomicAdd(pairs_out, s); }
+}
+__global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, const uint32_t *__restrict__ offs,
+                            uint4 *__restrict__ list, unsigned long long *__restrict__ n_out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_bat) return;
+    const uint32_t o = offs[t], n = offs[t + 1] - o;
+    if (t == n_bat - 1) *n_out = offs[n_bat];
+    if (!n) return;
+    const uint32_t b0 = t * NB, nbv = min(NB, nb - b0), gs = gstart[b0], ge = gstart[b0 + nbv];
+    for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(b0, nbv, gs + k * split, min(ge, gs + (k + 1) * split));
 }
 
 template <int UNUSED>
@@ -307,64 +337,62 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     __shared__ __attribute__((aligned(16))) uint4 tab_lds[kCmpWaves][2][16];
     __shared__ uint64_t stage[kCmpWaves][kStage];
     __shared__ uint32_t inv_lds[kMaxParts + 1];    // ceil(65536 / P): x / P == (x * inv) >> 16 for x < 4096, P <= 16
-    __shared__ unsigned long long blk_pairs[2];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kCmpWaves;
     const uint32_t *__restrict__ gids = A.gids;
-    if (threadIdx.x < 2) blk_pairs[threadIdx.x] = 0;
     if (threadIdx.x >= 1 && threadIdx.x <= kMaxParts) inv_lds[threadIdx.x] = (65536u + threadIdx.x - 1u) / threadIdx.x;
     __syncthreads();
     HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor, 0ull, 0u, 0ull};
     RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
-    unsigned long long pairs[2] = {0, 0};   // per lane (lane i adds bucket i of every batch), reduced once at the end
 
     // what a batch covers: nbv buckets from b0 on, groups [g0, g1), candidates [c0, c1)
     struct Extent { uint32_t nbv, b0, g0, g1, c0, c1; };
 
-    // The suffix image's batches come first (they are the heavier ones), then the prefix image's; inside a side the wave takes the
-    // batches q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
+    // The suffix image's work entries come first (they are the heavier ones), then the prefix image's; inside a side the wave takes the
+    // entries q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
     // describes it stays in scalar registers.
     for (int side = 1; side >= 0; --side) {
 #ifdef FFH_EXP_ONLY_SIDE   // timing experiment: one image only (results wrong)
         if (side != FFH_EXP_ONLY_SIDE) continue;
 #endif
         const SideArgs S = A.side[side];
-        const uint32_t n_total = S.n_batches;
+        if (!S.n_list) continue;
+        const uint32_t n_total = *S.n_list;
         uint32_t q = blockIdx.x * kCmpWaves + wave;
         if (q >= n_total) continue;
-        const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ bstart = S.bstart, *__restrict__ gwords = S.gwords;
+        const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ gwords = S.gwords;
+        const uint32_t *__restrict__ list = reinterpret_cast<const uint32_t *>(S.list);
         const uint2 *__restrict__ gtab = S.gtab;
-        const uint32_t n_slices = 1u << S.sl_shift, GW = (uint32_t)group_words((int)S.rest);
+        const uint32_t GW = (uint32_t)group_words((int)S.rest);
         rc.r_far = S.r_far;
         rc.side_bit = (uint32_t)side << 31;
         rc.width = S.width;
 
-        // ---- the loads of the pipeline.  A batch past the end is an empty one (its loads are skipped). ----
-        // bucket boundaries of batch qq: lane l <= NB holds gstart / istart of bucket b0 + l (clamped to the image's last entry)
-        auto load_desc = [&](uint32_t qq, uint32_t &dG, uint32_t &dI) {
+        // ---- the loads of the pipeline.  An entry past the end is an empty one (its loads are skipped). ----
+        // work entry qq: lanes 0..3 = {first bucket, buckets, first group, end group}
+        auto load_entry = [&](uint32_t qq, uint32_t &dE) {
+            dE = 0;
+            if (qq < n_total && lane < 4) dE = list[(size_t)qq * 4 + lane];
+        };
+        // bucket boundaries of the entry: lane l <= nbv holds gstart / istart of bucket b0 + l
+        auto load_desc = [&](uint32_t qq, uint32_t dE, uint32_t &dG, uint32_t &dI) {
             dG = 0; dI = 0;
             if (qq < n_total) {
-                const BatchId b = decode_batch(S, qq);
-                const uint32_t idx = min(b.b0 + min(lane, S.NB), S.nb);
+                const uint32_t idx = lane_of(dE, 0) + min(lane, lane_of(dE, 1));
                 dG = gstart[idx];
                 dI = istart[idx];
             }
         };
-        auto extent_of = [&](uint32_t qq, uint32_t dG, uint32_t dI) -> Extent {
+        auto extent_of = [&](uint32_t qq, uint32_t dE, uint32_t dG, uint32_t dI) -> Extent {
             Extent e{0, 0, 0, 0, 0, 0};
             if (qq < n_total) {
-                const BatchId b = decode_batch(S, qq);
-                e.b0 = b.b0;
-                e.nbv = min(S.NB, S.nb - b.b0);
-                const uint32_t gs = lane_of(dG, 0), ge = lane_of(dG, e.nbv);
-                e.g0 = gs; e.g1 = ge;
-                if (S.sl_shift) {  // one bucket, slice b.sl of it; the last slice takes whatever is left
-                    e.g0 = min(ge, gs + b.sl * S.KS);
-                    e.g1 = (b.sl == n_slices - 1u) ? ge : min(ge, gs + (b.sl + 1) * S.KS);
-                }
+                e.b0 = lane_of(dE, 0);
+                e.nbv = lane_of(dE, 1);
+                e.g0 = max(lane_of(dG, 0), lane_of(dE, 2));
+                e.g1 = min(lane_of(dG, e.nbv), lane_of(dE, 3));
                 e.c0 = lane_of(dI, 0); e.c1 = lane_of(dI, e.nbv);
-                if (e.g1 == e.g0) e.c1 = e.c0;   // nothing to compare the candidates with
+                if (e.g1 <= e.g0) { e.g1 = e.g0; e.c1 = e.c0; }   // nothing to compare the candidates with
             }
             return e;
         };
@@ -411,9 +439,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             }
             // bucket i: its groups and candidates clipped to the piece; P jobs per candidate
             const uint32_t nG = row_next(dG), nI = row_next(dI);
-            uint32_t bg0 = dG, bg1 = nG;
-            if (S.sl_shift) { bg0 = e.g0; bg1 = e.g1; }   // (one bucket: its slice)
-            const uint32_t lo_g = min(max(bg0, g0), g1), hi_g = min(max(bg1, g0), g1);
+            const uint32_t lo_g = min(max(dG, g0), g1), hi_g = min(max(nG, g0), g1);
             const uint32_t lo_c = min(max(dI, c0), c1), hi_c = min(max(nI, c0), c1);
             const bool act = lane < e.nbv;
             const uint32_t ngr = act ? hi_g - lo_g : 0u, ng = (act && ngr) ? hi_c - lo_c : 0u;
@@ -464,11 +490,15 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             }
         };
 
-        // ---- prologue: boundaries of three batches, candidate ids of two, groups and guide entries of the first ----
-        uint32_t dG0, dI0, dG1, dI1, dG2, dI2;
-        load_desc(q, dG0, dI0);
-        load_desc(q + n_waves, dG1, dI1);
-        load_desc(q + 2 * n_waves, dG2, dI2);
+        // ---- prologue: work entries of four batches, boundaries of three, candidate ids of two, groups and guide entries of the first ----
+        uint32_t dE0, dE1, dE2, dE3, dG0, dI0, dG1, dI1, dG2, dI2;
+        load_entry(q, dE0);
+        load_entry(q + n_waves, dE1);
+        load_entry(q + 2 * n_waves, dE2);
+        load_entry(q + 3 * n_waves, dE3);
+        load_desc(q, dE0, dG0, dI0);
+        load_desc(q + n_waves, dE1, dG1, dI1);
+        load_desc(q + 2 * n_waves, dE2, dG2, dI2);
         uint4 kreg[kKeyRegs];
         uint32_t greg_a[kGidRegs], greg_b[kGidRegs];
         uint2 ereg[kGidRegs];
@@ -478,24 +508,22 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         for (int j = 0; j < kGidRegs; ++j) { ereg[j] = make_uint2(0, 0); greg_a[j] = 0; greg_b[j] = 0; }
         const uint32_t cap_g = (uint32_t)kKW / GW;   // groups the strip holds
         {
-            const Extent e0 = extent_of(q, dG0, dI0), e1 = extent_of(q + n_waves, dG1, dI1);
+            const Extent e0 = extent_of(q, dE0, dG0, dI0), e1 = extent_of(q + n_waves, dE1, dG1, dI1);
             load_gids(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a);
             load_gids(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_b);
             load_groups(e0.g0, min(e0.g1, e0.g0 + cap_g), kreg);
             load_entries(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a, ereg);
         }
         for (; q < n_total; q += n_waves) {
-            const Extent e = extent_of(q, dG0, dI0);
-            // the targets of the batch's buckets, for the executed-pair statistics (used at the end of the batch)
-            uint32_t dB = 0;
-            { const BatchId b = decode_batch(S, q); dB = bstart[min(b.b0 + min(lane, S.NB), S.nb)]; }
+            const Extent e = extent_of(q, dE0, dG0, dI0);
             const bool fits = e.g1 - e.g0 <= cap_g && e.c1 - e.c0 <= (uint32_t)kKC, work = e.c1 > e.c0;
             uint32_t n_jobs = 0;
             // everything requested a batch ago has arrived (the compiler's waits cover it): park it
             if (fits && work) n_jobs = park(e, e.g0, e.g1, e.c0, e.c1, kreg, greg_a, ereg, dG0, dI0);
             if (!fits && work) {
-                // A batch that does not fit the strip (a repeat family's bucket, a skewed guide set) is done in pieces of cap_g groups x kKC
-                // candidates fetched on the spot, through the same registers: correct for any input, the common case never does it.
+                // An entry that does not fit the strip (more candidates than it holds: a skewed guide set) is done in pieces of cap_g
+                // groups x kKC candidates fetched on the spot, through the same registers: correct for any input, the common case
+                // never does it.
                 for (uint32_t t0 = e.g0; t0 < e.g1; t0 += cap_g) {
                     const uint32_t t1 = min(e.g1, t0 + cap_g);
                     load_groups(t0, t1, kreg);
@@ -508,10 +536,12 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                     }
                 }
             }
-            // ---- request what the next batches need: boundaries of batch +3, candidate ids of +2, guide entries and groups of +1 ----
-            uint32_t dG3, dI3;
-            load_desc(q + 3 * n_waves, dG3, dI3);
-            const Extent e1 = extent_of(q + n_waves, dG1, dI1), e2 = extent_of(q + 2 * n_waves, dG2, dI2);
+            // ---- request what the next batches need: the work entry of batch +4, boundaries of +3, candidate ids of +2, guide entries
+            //      and groups of +1 ----
+            uint32_t dE4, dG3, dI3;
+            load_entry(q + 4 * n_waves, dE4);
+            load_desc(q + 3 * n_waves, dE3, dG3, dI3);
+            const Extent e1 = extent_of(q + n_waves, dE1, dG1, dI1), e2 = extent_of(q + 2 * n_waves, dE2, dG2, dI2);
 #pragma unroll
             for (int j = 0; j < kGidRegs; ++j) greg_a[j] = greg_b[j];
             load_gids(e2.c0, min(e2.c1, e2.c0 + (uint32_t)kKC), greg_b);
@@ -519,20 +549,11 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             load_groups(e1.g0, min(e1.g1, e1.g0 + cap_g), kreg);
             // ---- compute this batch out of LDS ----
             if (n_jobs) rows(e, n_jobs);
-            {   // executed pair tests: every target of a bucket against every candidate of it (lane i: bucket i; a sliced bucket
-                // counts in its first slice)
-                const uint32_t nt = row_next(dB) - dB, ng = row_next(dI0) - dI0;
-                if (lane < e.nbv && (!S.sl_shift || (q & (n_slices - 1u)) == 0)) pairs[side] += (unsigned long long)nt * ng;
-            }
+            dE0 = dE1; dE1 = dE2; dE2 = dE3; dE3 = dE4;
             dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
         }
     }
     hs.finish();
-    if (pairs[0]) atomicAdd(&blk_pairs[0], pairs[0]);   // lanes 0 .. NB - 1 carry something
-    if (pairs[1]) atomicAdd(&blk_pairs[1], pairs[1]);
-    __syncthreads();
-    // 64 x 2 counters instead of 2: atomics on ONE address complete at ~90 per microsecond
-    if (threadIdx.x < 2 && blk_pairs[threadIdx.x]) atomicAdd(cursor + kPairSlotBase + (blockIdx.x & (kPairSlots - 1)) * 2 + threadIdx.x, blk_pairs[threadIdx.x]);
 }
 
 }  // namespace ffh
