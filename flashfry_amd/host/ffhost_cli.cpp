@@ -217,17 +217,70 @@ int runScore(int argc, char **argv) {
     return 0;
 }
 
+// ---- bulge: BASELINE.json config C5 -- Cas12a (TTTV) off-targets with <= N mismatches AND <= 1 one-base bulge --------------------
+// No counterpart in the reference (it has no gap search): the alignment rules are DESIGN.md section 8 / csrc/ffh_bulge.hpp.  The table is
+// this repository's own: one row per (guide, off-target), guides in FASTA order, off-targets in database order.
+int runBulge(int argc, char **argv) {
+    const Options o = parse(argc, argv, {"tttv"}, {"fasta", "database", "output", "maxMismatch", "maxBulge", "flankingSequence", "gpus", "devices"});
+    require(o, {"fasta", "database", "output"});
+    const int maxMismatch = o.num("maxMismatch", 3), maxBulge = o.num("maxBulge", 1);
+    const std::string db = o.str("database");
+    const HeaderInfo hdr = readHeaderInfo(db);
+    if (hdr.enzymeIndex != 1) throw Error("the bulge search is specified for Cas12a / Cpf1 databases (enzyme cpf1) only");
+    const ParameterPack &pack = ParameterPack::indexToParameterPack(hdr.enzymeIndex);
+    BitEncoding bitCoder(pack);
+    const std::vector<CRISPRSite> sites = findTargetSites(o.str("fasta"), pack, o.num("flankingSequence", 6));
+    std::vector<uint64_t> longs;
+    for (const auto &s : sites) longs.push_back(bitCoder.bitEncodeString(s.bases, 1));
+    std::fprintf(stderr, "bulge search for %zu guides, <= %d mismatches, <= %d bulge%s\n", sites.size(), maxMismatch, maxBulge, o.has("tttv") ? ", TTTV sites only" : "");
+    const std::vector<int> devs = deviceList(o);
+    // bin shards on several GPUs concatenate in shard order = database order (no cut-off, no scores: nothing to exchange)
+    std::vector<ffh_ctx *> ctx(devs.size(), nullptr);
+    std::vector<ffh_bulge_result *> res(devs.size(), nullptr);
+    const uint32_t nBins = (uint32_t)hdr.binBytes.size();
+    FILE *out = std::fopen(o.str("output").c_str(), "w");
+    if (!out) throw Error("cannot write " + o.str("output"));
+    std::string err;
+    for (size_t d = 0; d < devs.size() && err.empty(); ++d) {
+        ctx[d] = ffh_create(devs[d], 0);
+        if (!ctx[d]) { err = ffh_last_error(nullptr); break; }
+        const uint32_t b0 = (uint32_t)((uint64_t)nBins * d / devs.size()), b1 = (uint32_t)((uint64_t)nBins * (d + 1) / devs.size());
+        if (ffh_db_open(ctx[d], db.c_str(), b0, b1) ||
+            ffh_discover_bulge(ctx[d], longs.data(), (uint32_t)longs.size(), maxMismatch, maxBulge, o.has("tttv") ? FFH_BULGE_PAM_TTTV : 0u, &res[d]))
+            err = ffh_last_error(ctx[d]);
+    }
+    if (err.empty()) {
+        std::fprintf(out, "guide\tguideSequence\toffTarget\tcount\tmismatches\tbulgeType\tbulgePosition\n");
+        static const char *kind[3] = {"none", "RNA", "DNA"};
+        for (size_t g = 0; g < sites.size(); ++g)
+            for (size_t d = 0; d < devs.size(); ++d) {
+                const uint64_t *go = ffh_bulge_result_guide_offsets(res[d]), *ht = ffh_bulge_result_hit_targets(res[d]);
+                const uint8_t *mm = ffh_bulge_result_hit_mismatches(res[d]), *ty = ffh_bulge_result_hit_bulge_type(res[d]), *ps = ffh_bulge_result_hit_bulge_position(res[d]);
+                for (uint64_t h = go[g]; h < go[g + 1]; ++h) {
+                    const StringCount sc = bitCoder.bitDecodeString(ht[h]);
+                    std::fprintf(out, "%s:%d\t%s\t%s\t%d\t%u\t%s\t%u\n", sites[g].contig.c_str(), sites[g].position, sites[g].bases.c_str(), sc.str.c_str(), sc.count,
+                                 (unsigned)mm[h], kind[ty[h] < 3 ? ty[h] : 0], (unsigned)ps[h]);
+                }
+            }
+    }
+    std::fclose(out);
+    for (size_t d = 0; d < devs.size(); ++d) { if (res[d]) ffh_bulge_result_free(res[d]); if (ctx[d]) ffh_destroy(ctx[d]); }
+    if (!err.empty()) throw Error(err);
+    return 0;
+}
+
 }  // namespace ffhost
 
 static void usage() {
     std::fprintf(stderr,
-                 "flashfry-hip <index|discover|score> [options]   (MI355X build of FlashFry's discover/score path)\n"
+                 "flashfry-hip <index|discover|score|bulge> [options]   (MI355X build of FlashFry's discover/score path)\n"
                  "  index    --reference FILE --database FILE [--enzyme spcas9ngg] [--binSize 7] [--tmpLocation DIR]\n"
                  "  discover --database FILE --fasta FILE --output FILE [--positionOutput] [--maxMismatch 4] [--flankingSequence 6]\n"
                  "           [--maximumOffTargets 2000] [--minGC 0] [--maxGC 1] [--forceLinear] [--gpus N]\n"
                  "  score    --input FILE --output FILE --database FILE\n"
                  "           --scoringMetrics hsu2013,doench2016cfd,minot,dangerous,jostandsantos,reciprocalofftargets\n"
-                 "           [--maxMismatch N] [--includeOTs] [--numericOutput] [--maxReciprocalMismatch 1]\n");
+                 "           [--maxMismatch N] [--includeOTs] [--numericOutput] [--maxReciprocalMismatch 1]\n"
+                 "  bulge    --database FILE(cpf1) --fasta FILE --output FILE [--maxMismatch 3] [--maxBulge 1] [--tttv] [--gpus N]\n");
 }
 
 int main(int argc, char **argv) {
@@ -239,6 +292,7 @@ int main(int argc, char **argv) {
         if (cmd == "index") rc = ffhost::runIndex(argc - 2, argv + 2);
         else if (cmd == "discover") rc = ffhost::runDiscover(argc - 2, argv + 2);
         else if (cmd == "score") rc = ffhost::runScore(argc - 2, argv + 2);
+        else if (cmd == "bulge") rc = ffhost::runBulge(argc - 2, argv + 2);
         else { usage(); return 2; }
         std::fprintf(stderr, "Total runtime %.2f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());  // Main.scala:63
         return rc;

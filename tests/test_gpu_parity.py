@@ -620,3 +620,82 @@ def test_hit_lists_without_positions(capi, oracle):
     assert np.array_equal(lean.hit_mismatches, full.hit_mismatches)
     assert lean.hit_cfd.tobytes() == full.hit_cfd.tobytes() and lean.summaries.tobytes() == full.summaries.tobytes()
     assert np.array_equal((lean.hit_targets >> np.uint64(48)).astype(np.int64), np.diff(full.pos_offsets.astype(np.int64)))
+
+
+def _bulge_by_prefix_suffix_sums(g_bases, t_bases, max_bulge):
+    """A second, independently written checker of the bulge specification: instead of re-counting every
+    alignment base by base (the oracle's triple loop), the mismatch indicators of the three diagonals of the alignment matrix
+    -- guide i against target i, i - 1, i + 1 -- are cumulated once; an alignment with one gap is a prefix of the main diagonal
+    plus a suffix of an off diagonal, so every candidate is two table look-ups (the DP over <= 1 gap, unrolled).  Vectorised over
+    all targets.  Returns (best mismatches, type 0 none / 1 RNA / 2 DNA, position)."""
+    n = 20
+    T = t_bases.shape[0]
+    d0 = (t_bases != g_bases[None, :]).astype(np.int32)                       # g_i vs t_i
+    dm = (t_bases[:, :n - 1] != g_bases[None, 1:]).astype(np.int32)           # g_i vs t_{i-1}, i = 1..19  (index i - 1)
+    dp = (t_bases[:, 1:] != g_bases[None, :n - 1]).astype(np.int32)           # g_i vs t_{i+1}, i = 0..18  (index i)
+    pre0 = np.concatenate([np.zeros((T, 1), np.int32), np.cumsum(d0, 1)], 1)  # pre0[:, k] = mismatches of pairs 0 .. k-1
+    sm = np.concatenate([np.cumsum(dm[:, ::-1], 1)[:, ::-1], np.zeros((T, 1), np.int32)], 1)   # sm[:, j] = sum dm[j:]
+    sp = np.concatenate([np.cumsum(dp[:, ::-1], 1)[:, ::-1], np.zeros((T, 1), np.int32)], 1)   # sp[:, j] = sum dp[j:]
+    best = pre0[:, n].copy()
+    btype = np.zeros(T, np.int32)
+    bpos = np.zeros(T, np.int32)
+    if max_bulge:
+        for kind in (1, 2):                                                    # RNA first: it wins ties against DNA
+            for k in range(1, n - 1):
+                # RNA bulge at k: guide base k unpaired, g_i ~ t_{i-1} for i > k  -> dm indices k .. 18
+                # DNA bulge at k: target base k unpaired, g_i ~ t_{i+1} for k <= i <= 18 -> dp indices k .. 18
+                mm = pre0[:, k] + (sm[:, k] if kind == 1 else sp[:, k])
+                better = mm < best
+                best = np.where(better, mm, best)
+                btype = np.where(better, kind, btype)
+                bpos = np.where(better, k, bpos)
+    return best, btype, bpos
+
+
+def test_cas12a_bulge_search_against_a_second_independent_checker(capi, oracle):
+    """the same specification checked by differently structured code (cumulated diagonals instead of per-alignment loops), on a larger
+    database than the oracle's pair-by-pair loop can cover: 60 000 targets x 60 guides = 3.6e6 pairs, three parameter sets"""
+    rng = np.random.default_rng(2024)
+    raw = np.unique(rng.integers(0, 1 << 40, size=60000, dtype=np.uint64))
+    guides40 = rng.integers(0, 1 << 40, size=60, dtype=np.uint64)
+    extra = []
+    for g in guides40:                                                          # near-copies so that every alignment kind occurs
+        bases = [(int(g) >> (2 * (19 - i))) & 3 for i in range(20)]
+        for _ in range(25):
+            kind, pos = int(rng.integers(0, 3)), int(rng.integers(1, 19))
+            tb = list(bases) if kind == 0 else (bases[:pos] + bases[pos + 1:] + [int(rng.integers(0, 4))] if kind == 1 else (bases[:pos] + [int(rng.integers(0, 4))] + bases[pos:])[:20])
+            for _ in range(int(rng.integers(0, 4))):
+                tb[int(rng.integers(0, 20))] = int(rng.integers(0, 4))
+            v = 0
+            for b in tb:
+                v = (v << 2) | b
+            extra.append(v)
+    raw = np.unique(np.concatenate([raw, np.array(extra, dtype=np.uint64)]))
+    pam_n = rng.integers(0, 4, size=len(raw)).astype(np.uint64)
+    seq = (np.uint64(0b111111) << np.uint64(42)) | (pam_n << np.uint64(40)) | raw
+    binkey = (seq >> np.uint64(2 * (24 - 11))) & np.uint64(0x3FFF)
+    seq = seq[np.lexsort((seq, binkey))]
+    targets = seq | (np.uint64(1) << np.uint64(48))
+    positions = rng.integers(0, 1 << 27, size=len(seq), dtype=np.uint64)
+    guides = guides40 | np.uint64(0b11111100 << 40) | np.uint64(1 << 48)
+    shifts = (2 * (19 - np.arange(20))).astype(np.uint64)
+    t_bases = ((seq[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.int8)
+    for max_mm, max_bulge, tttv in ((3, 1, False), (2, 1, True), (4, 0, False)):
+        with capi.Context(1) as ctx:
+            ctx.load_soa(targets, positions)
+            res = ctx.discover_bulge(guides, max_mm, max_bulge, tttv=tttv)
+        n_checked = 0
+        for gi, g in enumerate(guides40):
+            g_bases = ((np.uint64(g) >> shifts) & np.uint64(3)).astype(np.int8)
+            best, btype, bpos = _bulge_by_prefix_suffix_sums(g_bases, t_bases, max_bulge)
+            keep = best <= max_mm
+            if tttv:
+                keep &= ((seq >> np.uint64(40)) & np.uint64(3)) != 3
+            idx = np.nonzero(keep)[0]
+            a, b = int(res.guide_offsets[gi]), int(res.guide_offsets[gi + 1])
+            assert np.array_equal(res.hit_targets[a:b], targets[idx]), (gi, max_mm, max_bulge)
+            assert np.array_equal(res.hit_mismatches[a:b], best[idx].astype(np.uint8))
+            assert np.array_equal(res.hit_bulge_type[a:b], btype[idx].astype(np.uint8))
+            assert np.array_equal(res.hit_bulge_position[a:b], bpos[idx].astype(np.uint8))
+            n_checked += len(idx)
+        assert n_checked >= 60

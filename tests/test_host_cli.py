@@ -208,3 +208,60 @@ def test_empty_inputs_through_the_cli(cli, oracle, tmp_path):
         f.write(">nothing\nATATATATATATATATATATATATAT\n")          # no guide in here
     subprocess.check_call([cli, "discover", "--database", db, "--fasta", gfa, "--output", out], stderr=subprocess.DEVNULL)
     assert open(out).read().count("\n") == 1
+
+
+@pytest.mark.gpu
+def test_bulge_subcommand_writes_what_the_library_finds(cli, tmp_path):
+    """`flashfry-hip bulge` (config C5: Cas12a, mismatches + one bulge; this repository's own table, the reference has no such
+    search): its rows are exactly the library's hits for the guides the FASTA holds, guides in file order, hits in database order"""
+    from flashfry_amd import capi
+    fa = str(tmp_path / "genome.fa")
+    random_genome(fa, n_contigs=2, length=40000, seed=12)
+    db = str(tmp_path / "db")
+    assert subprocess.run([cli, "index", "--reference", fa, "--database", db, "--enzyme", "cpf1"], capture_output=True).returncode == 0
+    seq = "".join(l.strip() for l in open(fa) if not l.startswith(">")).upper()
+    rng = np.random.default_rng(5)
+    guides = []
+    while len(guides) < 12:   # forward TTTN sites cut out of the genome; every other one loses a base (an RNA-bulge relative of its site)
+        i = int(rng.integers(0, len(seq) - 30))
+        w = seq[i:i + 24]
+        if w.startswith("TTT") and set(w) <= set("ACGT") and not w.endswith("AAA"):
+            if len(guides) % 2:
+                k = int(rng.integers(6, 20))
+                w = w[:k] + w[k + 1:] + seq[i + 24]
+            guides.append(w)
+    gf = str(tmp_path / "guides.fa")
+    with open(gf, "w") as f:
+        for k, w in enumerate(guides):
+            f.write(">g%d\n%s\n" % (k, w))
+    out = str(tmp_path / "bulge.tsv")
+    r = subprocess.run([cli, "bulge", "--database", db, "--fasta", gf, "--output", out, "--maxMismatch", "2", "--maxBulge", "1"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert rows[0] == ["guide", "guideSequence", "offTarget", "count", "mismatches", "bulgeType", "bulgePosition"]
+    rows = rows[1:]
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    enc = lambda w: sum(code[ch] << (2 * (23 - i)) for i, ch in enumerate(w))
+    # the FASTA scan may find more than one site per record (both strands): take the guide sequences the CLI reports, in its order
+    order = []
+    for row in rows:
+        if not order or order[-1] != (row[0], row[1]):
+            order.append((row[0], row[1]))
+    longs = np.array([enc(s) | (1 << 48) for _, s in order], dtype=np.uint64)
+    with capi.Context(0) as ctx:
+        ctx.open(db)
+        res = ctx.discover_bulge(longs, 2, 1)
+    want = []
+    kinds = ["none", "RNA", "DNA"]
+    dec = lambda v: "".join("ACGT"[(int(v) >> (2 * (23 - i))) & 3] for i in range(24))
+    for gi, (name, s) in enumerate(order):
+        for h in range(int(res.guide_offsets[gi]), int(res.guide_offsets[gi + 1])):
+            t = int(res.hit_targets[h])
+            want.append([name, s, dec(t), str(t >> 48), str(int(res.hit_mismatches[h])), kinds[int(res.hit_bulge_type[h])], str(int(res.hit_bulge_position[h]))])
+    assert rows == want and len(rows) >= 12
+    assert {r_[5] for r_ in rows} >= {"none", "RNA"}
+    # a Cas9 database is refused
+    db9 = str(tmp_path / "db9")
+    assert subprocess.run([cli, "index", "--reference", fa, "--database", db9, "--enzyme", "spcas9ngg"], capture_output=True).returncode == 0
+    r = subprocess.run([cli, "bulge", "--database", db9, "--fasta", gf, "--output", out], capture_output=True)
+    assert r.returncode == 1 and b"Cas12a" in r.stderr
