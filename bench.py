@@ -267,24 +267,24 @@ def verify_step(torch, ctx, db, guides_np, step_result, args):
     sample of guides the delivered hit list must be exactly what a brute-force scan of all targets + the ordered cut-off
     (CRISPRSiteOT.scala:39-46) gives.  Raises on any difference."""
     G = len(guides_np)
-    times, times_np = [], []
+    variants = (("no_positions", dict(positions=False, hit_scores=False)),   # what `discover` delivers unless --positionOutput is given
+                ("lists", dict(hit_scores=False)),                           # sequences, counts, mismatches AND positions: the reference's product
+                ("lists_and_hit_scores", dict()))                            # + the per-hit pam*cfd array (an extra of this library)
+    med = {}
     full = None
-    for _ in range(3):   # hit lists WITHOUT the position arrays: what `discover` delivers unless --positionOutput is given
-        full = None      # the previous result goes back to the page-locked pool first
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        full = ctx.discover(guides_np, args.max_mismatch, args.max_offtargets, positions=False)
-        times_np.append((time.perf_counter() - t0) * 1e3)
-    if full.summaries.tobytes() != step_result.summaries.tobytes() or full.positions is not None:
-        raise SystemExit("bench verification failed: the position-less discover differs")
-    for _ in range(3):
-        full = None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        full = ctx.discover(guides_np, args.max_mismatch, args.max_offtargets)
-        times.append((time.perf_counter() - t0) * 1e3)
-    if full.summaries.tobytes() != step_result.summaries.tobytes():
-        raise SystemExit("bench verification failed: aggregates-only summaries differ from the list-delivering discover")
+    for name, kw in variants:
+        times = []
+        for _ in range(3):
+            full = None      # the previous result goes back to the page-locked pool first
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            full = ctx.discover(guides_np, args.max_mismatch, args.max_offtargets, **kw)
+            times.append((time.perf_counter() - t0) * 1e3)
+        med[name] = float(np.median(times))
+        if full.summaries.tobytes() != step_result.summaries.tobytes():
+            raise SystemExit("bench verification failed: aggregates-only summaries differ from the list-delivering discover (%s)" % name)
+        if name == "no_positions" and full.positions is not None:
+            raise SystemExit("bench verification failed: the position-less discover delivered positions")
     sample = sorted(set(list(range(0, G, max(1, G // 12)))[:12] + [1, G // 3 + 1, G - 1]))
     cnt_all = (db["targets"] >> 48) & 0xFFFF
     for g in sample:
@@ -307,7 +307,7 @@ def verify_step(torch, ctx, db, guides_np, step_result, args):
                 raise SystemExit("bench verification failed: positions of guide %d differ" % g)
     note = ("summaries of the timed aggregates-only step == summaries of a list-delivering ffh_discover (bytes); hit lists and positions of %d "
             "sampled guides == brute-force torch scan of all targets + ordered cut-off" % len(sample))
-    return True, (float(np.median(times)), float(np.median(times_np))), note
+    return True, med, note
 
 
 def skewed_workload(torch, capi, synth, ctx_uniform, dev, local, args):
@@ -550,10 +550,13 @@ def main():
             # comparable with the reference's BitEncoding.allComparisons counter
             "executed_pair_tests_per_step": pairs, "executed_pair_tests_per_s": pairs * args.steps / dt,
             "verified": verified, "verification": verify_note,
-            # the complete discover product: scan + cut-off + scores + retained hit lists and their positions copied to the host
-            "discover_with_lists_ms": lists_ms[0] if lists_ms else None,
+            # the complete discover product: scan + cut-off + aggregates + the retained hits (target long incl. count, mismatches) and
+            # their positions on the host -- what ResultsAggregator hands to the writer (CRISPRHit: sequence, count, coordinates)
+            "discover_with_lists_ms": lists_ms["lists"] if lists_ms else None,
             # ... without the position arrays (the reference's discover table prints them only with --positionOutput)
-            "discover_with_lists_no_positions_ms": lists_ms[1] if lists_ms else None,
+            "discover_with_lists_no_positions_ms": lists_ms["no_positions"] if lists_ms else None,
+            # ... with this library's per-hit pam*cfd array on top (8 more bytes per hit across the link)
+            "discover_with_lists_and_hit_scores_ms": lists_ms["lists_and_hit_scores"] if lists_ms else None,
             "roofline": {"bound": "valu-issue", "kernel": "ffh::k_compare",
                          # SURVEY.md section 8d's HBM figure: algorithmic bytes of the launch against the 8 TB/s data-sheet peak
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

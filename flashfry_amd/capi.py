@@ -17,6 +17,7 @@ FINALIZE_SUMMARIES_ONLY = 1
 FINALIZE_JOST = 2
 FINALIZE_PRIOR_ON_DEVICE = 4
 FINALIZE_NO_POSITIONS = 8
+FINALIZE_NO_HIT_SCORES = 16
 
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -206,7 +207,7 @@ class Result:
     """An ffh_result: guides in input order, hits in database order, already cut off.  The arrays are read-only views
     of the library's (page-locked) result block, released when the last of them is garbage-collected."""
 
-    def __init__(self, L, h, lists=True, positions=True):
+    def __init__(self, L, h, lists=True, positions=True, hit_scores=True):
         own = _ResultOwner(L, h)
         n = L.ffh_result_n_guides(h)
         self._L, self._own, self.n_guides = L, own, n
@@ -222,9 +223,8 @@ class Result:
         if lists:
             self.hit_targets = _view(own, L.ffh_result_hit_targets(h), H, np.uint64)
             self.hit_mismatches = _view(own, L.ffh_result_hit_mismatches(h), H, np.uint8)
-            self.hit_cfd = _view(own, L.ffh_result_hit_cfd(h), H, np.float64)
-            if positions:
-                self.pos_offsets = _view(own, L.ffh_result_pos_offsets(h), H + 1, np.uint64)
+            self.hit_cfd = _view(own, L.ffh_result_hit_cfd(h), H, np.float64) if hit_scores else None  # FFH_FINALIZE_NO_HIT_SCORES
+            if positions:   # pos_offsets: folded by the library on first use (__getattr__), like the offsets of an aggregates-only result
                 self.positions = _view(own, L.ffh_result_positions(h), P, np.uint64)
             else:  # FFH_FINALIZE_NO_POSITIONS: the count of a hit is in bits 63:48 of its target long
                 self.pos_offsets = self.positions = None
@@ -236,6 +236,9 @@ class Result:
         if name == "guide_offsets":
             self.guide_offsets = _view(self._own, self._L.ffh_result_guide_offsets(self._own.h), self.n_guides + 1, np.uint64)
             return self.guide_offsets
+        if name == "pos_offsets":
+            self.pos_offsets = _view(self._own, self._L.ffh_result_pos_offsets(self._own.h), self.n_hits + 1, np.uint64)
+            return self.pos_offsets
         raise AttributeError(name)
 
     def hits(self, g):
@@ -435,7 +438,7 @@ class Context:
         self._check(self.L.ffh_finalize(self.h, C.cast(C.c_void_p(prior_device_ptr), u32p), max_offtargets, flags, C.byref(out)))
         return Result(self.L, out.value, lists=not summaries_only)
 
-    def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False, jost=False, positions=True):
+    def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False, jost=False, positions=True, hit_scores=True):
         out = C.c_void_p()
         pt = None
         if prior_totals is not None:
@@ -443,12 +446,12 @@ class Context:
             assert len(pt) == self._n_guides
         self._check(self.L.ffh_finalize(self.h, pt.ctypes.data_as(u32p) if pt is not None else None, max_offtargets,
                                         (FINALIZE_SUMMARIES_ONLY if summaries_only else 0) | (FINALIZE_JOST if jost else 0) |
-                                        (0 if positions else FINALIZE_NO_POSITIONS), C.byref(out)))
-        return Result(self.L, out.value, lists=not summaries_only, positions=positions)
+                                        (0 if positions else FINALIZE_NO_POSITIONS) | (0 if hit_scores else FINALIZE_NO_HIT_SCORES), C.byref(out)))
+        return Result(self.L, out.value, lists=not summaries_only, positions=positions, hit_scores=hit_scores)
 
-    def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False, positions=True):
+    def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False, positions=True, hit_scores=True):
         self.scan(guides, max_mismatch)
-        return self.finalize(max_offtargets, None, summaries_only, jost, positions)
+        return self.finalize(max_offtargets, None, summaries_only, jost, positions, hit_scores)
 
     def score_lists(self, guides, guide_offsets, hit_targets):
         """the `score` path: score caller-supplied hit lists (CSR) on the device"""

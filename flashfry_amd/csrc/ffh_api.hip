@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/flashfry_hip.h"
@@ -111,7 +112,7 @@ struct PinnedPool {
     }
     void put(void *p, size_t cap) {
         std::lock_guard<std::mutex> g(m);
-        if (free_blocks.size() >= 4) { (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
+        if (free_blocks.size() >= 6) { (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
         free_blocks.emplace_back(p, cap);
     }
     ~PinnedPool() { for (auto &b : free_blocks) (void)hipHostFree(b.first); }
@@ -120,46 +121,59 @@ struct PinnedPool {
 struct ffh_result {
     uint32_t n_guides = 0;
     uint64_t n_hits = 0, n_positions = 0;
-    bool offsets_pending = false;  // aggregates-only result: guide_offsets / n_hits are folded from the summaries when first asked for
+    bool offsets_pending = false;      // aggregates-only result: guide_offsets / n_hits are folded from the summaries when first asked for
+    bool pos_offsets_pending = false;  // pos_offsets are folded from the counts in the hit target longs when first asked for
     int scores_valid = 0;
-    // all arrays live in one pinned block owned by the context's pool
+    // the arrays live in two pinned blocks owned by the context's pool: everything per guide and per hit, and the positions
+    // (whose number is known only after the per-hit arrays are on their way to the host)
     std::shared_ptr<PinnedPool> pool;
-    void *block = nullptr;
-    size_t block_cap = 0;
+    void *block = nullptr, *block2 = nullptr;
+    size_t block_cap = 0, block2_cap = 0;
     ffh_guide_summary *summaries = nullptr;
     uint64_t *guide_offsets = nullptr, *hit_targets = nullptr, *pos_offsets = nullptr, *positions = nullptr;
     double *hit_cfd = nullptr;
     uint8_t *hit_mm = nullptr;
 
-    // lays the arrays out in one block; lists == false keeps only summaries + guide offsets
-    bool allocate(const std::shared_ptr<PinnedPool> &p, uint32_t G, uint64_t H, uint64_t P, bool lists, bool with_positions = true) {
+    // lists == false keeps only summaries + guide offsets
+    bool allocate(const std::shared_ptr<PinnedPool> &p, uint32_t G, uint64_t H, bool lists, bool with_cfd = true, bool with_pos_offsets = true) {
         pool = p;
-        n_guides = G; n_hits = H; n_positions = (lists && with_positions) ? P : 0;
+        n_guides = G; n_hits = H;
         auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
         size_t o_sum = 0, o_goff = o_sum + up((size_t)G * sizeof(ffh_guide_summary)), o_ht = o_goff + up(((size_t)G + 1) * 8);
-        size_t o_cfd = o_ht, o_poff = o_ht, o_pos = o_ht, o_mm = o_ht, total = o_ht;
+        size_t o_cfd = o_ht, o_poff = o_ht, o_mm = o_ht, total = o_ht;
         if (lists) {
-            o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + up((size_t)H * 8);
-            o_pos = o_poff + (with_positions ? up(((size_t)H + 1) * 8) : 0);
-            o_mm = o_pos + (with_positions ? up((size_t)P * 8) : 0); total = o_mm + up((size_t)H);
+            o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + (with_cfd ? up((size_t)H * 8) : 0);
+            o_mm = o_poff + (with_pos_offsets ? up(((size_t)H + 1) * 8) : 0); total = o_mm + up((size_t)H);
         }
         block = pool->get(total + 64, block_cap);
         if (!block) return false;
         char *b = (char *)block;
         summaries = (ffh_guide_summary *)(b + o_sum); guide_offsets = (uint64_t *)(b + o_goff);
         if (lists) {
-            hit_targets = (uint64_t *)(b + o_ht); hit_cfd = (double *)(b + o_cfd); hit_mm = (uint8_t *)(b + o_mm);
-            if (with_positions) { pos_offsets = (uint64_t *)(b + o_poff); positions = (uint64_t *)(b + o_pos); }
+            hit_targets = (uint64_t *)(b + o_ht); hit_mm = (uint8_t *)(b + o_mm);
+            if (with_cfd) hit_cfd = (double *)(b + o_cfd);
+            if (with_pos_offsets) pos_offsets = (uint64_t *)(b + o_poff);
         }
         return true;
     }
-    ~ffh_result() { if (block && pool) pool->put(block, block_cap); }
+    bool allocate_positions(uint64_t P) {
+        n_positions = P;
+        block2 = pool->get((size_t)P * 8 + 64, block2_cap);
+        positions = (uint64_t *)block2;
+        return block2 != nullptr;
+    }
+    ~ffh_result() {
+        if (block && pool) pool->put(block, block_cap);
+        if (block2 && pool) pool->put(block2, block2_cap);
+    }
 };
 
 struct ffh_ctx {
     int device = 0, enzyme = 0;
     hipStream_t st = nullptr;
     hipStream_t own_st = nullptr;  // the stream the context created; st may name the caller's instead (ffh_use_stream)
+    hipStream_t copy_st = nullptr; // result copies to the host that run beside the kernels still producing the rest of the result
+    hipEvent_t copy_ev = nullptr;
     bool borrowed = false;
     Geometry geo{};
     std::string err;
@@ -205,8 +219,8 @@ struct ffh_ctx {
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
 
     // finalize scratch
-    DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals;
-    DevBuf<uint64_t> ret_off, out_target, out_posoff, out_pos;
+    DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals, hit_pre;
+    DevBuf<uint64_t> ret_off, pos_base, out_target, out_posoff, out_pos;
     DevBuf<uint8_t> out_mm;
     DevBuf<double> out_cfd, out_hsu, out_jost;
     DevBuf<GuideSummary> summ;
@@ -467,6 +481,8 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_st, hipStreamNonBlocking);
     ctx->st = ctx->own_st;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
@@ -495,6 +511,8 @@ void ffh_destroy(ffh_ctx *ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
+    if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
     if (ctx->own_st) (void)hipStreamDestroy(ctx->own_st);
     delete ctx;  // the device buffers free themselves
 }
@@ -952,7 +970,7 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
     if (ctx->n_guides) {
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
-                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p);
+                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p, (uint32_t *)nullptr);
         FFH_HIP(hipMemcpyAsync(totals, ctx->totals.p, (size_t)ctx->n_guides * 4, hipMemcpyDeviceToHost, ctx->st));
     }
     FFH_HIP(hipStreamSynchronize(ctx->st));
@@ -967,7 +985,7 @@ int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals, uint32_t clam
     { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
     if (ctx->n_guides)
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(ctx->n_guides, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, (const uint32_t *)nullptr,
-                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, device_totals);
+                           ctx->n_guides, clamp, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, device_totals, (uint32_t *)nullptr);
     FFH_HIP(hipGetLastError());
     FFH_HIP(hipStreamSynchronize(ctx->st));
     return FFH_OK;
@@ -981,6 +999,14 @@ int ffh_summaries_to_device(ffh_ctx *ctx, void *device_summaries) {
     if (ctx->n_guides) FFH_HIP(hipMemcpyAsync(device_summaries, ctx->summ.p, (size_t)ctx->n_guides * sizeof(ffh_guide_summary), hipMemcpyDeviceToDevice, ctx->st));
     FFH_HIP(hipStreamSynchronize(ctx->st));
     return FFH_OK;
+}
+
+// device -> page-locked host.  (A copy kernel of our own with a few persistent blocks storing into the mapped result block was
+// tried in place of the runtime's copy, which is a kernel too (__amd_rocclr_copyBuffer): 16 blocks reach 36 GB/s and leave the
+// kernels beside them alone, 64 blocks reach the runtime's 53-55 GB/s and slow them 5-30x exactly as the runtime's copy does --
+// it is the host-bound write traffic, not the CUs it occupies.  End to end the runtime's copy was 0.4-0.7 ms faster.)
+static hipError_t copy_out(ffh_ctx *, void *host, const void *dev, size_t bytes, hipStream_t st) {
+    return bytes ? hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
 }
 
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets, unsigned flags, ffh_result **out) {
@@ -1007,17 +1033,21 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     if (flags & FFH_FINALIZE_SUMMARIES_ONLY) {
         // aggregates only: one fused pass per guide (cut-off, scores, ordered sums), no per-hit arrays, one synchronisation
         ffh_result *r = new (std::nothrow) ffh_result();
-        if (!r || !r->allocate(ctx->pool, G, 0, 0, false)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+        if (!r || !r->allocate(ctx->pool, G, 0, false)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
         r->scores_valid = ctx->geo.cas9_23;
+        // the kernel stores every summary into the result's page-locked block as well (hipHostMalloc memory is mapped into the
+        // device's address space): the 88 bytes per guide cross the link under the kernel instead of in a copy after it
+        static const bool zero_copy = !(getenv("FFH_SUMMARY_COPY") && atoi(getenv("FFH_SUMMARY_COPY")) == 1);
         if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
-                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr);
+                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                  zero_copy ? (GuideSummary *)r->summaries : (GuideSummary *)nullptr);
         // no scan of the per-guide hit counts and no copy of the offsets: nobody needs them to read the aggregates, and whoever
         // asks (ffh_result_guide_offsets / ffh_result_n_hits) gets them folded from the summaries' n_hits on the host
         hipError_t e = hipEventRecord(ctx->ev[1], st);
         if (e == hipSuccess) e = hipGetLastError();
-        if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+        if (G && e == hipSuccess && !zero_copy) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
         r->offsets_pending = true;
@@ -1029,54 +1059,66 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         return FFH_OK;
     }
     { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
+    const bool want_pos = !(flags & FFH_FINALIZE_NO_POSITIONS), want_cfd = !(flags & FFH_FINALIZE_NO_HIT_SCORES);
+    // ordered cut-off; with positions wanted it also leaves, per kept hit, the number of the guide's kept positions before it, so that
+    // every hit's slot in the position array follows from one scan over the guides (no scan over the hits, no second round trip)
+    if (want_pos) { FFH_HIP(ctx->hit_pre.reserve(ctx->n_raw + 1)); FFH_HIP(ctx->pos_base.reserve((size_t)G + 2)); }
     if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
-                              ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr);
+                              ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr, want_pos ? ctx->hit_pre.p : (uint32_t *)nullptr);
     exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
-    uint64_t Hr = 0;
+    uint64_t Hr = 0, Pr = 0;
     FFH_HIP(hipMemcpyAsync(&Hr, ctx->ret_off.p + G, 8, hipMemcpyDeviceToHost, st));
+    if (want_pos) {
+        exclusive_scan<uint32_t, uint64_t>(ctx->ot_count.p, G, ctx->pos_base.p, ctx->scan_tmp64.p, st);
+        FFH_HIP(hipMemcpyAsync(&Pr, ctx->pos_base.p + G, 8, hipMemcpyDeviceToHost, st));
+    }
     FFH_HIP(hipStreamSynchronize(st));
-    FFH_HIP(ctx->out_target.reserve(Hr + 1));
-    FFH_HIP(ctx->out_mm.reserve(Hr + 1));
+    FFH_HIP(ctx->out_target.reserve(Hr + 2));
+    FFH_HIP(ctx->out_mm.reserve(Hr + 16));
     FFH_HIP(ctx->out_cnt.reserve(std::max<uint64_t>(Hr, ctx->T) + 1));
     FFH_HIP(ctx->out_tidx.reserve(Hr + 1));
-    FFH_HIP(ctx->out_cfd.reserve(Hr + 1));
+    FFH_HIP(ctx->out_cfd.reserve(Hr + 2));
     FFH_HIP(ctx->out_hsu.reserve(Hr + 1));
     double *d_jost = nullptr;  // the CRISPRi aggregates are computed on request only: they cost a third per-hit array
     if (flags & FFH_FINALIZE_JOST) { FFH_HIP(ctx->out_jost.reserve(Hr + 1)); d_jost = ctx->out_jost.p; }
-    FFH_HIP(ctx->out_posoff.reserve(Hr + 2));
+    if (want_pos) { FFH_HIP(ctx->out_posoff.reserve(Hr + 2)); FFH_HIP(ctx->out_pos.reserve(Pr + 2)); }
+    ffh_result *r = new (std::nothrow) ffh_result();
+    if (!r || !r->allocate(ctx->pool, G, Hr, true, want_cfd, want_pos) || (want_pos && !r->allocate_positions(Pr))) {
+        delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM;
+    }
+    r->scores_valid = ctx->geo.cas9_23;
+    r->pos_offsets_pending = want_pos;  // never copied: hit h owns (hit_targets[h] >> 48) positions (settle_pos_offsets)
     if (ctx->n_raw)
         hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, G, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
                            ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
-                           ctx->out_hsu.p, d_jost);
-    exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, Hr, ctx->out_posoff.p, ctx->scan_tmp64.p, st);
-    uint64_t Pr = 0;
-    FFH_HIP(hipMemcpyAsync(&Pr, ctx->out_posoff.p + Hr, 8, hipMemcpyDeviceToHost, st));
-    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
-                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)d_jost, G, ctx->summ.p);
-    FFH_HIP(hipStreamSynchronize(st));
-    const bool want_lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY), want_pos = want_lists && !(flags & FFH_FINALIZE_NO_POSITIONS);
+                           ctx->out_hsu.p, d_jost, want_pos ? (const uint32_t *)ctx->hit_pre.p : (const uint32_t *)nullptr,
+                           want_pos ? (const uint64_t *)ctx->pos_base.p : (const uint64_t *)nullptr, want_pos ? ctx->out_posoff.p : (uint64_t *)nullptr);
+    // The link (~55 GB/s) is what a list-delivering call waits for: the per-hit arrays leave on the copy stream as soon as
+    // k_score_hits has written them; the positions are gathered beside that transfer and queue behind it; the aggregation and the
+    // small per-guide copies run on the main stream meanwhile.
+    hipError_t e = hipEventRecord(ctx->copy_ev, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_st, ctx->copy_ev, 0);
+    if (Hr && e == hipSuccess) e = copy_out(ctx, r->hit_targets, ctx->out_target.p, Hr * 8, ctx->copy_st);
+    if (Hr && e == hipSuccess) e = copy_out(ctx, r->hit_mm, ctx->out_mm.p, Hr, ctx->copy_st);
+    if (Hr && want_cfd && e == hipSuccess) e = copy_out(ctx, r->hit_cfd, ctx->out_cfd.p, Hr * 8, ctx->copy_st);
+    auto fail = [&](const char *what) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamSynchronize(st); ctx->err = std::string(what) + hipGetErrorString(e); delete r; return FFH_E_HIP; };
+    if (e != hipSuccess) return fail("result copy: ");
     if (want_pos) {
-        FFH_HIP(ctx->out_pos.reserve(Pr + 1));
         if (Hr) hipLaunchKernelGGL(k_gather_positions, dim3(blocks_for(Hr, 256)), dim3(256), 0, st, ctx->out_tidx.p, ctx->out_cnt.p, ctx->out_posoff.p, Hr, ctx->pos_off.p,
                                    ctx->positions.p, ctx->out_pos.p);
+        e = hipEventRecord(ctx->copy_ev, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_st, ctx->copy_ev, 0);
+        if (Pr && e == hipSuccess) e = copy_out(ctx, r->positions, ctx->out_pos.p, Pr * 8, ctx->copy_st);
     }
-    FFH_HIP(hipEventRecord(ctx->ev[1], st));
-    FFH_HIP(hipGetLastError());
-    ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r || !r->allocate(ctx->pool, G, Hr, Pr, want_lists, want_pos)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
-    r->scores_valid = ctx->geo.cas9_23;
-    hipError_t e = hipSuccess;
-    if (G) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
+                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)d_jost, G, ctx->summ.p);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], st);
+    if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
-    if (want_lists) {
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_targets, ctx->out_target.p, Hr * 8, hipMemcpyDeviceToHost, st);
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_mm, ctx->out_mm.p, Hr, hipMemcpyDeviceToHost, st);
-        if (Hr && e == hipSuccess) e = hipMemcpyAsync(r->hit_cfd, ctx->out_cfd.p, Hr * 8, hipMemcpyDeviceToHost, st);
-        if (want_pos && e == hipSuccess) e = hipMemcpyAsync(r->pos_offsets, ctx->out_posoff.p, (Hr + 1) * 8, hipMemcpyDeviceToHost, st);
-        if (want_pos && Pr && e == hipSuccess) e = hipMemcpyAsync(r->positions, ctx->out_pos.p, Pr * 8, hipMemcpyDeviceToHost, st);
-    }
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { ctx->err = std::string("result copy: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_st);
+    if (e != hipSuccess) return fail("result copy: ");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
     ctx->tm.finalize_ms = ms;
@@ -1138,7 +1180,7 @@ int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, con
                               ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)ctx->out_jost.p, G, ctx->summ.p);
     FFH_HIP(hipGetLastError());
     ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r || !r->allocate(ctx->pool, G, H, 0, true)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
+    if (!r || !r->allocate(ctx->pool, G, H, true)) { delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM; }
     r->scores_valid = ctx->geo.cas9_23;
     if (G) std::memcpy(r->guide_offsets, guide_offsets, ((size_t)G + 1) * 8);
     else r->guide_offsets[0] = 0;
@@ -1180,7 +1222,28 @@ const uint64_t *ffh_result_guide_offsets(const ffh_result *r) { settle_offsets(r
 const uint64_t *ffh_result_hit_targets(const ffh_result *r) { return r->hit_targets; }
 const uint8_t *ffh_result_hit_mismatches(const ffh_result *r) { return r->hit_mm; }
 const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd; }
-const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { return r->pos_offsets; }
+// exclusive prefix sums of the hits' position counts (bits 63:48 of the target longs), a few host threads over contiguous slices
+static void settle_pos_offsets(const ffh_result *cr) {
+    ffh_result *r = const_cast<ffh_result *>(cr);
+    if (!r->pos_offsets_pending) return;
+    r->pos_offsets_pending = false;
+    const uint64_t H = r->n_hits;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<uint64_t>(std::min(8u, hw), H / 262144 + 1);
+    std::vector<uint64_t> part(nt + 1, 0);
+    auto slice = [&](unsigned t, uint64_t &a, uint64_t &b) { a = H * t / nt; b = H * (t + 1) / nt; };
+    auto run = [&](auto &&fn) {
+        if (nt == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    run([&](unsigned t) { uint64_t a, b, s = 0; slice(t, a, b); for (uint64_t h = a; h < b; ++h) s += r->hit_targets[h] >> 48; part[t + 1] = s; });
+    for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
+    run([&](unsigned t) { uint64_t a, b, s = part[t]; slice(t, a, b); for (uint64_t h = a; h < b; ++h) { r->pos_offsets[h] = s; s += r->hit_targets[h] >> 48; } });
+    r->pos_offsets[H] = part[nt];
+}
+const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { if (r->pos_offsets) settle_pos_offsets(r); return r->pos_offsets; }
 const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions; }
 void ffh_result_free(ffh_result *r) { delete r; }
 
@@ -1529,7 +1592,7 @@ static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, cons
     if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
                               (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                               d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p,
-                              (GuideSummary *)d_summaries, d_totals, d_fix_totals);
+                              (GuideSummary *)d_summaries, d_totals, d_fix_totals, (GuideSummary *)nullptr);
     FFH_HIP(hipGetLastError());
     if (!d_fix_totals) { FFH_HIP(hipEventRecord(ctx->ev[1], ctx->st)); ctx->finalize_timing_pending = true; }
     FFH_HIP(fence_out(ctx));

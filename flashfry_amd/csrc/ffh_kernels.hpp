@@ -421,7 +421,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // reports min(sum of all counts, overflow) (multi-GPU exchange).
 __global__ __launch_bounds__(256) void k_cutoff(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
                                                 const uint32_t *__restrict__ prior, uint32_t n_guides, uint32_t overflow, uint32_t *__restrict__ n_ret,
-                                                uint32_t *__restrict__ ot_count, uint32_t *__restrict__ full, uint32_t *__restrict__ totals) {
+                                                uint32_t *__restrict__ ot_count, uint32_t *__restrict__ full, uint32_t *__restrict__ totals,
+                                                uint32_t *__restrict__ pre /* nullable: per kept hit, the guide's kept positions before it */) {
     const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_guides) return;
     const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(256) void k_cutoff(const uint32_t *__restrict__ seg
         const uint32_t c = in ? (uint32_t)(st[i + lane] >> 48) : 0u;
         const uint32_t incl = wave_inclusive_scan_u32(c, lane);
         const bool keep = in && (run + (incl - c) < overflow);
+        if (pre && keep) pre[i + lane] = run - p0 + (incl - c);
         const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
         kept += nk;
         if (nk) run += __shfl(incl, nk - 1, 64);
@@ -516,7 +518,9 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
                              const uint32_t *__restrict__ n_ret, const uint64_t *__restrict__ ret_off, const uint64_t *__restrict__ st,
                              const uint64_t *__restrict__ guides, Geometry geo, const ScoreTables *__restrict__ tab, uint64_t *__restrict__ out_target,
                              uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
-                             double *__restrict__ out_cfd, double *__restrict__ out_hsu, double *__restrict__ out_jost /* may be null */) {
+                             double *__restrict__ out_cfd, double *__restrict__ out_hsu, double *__restrict__ out_jost /* may be null */,
+                             const uint32_t *__restrict__ pre, const uint64_t *__restrict__ pos_base, uint64_t *__restrict__ out_posoff /* all three
+                             nullable: first position slot of every retained hit = the guide's base + the kept positions before the hit (k_cutoff) */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint64_t key = hits[i];
@@ -536,6 +540,7 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
     out_cfd[o] = cfd;
     out_hsu[o] = hsu;
     if (out_jost) out_jost[o] = (geo.c0 == 3 && mm != 0) ? jost_pair(guides[g], t, geo, tab) : __builtin_nan("");
+    if (out_posoff) out_posoff[o] = pos_base[g] + pre[i];
 }
 
 // the same for caller-supplied hit lists (the `score` path: hit lists re-read from a discover table)
@@ -673,7 +678,9 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
                                                         const ScoreTables *__restrict__ tab, uint32_t n_guides, uint32_t overflow, int want_jost,
                                                         uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out,
                                                         uint32_t *__restrict__ totals_out /* nullable: min(positions of all hits, overflow) */,
-                                                        const uint32_t *__restrict__ fix_totals /* nullable: redo only guides the prior changes */) {
+                                                        const uint32_t *__restrict__ fix_totals /* nullable: redo only guides the prior changes */,
+                                                        GuideSummary *__restrict__ host_out /* nullable: page-locked host copy of out[], written
+                                                        by the kernel itself so that no device-to-host copy follows the launch */) {
     __shared__ ScoreTables lt;  // 4.6 KB: the coefficient tables, read with rolled loops (low register count -> 8 waves per SIMD)
     {
         const double *src = reinterpret_cast<const double *>(tab);
@@ -742,6 +749,7 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     s.jost_max = jost_max; s.jost_sum = jost_sum;
     if (lane == 0) {
         out[g] = s; n_ret[g] = kept;
+        if (host_out) host_out[g] = s;
         if (totals_out) totals_out[g] = min(run - p0, overflow);
     }
 }

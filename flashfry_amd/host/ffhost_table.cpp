@@ -334,7 +334,7 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         for (size_t g = 0; g < ng; ++g) prior[d][g] = (uint32_t)std::min<uint64_t>((uint64_t)prior[d - 1][g] + totals[d - 1][g], (uint64_t)std::max(maximumOffTargets, 0));
     parallel([&](size_t d) {
         // without --positionOutput the table prints sequence_count_mismatches only: the position arrays stay on the device
-        if (ffh_finalize(ctx[d], d ? prior[d].data() : nullptr, maximumOffTargets, wantPositions ? 0u : FFH_FINALIZE_NO_POSITIONS, &res[d])) errs[d] = abiError(ctx[d]);
+        if (ffh_finalize(ctx[d], d ? prior[d].data() : nullptr, maximumOffTargets, FFH_FINALIZE_NO_HIT_SCORES | (wantPositions ? 0u : FFH_FINALIZE_NO_POSITIONS), &res[d])) errs[d] = abiError(ctx[d]);
     });
     auto t3 = clk::now();
     // deliver the hits in database order = shard order (what aggregator.updateOT would have received)
@@ -350,15 +350,15 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
         for (size_t d = 0; d < nd; ++d) {
             const ffh_result *r = res[d];
             const ffh_guide_summary &s = ffh_result_summaries(r)[g];
-            const uint64_t *go = ffh_result_guide_offsets(r), *ht = ffh_result_hit_targets(r), *po = ffh_result_pos_offsets(r), *pp = ffh_result_positions(r);
-            const double *cfd = ffh_result_hit_cfd(r);
+            const uint64_t *go = ffh_result_guide_offsets(r), *ht = ffh_result_hit_targets(r), *pp = ffh_result_positions(r);
+            const uint64_t *po = wantPositions ? ffh_result_pos_offsets(r) : nullptr;
+            // discover attaches no per-hit scores (they come from `score`, which calls ffh_score_lists): FFH_FINALIZE_NO_HIT_SCORES
             for (uint64_t h = go[g]; h < go[g + 1]; ++h) {
                 CRISPRHit hit;
                 hit.sequence = ht[h];
                 hit.nCoordinates = (uint32_t)(ht[h] >> 48);   // the occurrence count rides in bits 63:48 (BitEncoding.scala:46-67)
                 if (wantPositions) hit.coordinates.assign(pp + po[h], pp + po[h + 1]);
-                hit.hasCfd = cfd[h] == cfd[h];
-                hit.cfd = cfd[h];
+                hit.hasCfd = false;
                 ot.currentTotal += (long)hit.nCoordinates;
                 ot.offTargets.push_back(std::move(hit));
             }

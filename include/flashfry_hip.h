@@ -181,6 +181,10 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t cla
                                           nothing is gathered or copied for them.  What `discover` needs unless --positionOutput is
                                           given (modules/OffTargetDiscovery.scala:51-53): its table prints sequence_count_mismatches,
                                           and the count is in bits 63:48 of the hit's target long */
+#define FFH_FINALIZE_NO_HIT_SCORES 16u /* hit lists without the per-hit pam*cfd array (ffh_result_hit_cfd returns NULL): the reference's
+                                          discover delivers sequences, counts, mismatches and positions (crispr/CRISPRHit,
+                                          ResultsAggregator.scala:61-69), the scores are aggregates (ffh_guide_summary).  8 of the 17
+                                          bytes per hit that cross the link */
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
                  unsigned flags, ffh_result **out);
 
@@ -286,7 +290,9 @@ const uint64_t *ffh_result_guide_offsets(const ffh_result *r);           /* [n_g
 const uint64_t *ffh_result_hit_targets(const ffh_result *r);             /* [n_hits] target longs incl. count */
 const uint8_t  *ffh_result_hit_mismatches(const ffh_result *r);          /* [n_hits] */
 const double   *ffh_result_hit_cfd(const ffh_result *r);                 /* [n_hits] pam*cfd, NaN where not scored */
-const uint64_t *ffh_result_pos_offsets(const ffh_result *r);             /* [n_hits+1] into positions */
+const uint64_t *ffh_result_pos_offsets(const ffh_result *r);             /* [n_hits+1] into positions.  Not copied from the device:
+                                                                            hit h owns (hit_targets[h] >> 48) positions, the offsets are
+                                                                            folded from that on the host the first time they are asked for */
 const uint64_t *ffh_result_positions(const ffh_result *r);               /* [n_positions] BitPosition longs */
 void ffh_result_free(ffh_result *r);
 

@@ -46,7 +46,7 @@ JNIEXPORT jlong JNICALL FN(discover)(JNIEnv *e, jobject self, jlong ctx, jlongAr
     jlong *g = (*e)->GetLongArrayElements(e, guides, 0);
     if (!g) return 0;
     ffh_result *r = 0;
-    const int rc = ffh_discover(CTX(ctx), (const uint64_t *)g, (uint32_t)n, (int)max_mismatch, (int)max_offtargets, 0u, &r);
+    const int rc = ffh_discover(CTX(ctx), (const uint64_t *)g, (uint32_t)n, (int)max_mismatch, (int)max_offtargets, FFH_FINALIZE_NO_HIT_SCORES /* CRISPRHit carries the sequence and its positions; scores are ScoreModel work */, &r);
     (*e)->ReleaseLongArrayElements(e, guides, g, JNI_ABORT);
     return rc ? 0 : (jlong)(intptr_t)r;
 }

@@ -622,6 +622,39 @@ def test_hit_lists_without_positions(capi, oracle):
     assert np.array_equal((lean.hit_targets >> np.uint64(48)).astype(np.int64), np.diff(full.pos_offsets.astype(np.int64)))
 
 
+def test_hit_lists_without_per_hit_scores(capi, oracle):
+    """FFH_FINALIZE_NO_HIT_SCORES (what the CLI's discover and the JNI binding pass): sequences, mismatches, positions and aggregates
+    unchanged, no pam*cfd array; pos_offsets (never copied from the device, folded from the counts on first use) against the oracle"""
+    odb, t, p, g = dense_case(oracle, seed=6)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        full = ctx.discover(g, 4, 60, jost=True)
+        lean = ctx.finalize(60, jost=True, hit_scores=False)
+        bare = ctx.finalize(60, jost=True, hit_scores=False, positions=False)
+    ora = odb.discover(g, 4, 60)
+    assert lean.hit_cfd is None and bare.hit_cfd is None and bare.positions is None
+    for r in (lean, bare):
+        assert np.array_equal(r.guide_offsets, full.guide_offsets) and np.array_equal(r.hit_targets, full.hit_targets)
+        assert np.array_equal(r.hit_mismatches, full.hit_mismatches) and r.summaries.tobytes() == full.summaries.tobytes()
+    assert np.array_equal(lean.pos_offsets, full.pos_offsets) and np.array_equal(lean.positions, full.positions)
+    assert_same_hits(full, ora)
+    assert_same_hits(lean, ora)
+
+
+def test_position_offsets_of_a_large_result_are_folded_by_several_host_threads(capi, oracle):
+    """more than 262 144 retained hits: ffh_result_pos_offsets splits the fold over host threads; equal to numpy's cumulative sum"""
+    odb, t, p, g = dense_case(oracle, n_random=50000, n_guides=400, n_dense=400, variants=1600, seed=77)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        r = ctx.discover(g, 4, 100000, hit_scores=False)
+    assert r.n_hits > 300_000
+    want = np.concatenate([[0], np.cumsum((r.hit_targets >> np.uint64(48)).astype(np.uint64))]).astype(np.uint64)
+    assert np.array_equal(r.pos_offsets, want) and int(want[-1]) == r.n_positions == len(r.positions)
+    ora = odb.discover(g[:50], 4, 100000)
+    a = int(r.guide_offsets[50])
+    assert np.array_equal(r.positions[:int(r.pos_offsets[a])], ora.positions)
+
+
 def _bulge_by_prefix_suffix_sums(g_bases, t_bases, max_bulge):
     """A second, independently written checker of the bulge specification: instead of re-counting every
     alignment base by base (the oracle's triple loop), the mismatch indicators of the three diagonals of the alignment matrix

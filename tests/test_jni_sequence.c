@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     if (!ctx) FAIL("ffh_create: %s", ffh_last_error(NULL));            /* lastError(0) */
     if (ffh_db_open(ctx, db_path, 0, 0)) FAIL("ffh_db_open: %s", ffh_last_error(ctx));   /* dbOpen(ctx, path, 0, 0) */
     ffh_result *res = NULL;
-    if (ffh_discover(ctx, guides, (uint32_t)n, max_mm, max_ot, 0u, &res)) FAIL("ffh_discover: %s", ffh_last_error(ctx));
+    if (ffh_discover(ctx, guides, (uint32_t)n, max_mm, max_ot, FFH_FINALIZE_NO_HIT_SCORES, &res)) FAIL("ffh_discover: %s", ffh_last_error(ctx));
     const uint64_t *off = ffh_result_guide_offsets(res);               /* resultOffsets */
     const uint64_t *tg = ffh_result_hit_targets(res);                  /* resultTargets */
     const uint64_t *po = ffh_result_pos_offsets(res);                  /* resultPosOffsets */
