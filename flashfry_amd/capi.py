@@ -388,11 +388,13 @@ class Context:
         self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))
         return t[:self._n_guides]
 
-    def discover_bulge(self, guides, max_mismatch=3, max_bulge=1, tttv=False):
-        """config C5 (Cas12a): hits with <= max_mismatch mismatches and <= max_bulge one-base bulges; returns a BulgeResult (copies)"""
+    def discover_bulge(self, guides, max_mismatch=3, max_bulge=1, tttv=False, brute_force=False):
+        """config C5 (Cas12a): hits with <= max_mismatch mismatches and <= max_bulge one-base bulges; returns a BulgeResult (copies).
+        brute_force: every guide against every target (FFH_BULGE_BRUTE_FORCE) instead of the seeded candidate search"""
         g = np.ascontiguousarray(guides).view(np.uint64)
         out = C.c_void_p()
-        self._check(self.L.ffh_discover_bulge(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_bulge, 1 if tttv else 0, C.byref(out)))
+        self._check(self.L.ffh_discover_bulge(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_bulge, (1 if tttv else 0) | (2 if brute_force else 0),
+                                              C.byref(out)))
         try:
             return BulgeResult(self.L, out.value)
         finally:

@@ -1449,20 +1449,55 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
     int gbits = 1;
     while ((1u << gbits) < std::max<uint32_t>(n_guides, 2)) ++gbits;
     uint64_t n_hits = 0;
-    DevBuf<uint64_t> d_guides, key, val, alt_k, alt_v, d_target;
-    DevBuf<uint32_t> table, offs, scr32;
+    DevBuf<uint64_t> d_guides, key, val, alt_k, alt_v, d_target, d_dst, d_key, scr64;
+    DevBuf<uint32_t> table, offs, scr32, d_flag, d_pat[3];
     DevBuf<uint8_t> d_mm, d_type, d_pos;
+    const bool brute = (flags & FFH_BULGE_BRUTE_FORCE) != 0;
     if (n_guides && T) {
         FFH_HIP(d_guides.reserve(n_guides));
         FFH_HIP(hipMemcpyAsync(d_guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
+        // the seeds of the candidate search (ffh_bulge.hpp): P on the prefix image, D and R on the suffix image
+        BulgeSeed seeds[3];
+        int n_seeds = 0;
+        if (!brute) {
+            const int a = ctx->img[0].width, sfx = ctx->img[1].width;
+            for (int kind = 0; kind < (max_bulge ? 3 : 1); ++kind) {
+                const Image &im = ctx->img[kind == 0 ? 0 : 1];
+                const int w = kind == 0 ? a : sfx;
+                if (kind == 2 && w == 0) continue;  // one suffix bucket: seed D already visits it
+                std::vector<uint32_t> pat;
+                if (kind < 2) pat = patterns_for(ctx, w, max_mismatch);
+                else {  // R: max_mismatch substitutions over the s - 1 paired bases (bucket positions 1 .. s-1), any base at position 0
+                    const int n = w - 1;
+                    for (uint32_t q : patterns_for(ctx, n, max_mismatch)) {
+                        const uint32_t lo = q & ((1u << n) - 1u), hi = q >> n;
+                        for (uint32_t d = 0; d < 4; ++d) pat.push_back(((hi << 1 | (d >> 1)) << w) | (lo << 1 | (d & 1u)));
+                    }
+                }
+                if ((uint64_t)n_guides * ((pat.size() + 63) / 64) >= (1ull << 33)) { ctx->err = "too many guides x candidate buckets for one bulge search"; return FFH_E_ARG; }
+                FFH_HIP(d_pat[kind].reserve(pat.size()));
+                FFH_HIP(hipMemcpyAsync(d_pat[kind].p, pat.data(), pat.size() * 4, hipMemcpyHostToDevice, st));
+                FFH_HIP(hipStreamSynchronize(st));  // pat is a local
+                BulgeSeed &S = seeds[n_seeds++];
+                S.bstart = im.bstart.p; S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.patterns = d_pat[kind].p;
+                S.n_pat = (uint32_t)pat.size(); S.width = w; S.rest = im.rest; S.gw = (int)group_words((uint32_t)im.rest); S.kind = kind;
+            }
+        }
         unsigned long long *cursor = ctx->d_counters + 12;
         size_t cap = std::max<size_t>(1u << 20, (size_t)n_guides * 1024);
         for (;;) {
             FFH_HIP(key.reserve(cap)); FFH_HIP(val.reserve(cap));
             cap = std::min(key.cap, val.cap);
             FFH_HIP(hipMemsetAsync(cursor, 0, 8, st));
-            hipLaunchKernelGGL(k_bulge_scan, dim3(blocks_for(T, 256)), dim3(256), 0, st, ctx->targets.p, T, d_guides.p, n_guides, ctx->geo, max_mismatch, max_bulge,
-                               (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
+            if (brute)
+                hipLaunchKernelGGL(k_bulge_scan, dim3(blocks_for(T, 256)), dim3(256), 0, st, ctx->targets.p, T, d_guides.p, n_guides, ctx->geo, max_mismatch, max_bulge,
+                                   (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
+            else
+                for (int i = 0; i < n_seeds; ++i) {
+                    const uint64_t waves = (uint64_t)n_guides * ((seeds[i].n_pat + 63) / 64);
+                    hipLaunchKernelGGL(k_bulge_seed, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, seeds[i], (const uint64_t *)ctx->targets.p, (const uint64_t *)d_guides.p,
+                                       n_guides, ctx->geo, max_mismatch, max_bulge, (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
+                }
             FFH_HIP(hipGetLastError());
             unsigned long long found = 0;
             FFH_HIP(hipMemcpyAsync(&found, cursor, 8, hipMemcpyDeviceToHost, st));
@@ -1481,20 +1516,29 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
         ss.alt = alt_k.p; ss.val_alt = alt_v.p; ss.table = table.p; ss.offs = offs.p; ss.scan_tmp = scr32.p;
         uint64_t *sk = nullptr, *sv = nullptr;
         radix_sort_pairs(key.p, val.p, n_hits, 0, tbits + gbits, ss, st, sk, sv);  // (guide, database order)
-        FFH_HIP(d_target.reserve(n_hits)); FFH_HIP(d_mm.reserve(n_hits)); FFH_HIP(d_type.reserve(n_hits)); FFH_HIP(d_pos.reserve(n_hits));
-        hipLaunchKernelGGL(k_bulge_unpack, dim3(blocks_for(n_hits, 256)), dim3(256), 0, st, sk, sv, n_hits, tbits, ctx->targets.p, d_target.p, d_mm.p, d_type.p, d_pos.p);
-        FFH_HIP(hipGetLastError());
-        std::vector<uint64_t> keys(n_hits);
-        try {
-            r->hit_targets.resize(n_hits); r->hit_mm.resize(n_hits); r->hit_type.resize(n_hits); r->hit_pos.resize(n_hits);
-        } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return FFH_E_NOMEM; }
-        FFH_HIP(hipMemcpyAsync(keys.data(), sk, n_hits * 8, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(r->hit_targets.data(), d_target.p, n_hits * 8, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(r->hit_mm.data(), d_mm.p, n_hits, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(r->hit_type.data(), d_type.p, n_hits, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipMemcpyAsync(r->hit_pos.data(), d_pos.p, n_hits, hipMemcpyDeviceToHost, st));
+        // a pair reached through two seeds appears twice with the same record: keep the first of every key
+        FFH_HIP(d_flag.reserve(n_hits + 1)); FFH_HIP(d_dst.reserve(n_hits + 2)); FFH_HIP(scr64.reserve(scan_scratch_elems_safe(n_hits + 1)));
+        hipLaunchKernelGGL(k_bulge_flag_unique, dim3(blocks_for(n_hits, 256)), dim3(256), 0, st, (const uint64_t *)sk, n_hits, d_flag.p);
+        exclusive_scan<uint32_t, uint64_t>(d_flag.p, n_hits, d_dst.p, scr64.p, st);
+        uint64_t n_unique = 0;
+        FFH_HIP(hipMemcpyAsync(&n_unique, d_dst.p + n_hits, 8, hipMemcpyDeviceToHost, st));
         FFH_HIP(hipStreamSynchronize(st));
-        for (uint64_t i = 0; i < n_hits; ++i) ++r->guide_offsets[(size_t)(keys[i] >> tbits) + 1];
+        FFH_HIP(d_key.reserve(n_unique)); FFH_HIP(d_target.reserve(n_unique)); FFH_HIP(d_mm.reserve(n_unique)); FFH_HIP(d_type.reserve(n_unique)); FFH_HIP(d_pos.reserve(n_unique));
+        hipLaunchKernelGGL(k_bulge_unpack, dim3(blocks_for(n_hits, 256)), dim3(256), 0, st, (const uint64_t *)sk, (const uint64_t *)sv, n_hits, tbits, (const uint64_t *)ctx->targets.p,
+                           (const uint32_t *)d_flag.p, (const uint64_t *)d_dst.p, d_key.p, d_target.p, d_mm.p, d_type.p, d_pos.p);
+        FFH_HIP(hipGetLastError());
+        std::vector<uint64_t> keys;
+        try {
+            keys.resize(n_unique);
+            r->hit_targets.resize(n_unique); r->hit_mm.resize(n_unique); r->hit_type.resize(n_unique); r->hit_pos.resize(n_unique);
+        } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; return FFH_E_NOMEM; }
+        FFH_HIP(hipMemcpyAsync(keys.data(), d_key.p, n_unique * 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_targets.data(), d_target.p, n_unique * 8, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_mm.data(), d_mm.p, n_unique, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_type.data(), d_type.p, n_unique, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipMemcpyAsync(r->hit_pos.data(), d_pos.p, n_unique, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < n_unique; ++i) ++r->guide_offsets[(size_t)(keys[i] >> tbits) + 1];
         for (uint32_t g = 0; g < n_guides; ++g) r->guide_offsets[g + 1] += r->guide_offsets[g];
     }
     *out = r.release();

@@ -196,12 +196,14 @@ int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int ma
  * max_bulge (0 or 1) bulges of one base.  The reference has no bulge search; the specification is DESIGN.md section 8
  * ("f4") and csrc/ffh_bulge.hpp: alignments none / RNA bulge at guide position k / DNA bulge at target position k
  * (1 <= k <= 18, position 0 next to the PAM), best = fewest mismatches, ties none < RNA < DNA then smallest k.
- * Brute force over the resident shard, every guide against every target; no cut-off, no scores (CFD / Hsu2013 are not
- * defined for Cas12a).  Hits per guide in database order.  FFH_BULGE_PAM_TTTV keeps only targets whose fourth PAM base is
+ * Candidates come from the two resident scan images (csrc/ffh_bulge.hpp: one side of the bulge is a plain comparison of
+ * consecutive bases, i.e. a bucket key within max_mismatch of the guide's); every candidate is evaluated in full; no cut-off,
+ * no scores (CFD / Hsu2013 are not defined for Cas12a).  Hits per guide in database order.  FFH_BULGE_PAM_TTTV keeps only targets whose fourth PAM base is
  * not T (TTTV sites inside a TTTN database).
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct ffh_bulge_result ffh_bulge_result;
 #define FFH_BULGE_PAM_TTTV 1u
+#define FFH_BULGE_BRUTE_FORCE 2u /* every guide against every target instead of the seeded candidate search (its checker) */
 #define FFH_BULGE_NONE 0
 #define FFH_BULGE_RNA 1
 #define FFH_BULGE_DNA 2

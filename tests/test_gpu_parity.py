@@ -717,6 +717,9 @@ def test_cas12a_bulge_search_against_a_second_independent_checker(capi, oracle):
         with capi.Context(1) as ctx:
             ctx.load_soa(targets, positions)
             res = ctx.discover_bulge(guides, max_mm, max_bulge, tttv=tttv)
+            bf = ctx.discover_bulge(guides, max_mm, max_bulge, tttv=tttv, brute_force=True)
+        for name in ("guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position"):
+            assert np.array_equal(getattr(res, name), getattr(bf, name)), name      # seeded candidate search == every pair
         n_checked = 0
         for gi, g in enumerate(guides40):
             g_bases = ((np.uint64(g) >> shifts) & np.uint64(3)).astype(np.int8)
@@ -732,3 +735,45 @@ def test_cas12a_bulge_search_against_a_second_independent_checker(capi, oracle):
             assert np.array_equal(res.hit_bulge_position[a:b], bpos[idx].astype(np.uint8))
             n_checked += len(idx)
         assert n_checked >= 60
+
+
+def _cas12a_database(rng, n_random, guides40, copies):
+    """TTTN 24-mers in the database order of a 5'-PAM enzyme: random protospacers + near-copies (substitutions, RNA / DNA bulges) of the guides"""
+    raw = rng.integers(0, 1 << 40, size=n_random, dtype=np.uint64)
+    extra = []
+    for g in guides40:
+        bases = [(int(g) >> (2 * (19 - i))) & 3 for i in range(20)]
+        for _ in range(copies):
+            kind, pos = int(rng.integers(0, 3)), int(rng.integers(1, 19))
+            tb = list(bases) if kind == 0 else (bases[:pos] + bases[pos + 1:] + [int(rng.integers(0, 4))] if kind == 1 else (bases[:pos] + [int(rng.integers(0, 4))] + bases[pos:])[:20])
+            for _ in range(int(rng.integers(0, 4))):
+                tb[int(rng.integers(0, 20))] = int(rng.integers(0, 4))
+            v = 0
+            for b in tb:
+                v = (v << 2) | b
+            extra.append(v)
+    raw = np.unique(np.concatenate([raw, np.array(extra, dtype=np.uint64)]))
+    pam_n = rng.integers(0, 4, size=len(raw)).astype(np.uint64)
+    seq = (np.uint64(0b111111) << np.uint64(42)) | (pam_n << np.uint64(40)) | raw
+    binkey = (seq >> np.uint64(2 * (24 - 11))) & np.uint64(0x3FFF)
+    seq = seq[np.lexsort((seq, binkey))]
+    return seq | (np.uint64(1) << np.uint64(48)), rng.integers(0, 1 << 27, size=len(seq), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n_random,n_guides,max_mm,tttv", [(3_000_000, 1500, 3, True), (400_000, 3000, 2, False), (2_000, 40, 4, False)])
+def test_cas12a_seeded_bulge_search_equals_brute_force_at_scale(capi, n_random, n_guides, max_mm, tttv):
+    """the candidate search (prefix / shifted-suffix bucket seeds, csrc/ffh_bulge.hpp) must return exactly what the scan of every
+    (guide, target) pair returns: same hits, same best alignment; bucket widths 8 .. 10 over the three database sizes"""
+    rng = np.random.default_rng(n_random + max_mm)
+    guides40 = rng.integers(0, 1 << 40, size=n_guides, dtype=np.uint64)
+    targets, positions = _cas12a_database(rng, n_random, guides40[: min(n_guides, 400)], 12)
+    guides = guides40 | np.uint64(0b11111100 << 40) | np.uint64(1 << 48)
+    with capi.Context(1) as ctx:
+        ctx.load_soa(targets, positions)
+        widths = (ctx.info().prefix_bases, ctx.info().suffix_bases)
+        res = ctx.discover_bulge(guides, max_mm, 1, tttv=tttv)
+        bf = ctx.discover_bulge(guides, max_mm, 1, tttv=tttv, brute_force=True)
+    assert widths[0] + widths[1] == 20
+    for name in ("guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position"):
+        assert np.array_equal(getattr(res, name), getattr(bf, name)), name
+    assert len(res.hit_targets) >= 400 and {0, 1, 2} <= set(res.hit_bulge_type.tolist())
