@@ -383,6 +383,15 @@ class Context:
         self._n_guides = len(g)
         self._check(self.L.ffh_scan(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch))
 
+    def scan_device(self, guides_ptr, n_guides, max_mismatch=4):
+        """ffh_scan with the guides' longs already in device memory (the pointer of a torch tensor, ...)"""
+        self._n_guides = int(n_guides)
+        self._check(self.L.ffh_scan(self.h, C.cast(C.c_void_p(guides_ptr), u64p), int(n_guides), max_mismatch))
+
+    def discover_device(self, guides_ptr, n_guides, max_mismatch=4, max_offtargets=2000, **kw):
+        self.scan_device(guides_ptr, n_guides, max_mismatch)
+        return self.finalize(max_offtargets, None, **kw)
+
     def shard_totals(self, clamp):
         t = np.zeros(max(self._n_guides, 1), dtype=np.uint32)
         self._check(self.L.ffh_shard_totals(self.h, t.ctypes.data_as(u32p), clamp))

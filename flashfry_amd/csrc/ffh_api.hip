@@ -209,6 +209,8 @@ struct ffh_ctx {
     // per-pass scratch
     DevBuf<uint2> gtab[2];                                  // {rest key, bucket} of every guide of the current batch, per side (L2-resident)
     DevBuf<uint32_t> gbucket[2], patterns[2], istart[2];
+    DevBuf<unsigned long long> part_pairs[2];  // per candidate partition: targets x candidates of its buckets (k_item_bin)
+    uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
     DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
@@ -409,6 +411,7 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
     ig.range = im.range.p;
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
+    FFH_HIP(ctx->part_pairs[which].reserve((size_t)ig.n_part + 1));
     const uint64_t *gptr = ctx->guides.p + g0;
     // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
     // saves the fill launches before k_guide_part_hist and k_segments)
@@ -425,7 +428,9 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
     hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
-    hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p);
+    hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
+                       (const uint32_t *)ctx->img[which].bstart.p, ctx->part_pairs[which].p);
+    ctx->n_part[which] = ig.n_part;
     FFH_HIP(hipGetLastError());
     return FFH_OK;
 }
@@ -798,7 +803,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(ctx->guides.reserve((size_t)n_guides + 1));
     FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));  // cleared per batch by k_guide_keys, filled by k_segments
     FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
-    if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyHostToDevice, st));
+    // host or device memory (unified addressing tells): a caller whose guide set already sits in HBM passes the device pointer
+    if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyDefault, st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
 
     ctx->tbits = 1;
@@ -832,8 +838,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
         FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_bat)));
-        hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, im.bstart.p, S.nb, S.NB, S.split, n_bat,
-                           ctx->wl_count[which].p, ctx->d_counters + kStatPairs + which);
+        hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
+                           ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, ctx->n_part[which], ctx->d_counters + kStatPairs + which);
         exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->scan_tmp32.p, st);
         hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
                            ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which);

@@ -294,29 +294,31 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
 // ---------------------------------------------------------------------------------------------------------
 // The work list of one image for one compare launch, built from the bucket boundaries and the candidate CSR offsets:
 //   k_work_count  per batch of NB consecutive buckets: 0 entries if it has no candidate or no target, else ceil(groups / split);
-//                 the launch also adds up the executed-pair statistic (targets x candidates of every bucket)
+//                 the launch also adds up the executed-pair statistic (targets x candidates of every bucket) from the partial
+//                 sums k_item_bin left per partition
 //   (scan)
 //   k_work_fill   the entries.  A call with a handful of guides lists a few hundred batches instead of making every wave walk all
 //                 4^11 buckets' boundaries; a bucket of 1e5 targets becomes ~100 entries dealt to ~100 waves.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, const uint32_t *__restrict__ bstart,
-                                                    uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, uint32_t *__restrict__ counts,
-                                                    unsigned long long *__restrict__ pairs_out) {
+__global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
+                                                    uint32_t n_bat, uint32_t *__restrict__ counts, const unsigned long long *__restrict__ part_pairs,
+                                                    uint32_t n_part, unsigned long long *__restrict__ pairs_out) {
     __shared__ unsigned long long red[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long pairs = 0;
     if (t < n_bat) {
         const uint32_t b0 = t * NB, b1 = min(nb, b0 + NB);
         const uint32_t ngr = gstart[b1] - gstart[b0], nc = istart[b1] - istart[b0];
         counts[t] = (ngr && nc) ? (ngr + split - 1u) / split : 0u;
-        if (nc)
-            for (uint32_t b = b0; b < b1; ++b) pairs += (unsigned long long)(bstart[b + 1] - bstart[b]) * (istart[b + 1] - istart[b]);
     }
+    if (blockIdx.x != 0) return;
+    // the executed-pair statistic (targets x candidates of every bucket): k_item_bin left one partial sum per partition
+    unsigned long long pairs = 0;
+    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) pairs += part_pairs[d];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pairs;
     __syncthreads();
-    if (threadIdx.x == 0) { const unsigned long long s = red[0] + red[1] + red[2] + red[3]; if (s) atomicAdd(pairs_out, s); }
+    if (threadIdx.x == 0) atomicAdd(pairs_out, red[0] + red[1] + red[2] + red[3]);
 }
 __global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, const uint32_t *__restrict__ offs,
                             uint4 *__restrict__ list, unsigned long long *__restrict__ n_out) {

@@ -293,10 +293,13 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
 // contiguous, coalesced copy: scattering 4-byte stores straight to memory costs a partial-line write-back each once the
 // concurrently open output windows exceed the L2 (1.1 ms for the 5.3e7 entries of the hg38-scale prefix image).
 __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
-                                                           uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid) {
+                                                           uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid, const uint32_t *__restrict__ bstart,
+                                                           unsigned long long *__restrict__ part_pairs /* [n_part]: the partition's executed-pair statistic,
+                                                           sum over its buckets of targets x candidates (k_work_count adds the partitions up) */) {
     __shared__ uint32_t cnt[1 << kMaxLowBits];
     __shared__ uint32_t stage[kBinStage];
     __shared__ uint32_t scan_lds[16];
+    __shared__ unsigned long long pair_lds[16];
     const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits;
     for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
     __syncthreads();
@@ -312,14 +315,26 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__
             if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
         uint32_t tot;
         uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
+        unsigned long long pairs = 0;
         for (uint32_t k = 0; k < per; ++k)
             if (l0 + k < nlow) {
                 const uint32_t c = cnt[lds_slot(l0 + k)];
-                istart[((uint64_t)d << ig.low_bits) + l0 + k] = gbase + off;
+                const uint64_t bucket = ((uint64_t)d << ig.low_bits) + l0 + k;
+                istart[bucket] = gbase + off;
                 cnt[lds_slot(l0 + k)] = off;
                 off += c;
+                if (c) pairs += (unsigned long long)c * (bstart[bucket + 1] - bstart[bucket]);
             }
         if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) pairs += __shfl_xor(pairs, s, 64);
+        if ((threadIdx.x & 63) == 0) pair_lds[threadIdx.x >> 6] = pairs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kPartThreads / 64; ++w) t += pair_lds[w];
+            part_pairs[d] = t;
+        }
     };
     if (n <= (uint32_t)kBinStage) {
         // the usual case: the whole partition sits in registers (14 records per thread, all loads in flight at once), is counted and

@@ -168,7 +168,8 @@ int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius);
  * ------------------------------------------------------------------------------------------------------- */
 
 /* Finds every (guide, target) with mismatches(guide, target) <= max_mismatch (BitEncoding.scala:127-132) in
- * this shard; hits stay on the device, sorted by (guide, database order). */
+ * this shard; hits stay on the device, sorted by (guide, database order).  `guides` (here and in ffh_discover) may point to host
+ * or to device memory of the context's GPU: a guide set that already sits in HBM is not staged through the host again. */
 int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch);
 
 /* per guide: sum of positions over ALL hits of this shard, saturated at `clamp` (pass max_offtargets) */
