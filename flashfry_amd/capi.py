@@ -24,7 +24,7 @@ SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
     "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
-    "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
+    "ffh_scan_bounded", "ffh_set_bounding", "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
     "ffh_bulge_result_hit_targets", "ffh_bulge_result_hit_mismatches", "ffh_bulge_result_hit_bulge_type", "ffh_bulge_result_hit_bulge_position",
     "ffh_bulge_result_free", "ffh_exchange_pack", "ffh_exchange_mask", "ffh_exchange_unpack", "ffh_use_stream", "ffh_finalize_shard", "ffh_exchange_prior", "ffh_finalize_shard_fixup", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
@@ -74,7 +74,7 @@ class Timings(C.Structure):
                 ("n_raw_hits", C.c_uint64), ("pairs_prefix", C.c_uint64), ("pairs_suffix", C.c_uint64),
                 ("items_prefix", C.c_uint64), ("items_suffix", C.c_uint64), ("tiles_prefix", C.c_uint64),
                 ("tiles_suffix", C.c_uint64), ("compare_launches", C.c_uint32), ("prefix_bases", C.c_int),
-                ("prefix_radius", C.c_int), ("suffix_radius", C.c_int)]
+                ("prefix_radius", C.c_int), ("suffix_radius", C.c_int), ("bounded_slabs", C.c_uint32), ("retired_guides", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -138,6 +138,8 @@ def load_library(build=True):
     L.ffh_db_contig.argtypes = [C.c_void_p, C.c_uint32]
     L.ffh_set_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ffh_scan.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int]
+    L.ffh_scan_bounded.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int]
+    L.ffh_set_bounding.argtypes = [C.c_void_p, C.c_int]
     L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
     L.ffh_discover_bulge.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_bulge_result_n_guides.restype = C.c_uint32
@@ -383,14 +385,28 @@ class Context:
         self._n_guides = len(g)
         self._check(self.L.ffh_scan(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch))
 
+    def scan_bounded(self, guides, max_mismatch=4, max_offtargets=2000):
+        """ffh_scan_bounded: guides that reach max_offtargets positions are retired from the later slabs of the database"""
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        self._n_guides = len(g)
+        self._check(self.L.ffh_scan_bounded(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_offtargets))
+
+    def set_bounding(self, mode):
+        """0 never, 1 always, -1 automatic (the default)"""
+        self._check(self.L.ffh_set_bounding(self.h, int(mode)))
+
     def scan_device(self, guides_ptr, n_guides, max_mismatch=4):
         """ffh_scan with the guides' longs already in device memory (the pointer of a torch tensor, ...)"""
         self._n_guides = int(n_guides)
         self._check(self.L.ffh_scan(self.h, C.cast(C.c_void_p(guides_ptr), u64p), int(n_guides), max_mismatch))
 
-    def discover_device(self, guides_ptr, n_guides, max_mismatch=4, max_offtargets=2000, **kw):
-        self.scan_device(guides_ptr, n_guides, max_mismatch)
-        return self.finalize(max_offtargets, None, **kw)
+    def discover_device(self, guides_ptr, n_guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False, positions=True, hit_scores=True):
+        """ffh_discover with the guides' longs already in device memory"""
+        self._n_guides = int(n_guides)
+        out = C.c_void_p()
+        self._check(self.L.ffh_discover(self.h, C.cast(C.c_void_p(guides_ptr), u64p), int(n_guides), max_mismatch, max_offtargets,
+                                        self._finalize_flags(summaries_only, jost, positions, hit_scores), C.byref(out)))
+        return Result(self.L, out.value, lists=not summaries_only, positions=positions, hit_scores=hit_scores)
 
     def shard_totals(self, clamp):
         t = np.zeros(max(self._n_guides, 1), dtype=np.uint32)
@@ -449,6 +465,11 @@ class Context:
         self._check(self.L.ffh_finalize(self.h, C.cast(C.c_void_p(prior_device_ptr), u32p), max_offtargets, flags, C.byref(out)))
         return Result(self.L, out.value, lists=not summaries_only)
 
+    @staticmethod
+    def _finalize_flags(summaries_only, jost, positions, hit_scores):
+        return ((FINALIZE_SUMMARIES_ONLY if summaries_only else 0) | (FINALIZE_JOST if jost else 0) | (0 if positions else FINALIZE_NO_POSITIONS) |
+                (0 if hit_scores else FINALIZE_NO_HIT_SCORES))
+
     def finalize(self, max_offtargets=2000, prior_totals=None, summaries_only=False, jost=False, positions=True, hit_scores=True):
         out = C.c_void_p()
         pt = None
@@ -461,8 +482,13 @@ class Context:
         return Result(self.L, out.value, lists=not summaries_only, positions=positions, hit_scores=hit_scores)
 
     def discover(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False, positions=True, hit_scores=True):
-        self.scan(guides, max_mismatch)
-        return self.finalize(max_offtargets, None, summaries_only, jost, positions, hit_scores)
+        """ffh_discover: scan (bounded by max_offtargets when bounding is on for the context) + finalize"""
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        self._n_guides = len(g)
+        out = C.c_void_p()
+        self._check(self.L.ffh_discover(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_offtargets, self._finalize_flags(summaries_only, jost, positions, hit_scores),
+                                        C.byref(out)))
+        return Result(self.L, out.value, lists=not summaries_only, positions=positions, hit_scores=hit_scores)
 
     def score_lists(self, guides, guide_offsets, hit_targets):
         """the `score` path: score caller-supplied hit lists (CSR) on the device"""

@@ -222,6 +222,16 @@ struct ffh_ctx {
 
     // finalize scratch
     DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals, hit_pre;
+    // bounded scan (ffh_scan_bounded): the suffix images of the slabs, the slabs' first targets, their prefix-bucket ranges, the
+    // guides' running totals and the packed set of guides still active
+    std::vector<std::unique_ptr<Image>> slab_img;
+    std::vector<uint64_t> slab_t;
+    DevBuf<uint32_t> g_total, g_flag, g_pos, g_map;
+    DevBuf<uint64_t> g_active;
+    int slabs_state = 0;      // 0 not built, 1 built, -1 this database cannot be bounded
+    int bound_mode = 0;       // bounding on for this context
+    bool bound_auto = true;   // ... switched on by the first scan that collects more than kBoundAutoHits raw hits per guide
+    uint32_t bound_ot = 0;    // the limit the last scan was bounded by (0: it was not)
     DevBuf<uint64_t> ret_off, pos_base, out_target, out_posoff, out_pos;
     DevBuf<uint8_t> out_mm;
     DevBuf<double> out_cfd, out_hsu, out_jost;
@@ -292,21 +302,21 @@ static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
 }
 
 // ---- database residency ----------------------------------------------------------------------------------
-static int build_image(ffh_ctx *ctx, int which, int width) {
-    Image &im = ctx->img[which];
+// the image of targets [t_lo, t_lo + t_n) of the shard (the whole shard, or one slab of it in database order: ffh_scan_bounded)
+static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint64_t t_lo, uint64_t t_n) {
     const uint32_t nb = 1u << (2 * width);
     im.width = width;
     im.rest = ctx->geo.lc - width;
     const uint32_t R = (uint32_t)im.rest, GW = (uint32_t)group_words(im.rest);
     // every bucket rounds its targets up to whole groups of 32: at most T / 32 + nb groups (no host round trip for the exact number)
-    const uint64_t max_groups = ctx->T / 32 + nb;
+    const uint64_t max_groups = t_n / 32 + nb;
     if (max_groups * 32 >= (1ull << 31) - 64) { ctx->err = "too many target slots in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
     DevBuf<uint32_t> &keys = ctx->tmp_keys, &tidx_in = ctx->tmp_tidx;   // the counting sort's output, bit-sliced below (shared by the two images:
                                                                          // allocating and freeing GB-sized buffers costs tens of ms each)
     FFH_HIP(im.bstart.reserve((size_t)nb + 1));
     FFH_HIP(im.gstart.reserve((size_t)nb + 1));
-    FFH_HIP(keys.reserve(ctx->T + 1));
-    FFH_HIP(tidx_in.reserve(ctx->T + 1));
+    FFH_HIP(keys.reserve(t_n + 1));
+    FFH_HIP(tidx_in.reserve(t_n + 1));
     FFH_HIP(im.gwords.reserve((size_t)max_groups * GW + kKW + 64));
     FFH_HIP(im.tidx.reserve((size_t)max_groups * 32 + 64));
     FFH_HIP(ctx->icount.reserve((size_t)nb + 1));
@@ -314,15 +324,16 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
     FFH_HIP(hipMemsetAsync(ctx->icount.p, 0, ((size_t)nb + 1) * 4, ctx->st));
     FFH_HIP(hipMemsetAsync(ctx->ifill.p, 0, ((size_t)nb + 1) * 4, ctx->st));
-    const unsigned bl = blocks_for(ctx->T, 256);
-    if (ctx->T) {
-        if (which == 0) hipLaunchKernelGGL(k_image_hist<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, ctx->icount.p);
-        else hipLaunchKernelGGL(k_image_hist<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, ctx->icount.p);
+    const unsigned bl = blocks_for(t_n, 256);
+    const uint64_t *tg = ctx->targets.p + t_lo;
+    if (t_n) {
+        if (which == 0) hipLaunchKernelGGL(k_image_hist<false>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, ctx->icount.p);
+        else hipLaunchKernelGGL(k_image_hist<true>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, ctx->icount.p);
     }
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.bstart.p, ctx->scan_tmp32.p, ctx->st);
-    if (ctx->T) {
-        if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
-        else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p);
+    if (t_n) {
+        if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
+        else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
     }
     {   // the buckets that hold a target: candidate entries outside them are dropped while they are binned
         FFH_HIP(im.range.reserve(2));
@@ -337,6 +348,9 @@ static int build_image(ffh_ctx *ctx, int which, int width) {
     FFH_HIP(hipGetLastError());
     return FFH_OK;
 }
+
+static void drop_slabs(ffh_ctx *ctx);
+static int build_image(ffh_ctx *ctx, int which, int width) { return build_image_into(ctx, ctx->img[which], which, width, 0, ctx->T); }
 
 // targets/positions are already on the device in ctx->targets / ctx->positions
 static int prepare_database(ffh_ctx *ctx) {
@@ -365,6 +379,7 @@ static int prepare_database(ffh_ctx *ctx) {
     // scans: 16.7 M buckets for a 12-base image) than its short candidate lists save, so the split stays near the middle
     if (ctx->plan_a < 0) a = std::max(a, lc - 10);
     a = std::max(lc - 12, std::min(12, a));
+    drop_slabs(ctx);   // (slab images of the database that was resident before)
     int rc = build_image(ctx, 0, a);
     if (rc) return rc;
     rc = build_image(ctx, 1, lc - a);
@@ -380,8 +395,11 @@ static int prepare_database(ffh_ctx *ctx) {
 }
 
 // ---- candidate lists (CSR) + work items of one image (no host synchronisation: counts stay on the device) ------
-static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32_t ng, uint32_t item_base) {
-    Image &im = ctx->img[which];
+// im: the image the candidates are for (the shard's, or one slab's: ffh_scan_bounded); range: {first, last} bucket outside which
+// entries are dropped (device memory); gptr: the ng guides of this launch; seg_at >= 0: also clear the hit segments of guides
+// seg_at .. seg_at + ng - 1 (their numbers in the caller's array)
+static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t *range, int radius, const uint64_t *gptr, int64_t seg_at, uint32_t ng,
+                        uint32_t item_base, uint32_t rank_lo = 0u, uint32_t rank_hi = 63u) {
     const int width = im.width;
     const uint32_t nb = 1u << (2 * width);
     const std::vector<uint32_t> &pat = patterns_for(ctx, width, radius);
@@ -409,14 +427,16 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     ig.n_part = 1u << part_bits;
     ig.item_base = item_base;
     ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
-    ig.range = im.range.p;
+    ig.range = range;
+    ig.rank_lo = rank_lo; ig.rank_hi = rank_hi; ig.width = (uint32_t)width;
+    const bool filtered = rank_lo > 0u || rank_hi < 63u;   // one slab of a bounded scan: the sizes are counted, not derived
     FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
     FFH_HIP(ctx->part_pairs[which].reserve((size_t)ig.n_part + 1));
-    const uint64_t *gptr = ctx->guides.p + g0;
     // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
     // saves the fill launches before k_guide_part_hist and k_segments)
     if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[0].p, gbucket.p,
-                                       ctx->seg_begin.p + g0, ctx->seg_end.p + g0, ctx->part_hist.p, ig.n_part);
+                                       seg_at >= 0 ? ctx->seg_begin.p + seg_at : (uint32_t *)nullptr, seg_at >= 0 ? ctx->seg_end.p + seg_at : (uint32_t *)nullptr,
+                                       ctx->part_hist.p, ig.n_part);
     else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[1].p, gbucket.p, (uint32_t *)nullptr,
                             (uint32_t *)nullptr, ctx->part_hist.p, ig.n_part);
     FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
@@ -425,11 +445,13 @@ static int prepare_side(ffh_ctx *ctx, int which, int radius, uint32_t g0, uint32
     uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
     const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
     hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
-    hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+    if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+    else hipLaunchKernelGGL((k_item_partition<false, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
     exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
-    hipLaunchKernelGGL(k_item_partition<true>, dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
+    if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
+    else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
     hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
-                       (const uint32_t *)ctx->img[which].bstart.p, ctx->part_pairs[which].p);
+                       (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
     ctx->n_part[which] = ig.n_part;
     FFH_HIP(hipGetLastError());
     return FFH_OK;
@@ -791,7 +813,69 @@ const char *ffh_db_contig(const ffh_ctx *ctx, uint32_t id) {
     return ctx->contigs[id - 1].c_str();
 }
 
-int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm) {
+// ---- slabs of a bounded scan -------------------------------------------------------------------------------------
+// The database in database order is cut at prefix-bucket boundaries into slabs of growing size (1/64, 1/8, the rest); the prefix
+// image serves every slab through a bucket range, the suffix image exists once per slab.  Needs database order == prefix-bucket
+// order, i.e. a 3' PAM (every Cas9 pack); Cpf1's 5' PAM varies in front of the compared bases, so a Cpf1 context stays unbounded.
+// sorted by sequence?  and the first target of every first-three-bases rank r (cut[r] = smallest index with rank >= r)
+__global__ void k_slab_cuts(const uint64_t *__restrict__ targets, uint64_t n, int scan_len, uint32_t *__restrict__ bad, uint32_t *__restrict__ cut /* [65], preset to n */) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t M = (1ull << 48) - 1ull, t = targets[i] & M;
+    const uint32_t r = (uint32_t)(t >> (2 * scan_len - 6)) & 63u;
+    if (i == 0) { for (uint32_t k = 0; k <= r; ++k) cut[k] = 0u; return; }
+    const uint64_t p = targets[i - 1] & M;
+    if (p > t) atomicAdd(bad, 1u);
+    const uint32_t rp = (uint32_t)(p >> (2 * scan_len - 6)) & 63u;
+    for (uint32_t k = rp + 1; k <= r; ++k) cut[k] = (uint32_t)i;   // ranks without a target between rp and r start here too
+}
+
+static void drop_slabs(ffh_ctx *ctx) { ctx->slab_img.clear(); ctx->slab_t.clear(); ctx->slabs_state = 0; }
+
+// slab k = the targets whose first three bases rank in [kSlabRank[k], kSlabRank[k + 1]): 1/64, 3/64, 1/8, 3/16, 1/4 and 3/8 of
+// sequence space.  A guide with H hits spread like the genome is retired after the first slab boundary beyond 2000/H of it, so it
+// leaves at most ~1.6 x the hits its cut-off keeps plus one slab's worth; a guide of a million-copy family leaves 1/64 of them.
+// On the repeat-structured bench workload (2.5e8 raw hits unbounded): 3 slabs {1, 8} 1.43e8 raw hits / 16.5 ms per step,
+// 4 slabs {1, 8, 32} 7.0e7 / 15.2 ms, these 6 slabs 4.7e7 / 13.7 ms (19.1 ms unbounded); every slab costs ~0.8 ms of its own
+// (candidate binning with a counting pass, ordering and totals of its hits, two round trips).
+static const uint32_t kSlabRank[7] = {0u, 1u, 4u, 12u, 24u, 40u, 64u};
+
+static int ensure_slabs(ffh_ctx *ctx) {
+    if (ctx->slabs_state) return FFH_OK;   // 1 = built, -1 = this database cannot be bounded
+    ctx->slabs_state = -1;
+    const int sfx = ctx->img[1].width;
+    if (ctx->geo.c0 == 0 || ctx->T < (1u << 16) || ctx->img[0].width < 3) return FFH_OK;
+    hipStream_t st = ctx->st;
+    uint32_t *bad = (uint32_t *)ctx->d_counters + 9;
+    DevBuf<uint32_t> d_cut;
+    FFH_HIP(d_cut.reserve(66));
+    std::vector<uint32_t> cut(65, (uint32_t)ctx->T);
+    FFH_HIP(hipMemsetAsync(bad, 0, 4, st));
+    FFH_HIP(hipMemcpyAsync(d_cut.p, cut.data(), 65 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_slab_cuts, dim3(blocks_for(ctx->T, 256)), dim3(256), 0, st, (const uint64_t *)ctx->targets.p, ctx->T, ctx->geo.scan_len, bad, d_cut.p);
+    uint32_t hbad = 1;
+    FFH_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipMemcpyAsync(cut.data(), d_cut.p, 65 * 4, hipMemcpyDeviceToHost, st));
+    FFH_HIP(hipStreamSynchronize(st));
+    if (hbad) return FFH_OK;   // (targets not in sequence order: ffh_db_load_soa takes what it is given)
+    const int K = (int)(sizeof kSlabRank / sizeof kSlabRank[0]) - 1;
+    for (int k = 0; k < K; ++k) {
+        const uint64_t t0 = cut[kSlabRank[k]], t1 = kSlabRank[k + 1] >= 64u ? ctx->T : cut[kSlabRank[k + 1]];
+        ctx->slab_img.emplace_back(new Image());
+        const int rc = build_image_into(ctx, *ctx->slab_img.back(), 1, sfx, t0, t1 - t0);
+        if (rc) { drop_slabs(ctx); ctx->slabs_state = -1; return rc; }
+        ctx->slab_t.push_back(t0);
+    }
+    ctx->slab_t.push_back(ctx->T);
+    FFH_HIP(hipStreamSynchronize(st));
+    ctx->tmp_keys.release(); ctx->tmp_tidx.release();
+    ctx->slabs_state = 1;
+    return FFH_OK;
+}
+
+// bound_ot > 0: the caller will not ask for more than bound_ot positions per guide (maximumOffTargets), so a guide whose positions
+// reach it in the slabs scanned so far is retired from the later ones
+static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm, uint32_t bound_ot) {
     if (!ctx || (n_guides && !guides) || max_mm < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (ctx->img[0].width < 0) { ctx->err = "no database loaded"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
@@ -809,6 +893,8 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
 
     ctx->tbits = 1;
     while (ctx->tbits < 32 && (1ull << ctx->tbits) < std::max<uint64_t>(ctx->T, 2)) ++ctx->tbits;
+    int gbits = 1;   // 2^gbits > n_guides: the all-ones padding of the compare waves' chunks sorts behind every guide
+    while (gbits < 32 && (1ull << gbits) <= (uint64_t)n_guides) ++gbits;
     const Plan plan = choose_plan(ctx, std::min(max_mm, ctx->geo.lc));
     ctx->tm.prefix_bases = plan.a; ctx->tm.prefix_radius = plan.r1; ctx->tm.suffix_radius = plan.r2;
     const double np_p = ball_size(plan.a, plan.r1), np_s = ball_size(plan.s, plan.r2);
@@ -818,22 +904,32 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     max_batch = std::min(max_batch, (double)((1u << kGidBits) - 1u));
     if (ctx->max_guide_batch) max_batch = std::min(max_batch, (double)ctx->max_guide_batch);
     uint32_t batch = (uint32_t)std::max(1.0, std::floor(max_batch));
+    // the slabs of this scan: one (everything) unless the scan is bounded and the database allows it
+    struct Slab { const Image *suffix; uint32_t rank_lo, rank_hi; uint64_t n_targets; };
+    std::vector<Slab> slabs;
+    bool bounded = bound_ot > 0 && ctx->bound_mode > 0 && n_guides > 0 && plan.r2 >= 0;
+    if (bounded) { const int rc = ensure_slabs(ctx); if (rc) return rc; bounded = ctx->slabs_state == 1; }
+    if (bounded)
+        for (size_t k = 0; k + 1 < ctx->slab_t.size(); ++k)
+            slabs.push_back(Slab{ctx->slab_img[k].get(), kSlabRank[k], kSlabRank[k + 1] - 1u, ctx->slab_t[k + 1] - ctx->slab_t[k]});
+    else slabs.push_back(Slab{&ctx->img[1], 0u, 63u, ctx->T});
+    ctx->bound_ot = bounded ? bound_ot : 0u;
+    ctx->tm.bounded_slabs = bounded ? (uint32_t)slabs.size() : 0u;
     // How each image is cut into work entries for the compare kernel (ffh_compare.hpp): runs of NB small buckets sized so that a
     // typical run fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); k_work_count / k_work_fill then list the
     // runs that have candidates, a bucket larger than the strip as several strip-sized group ranges.  Candidate lists larger than the
     // strip take the kernel's piecewise path.
-    auto side_plan = [&](int which, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S) -> int {
+    auto side_plan = [&](int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S) -> int {
         S = SideArgs{};
-        const Image &im = ctx->img[which];
         S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
         S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
         const double cap_g = std::floor((double)kKW / group_words(im.rest));
-        const double avg_t = (double)ctx->T / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
+        const double avg_t = (double)n_targets / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
         const double by_groups = std::floor(0.75 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.7 * kKC / std::max(avg_c, 0.05));
         S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
         S.split = (uint32_t)cap_g;
         const uint32_t n_bat = (S.nb + S.NB - 1) / S.NB;
-        const uint64_t max_entries = (uint64_t)n_bat + (ctx->T / 32 + S.nb) / S.split + 2;
+        const uint64_t max_entries = (uint64_t)n_bat + (n_targets / 32 + S.nb) / S.split + 2;
         FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
         FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
         FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
@@ -850,59 +946,114 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     FFH_HIP(hipEventRecord(ctx->ev[0], st));
     float ms_cmp = 0, ms_prep = 0;
     unsigned long long cursor_before = 0, n_real_hits = 0;
-    for (uint32_t g0 = 0; g0 < n_guides;) {
-        const uint32_t ng = std::min(batch, n_guides - g0);
-        // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
-        hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(64), 0, st, ctx->d_counters, g0 == 0 ? 1 : 0);
-        const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
-        if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
-        FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
-        FFH_HIP(hipEventRecord(ctx->ev[2], st));
-        int rc = prepare_side(ctx, 0, plan.r1, g0, ng, 0u);
-        if (rc) return rc;
-        if (plan.r2 >= 0) {
-            rc = prepare_side(ctx, 1, plan.r2, g0, ng, (uint32_t)n_items_p);
+    // the guides a slab runs on: all of them, then the packed set of those still below the limit
+    const uint64_t *act_guides = ctx->guides.p;
+    const uint32_t *act_map = nullptr;
+    uint32_t n_act = n_guides;
+    bool first_launch = true;
+    if (bounded) {
+        FFH_HIP(ctx->g_total.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->g_flag.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->g_pos.reserve((size_t)n_guides + 2));
+        FFH_HIP(ctx->g_active.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->g_map.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->totals.reserve((size_t)n_guides + 1));
+        FFH_HIP(hipMemsetAsync(ctx->g_total.p, 0, (size_t)n_guides * 4, st));
+    }
+    for (size_t sl = 0; sl < slabs.size() && n_act; ++sl) {
+        const Slab &SL = slabs[sl];
+        const unsigned long long slab_start = cursor_before;
+        for (uint32_t g0 = 0; g0 < n_act;) {
+            const uint32_t ng = std::min(batch, n_act - g0);
+            // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
+            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(64), 0, st, ctx->d_counters, first_launch ? 1 : 0);
+            const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
+            if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
+            FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
+            FFH_HIP(hipEventRecord(ctx->ev[2], st));
+            int rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
             if (rc) return rc;
-        }
-        FFH_HIP(hipEventRecord(ctx->ev[3], st));
-        CompareArgs ca{};
-        rc = side_plan(0, plan.a, -1, np_p, ng, ca.side[0]);
-        if (rc) return rc;
-        if (plan.r2 >= 0) { rc = side_plan(1, plan.s, plan.r1, np_s, ng, ca.side[1]); if (rc) return rc; }   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
-        else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
-        ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
-        hipLaunchKernelGGL(k_compare<0>, dim3(ctx->compare_grid), dim3(kCmpThreads), 0, st, ca, ctx->d_counters);
-        FFH_HIP(hipGetLastError());
-        FFH_HIP(hipEventRecord(ctx->ev[4], st));
-        unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
-        FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipStreamSynchronize(st));
-        FFH_HIP(hipGetLastError());
-        const unsigned long long cursor = cnt[0];
-        // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
-        // silently wrong result (the bulge path has the same guard)
-        if (cursor >= (1ull << 32) - 64) { ctx->err = "more than 2^32 raw hits in one scan: lower maxMismatch, split the guide set, or shard the bins over more GPUs"; return FFH_E_ARG; }
-        if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept, copied device to device)
-            DevBuf<uint64_t> bigger;
-            FFH_HIP(bigger.reserve((size_t)(cursor + cursor / 2)));
-            if (cursor_before) FFH_HIP(hipMemcpyAsync(bigger.p, ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToDevice, st));
+            if (plan.r2 >= 0) {
+                rc = prepare_side(ctx, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)n_items_p);
+                if (rc) return rc;
+            }
+            FFH_HIP(hipEventRecord(ctx->ev[3], st));
+            CompareArgs ca{};
+            rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
+            if (rc) return rc;
+            if (plan.r2 >= 0) { rc = side_plan(1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]); if (rc) return rc; }   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+            else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
+            ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
+            ca.gmap = act_map ? act_map + g0 : nullptr;
+            hipLaunchKernelGGL(k_compare<0>, dim3(ctx->compare_grid), dim3(kCmpThreads), 0, st, ca, ctx->d_counters);
+            FFH_HIP(hipGetLastError());
+            FFH_HIP(hipEventRecord(ctx->ev[4], st));
+            unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
+            FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
             FFH_HIP(hipStreamSynchronize(st));
-            ctx->hits = std::move(bigger);
-            const unsigned long long back[2] = {cursor_before, n_real_hits};
-            FFH_HIP(hipMemcpy(ctx->d_counters, back, 16, hipMemcpyHostToDevice));  // the hit cursor and the hit count go back to where this batch began
-            continue;
+            FFH_HIP(hipGetLastError());
+            first_launch = false;
+            const unsigned long long cursor = cnt[0];
+            // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
+            // silently wrong result (the bulge path has the same guard)
+            if (cursor >= (1ull << 32) - 64) { ctx->err = "more than 2^32 raw hits in one scan: lower maxMismatch, split the guide set, or shard the bins over more GPUs"; return FFH_E_ARG; }
+            if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept, copied device to device)
+                DevBuf<uint64_t> bigger;
+                FFH_HIP(bigger.reserve((size_t)(cursor + cursor / 2)));
+                if (cursor_before) FFH_HIP(hipMemcpyAsync(bigger.p, ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToDevice, st));
+                FFH_HIP(hipStreamSynchronize(st));
+                ctx->hits = std::move(bigger);
+                const unsigned long long back[2] = {cursor_before, n_real_hits};
+                FFH_HIP(hipMemcpy(ctx->d_counters, back, 16, hipMemcpyHostToDevice));  // the hit cursor and the hit count go back to where this batch began
+                continue;
+            }
+            ctx->tm.pairs_prefix += cnt[kStatPairs]; ctx->tm.pairs_suffix += cnt[kStatPairs + 1];
+            float a = 0, b = 0;
+            FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
+            FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
+            ms_prep += a; ms_cmp += b;
+            ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += cnt[kStatEntries];
+            ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += cnt[kStatEntries + 1];
+            ctx->tm.compare_launches++;
+            cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
+            n_real_hits = cnt[1];    // the waves' own count (the cursor includes the padding of their last chunks)
+            g0 += ng;
         }
-        ctx->tm.pairs_prefix += cnt[kStatPairs]; ctx->tm.pairs_suffix += cnt[kStatPairs + 1];
-        float a = 0, b = 0;
-        FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
-        FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
-        ms_prep += a; ms_cmp += b;
-        ctx->tm.items_prefix += (uint64_t)((double)ng * np_p); ctx->tm.tiles_prefix += cnt[kStatEntries];
-        ctx->tm.items_suffix += (uint64_t)((double)ng * np_s); ctx->tm.tiles_suffix += cnt[kStatEntries + 1];
-        ctx->tm.compare_launches++;
-        cursor_before = cursor;  // the records already are sort keys: (global guide << tbits) | database index
-        n_real_hits = cnt[1];    // the waves' own count (the cursor includes the padding of their last chunks)
-        g0 += ng;
+        if (sl + 1 == slabs.size()) break;
+        // ---- the slab's positions per guide -> who is still below the limit -> the packed guide set of the next slab ----
+        const uint64_t n_new = cursor_before - slab_start;
+        FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, (size_t)n_guides * 4, st));
+        FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, (size_t)n_guides * 4, st));
+        if (n_new) {
+            uint64_t *sp = ctx->hits.p + slab_start;
+            if (n_new <= kSmallSort) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, sp, (uint32_t)n_new);
+            else {
+                const uint32_t nbk = sort_nblocks(n_new);
+                FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
+                FFH_HIP(ctx->sort_table.reserve((size_t)256 * nbk + 1));
+                FFH_HIP(ctx->sort_offs.reserve((size_t)256 * nbk + 1));
+                FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
+                SortScratch ss;
+                ss.alt = ctx->hits_alt.p + slab_start; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
+                sp = radix_sort_u64(sp, n_new, 0, ctx->tbits + gbits, 64, 64, ss, st);   // (either buffer then holds a permutation of the slab's records)
+            }
+            hipLaunchKernelGGL(k_segments, dim3(blocks_for(n_new, 256)), dim3(256), 0, st, (const uint64_t *)sp, n_new, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
+            FFH_HIP(ctx->hit_t.reserve(n_new + 1));
+            hipLaunchKernelGGL(k_hit_targets, dim3(blocks_for(n_new, 256)), dim3(256), 0, st, (const uint64_t *)sp, n_new, ctx->tbits, n_guides, (const uint64_t *)ctx->targets.p, ctx->hit_t.p);
+        }
+        hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(n_guides, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, (const uint64_t *)ctx->hit_t.p, (const uint32_t *)nullptr,
+                           n_guides, bound_ot, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_bound_update, dim3(blocks_for(n_guides, 256)), dim3(256), 0, st, ctx->g_total.p, (const uint32_t *)ctx->totals.p, n_guides, bound_ot, ctx->g_flag.p);
+        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_guides)));
+        exclusive_scan<uint32_t, uint32_t>(ctx->g_flag.p, n_guides, ctx->g_pos.p, ctx->scan_tmp32.p, st);
+        hipLaunchKernelGGL(k_bound_compact, dim3(blocks_for(n_guides, 256)), dim3(256), 0, st, (const uint64_t *)ctx->guides.p, (const uint32_t *)ctx->g_flag.p,
+                           (const uint32_t *)ctx->g_pos.p, n_guides, ctx->g_active.p, ctx->g_map.p);
+        FFH_HIP(hipGetLastError());
+        uint32_t still = 0;
+        FFH_HIP(hipMemcpyAsync(&still, ctx->g_pos.p + n_guides, 4, hipMemcpyDeviceToHost, st));
+        FFH_HIP(hipStreamSynchronize(st));
+        ctx->tm.retired_guides = n_guides - still;
+        act_guides = ctx->g_active.p; act_map = ctx->g_map.p; n_act = still;
+    }
+    if (bounded) {   // (k_guide_keys cleared nothing: the slabs' own segments are in the arrays)
+        FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, (size_t)n_guides * 4, st));
+        FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, (size_t)n_guides * 4, st));
     }
     ctx->n_raw = cursor_before;
     FFH_HIP(hipEventRecord(ctx->ev[5], st));
@@ -918,8 +1069,6 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
         SortScratch ss;
         ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        int gbits = 1;   // 2^gbits > n_guides: the all-ones padding of the compare waves' chunks sorts behind every guide
-        while (gbits < 32 && (1ull << gbits) <= (uint64_t)n_guides) ++gbits;
         ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
     }
     // seg_begin / seg_end were cleared by the prefix-side k_guide_keys of every batch
@@ -933,6 +1082,30 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm
     ctx->tm.prepare_ms = ms_prep; ctx->tm.compare_ms = ms_cmp; ctx->tm.n_raw_hits = n_real_hits;
     ctx->scan_timing_pending = true;
     ctx->scanned = true;
+    // a guide set that sits in repeat families (thousands of raw hits per guide, most of them beyond any cut-off): bound the
+    // scans that follow on this context
+    constexpr unsigned long long kBoundAutoHits = 2048;
+    if (ctx->bound_auto && !ctx->bound_mode && n_guides >= 64 && n_real_hits > kBoundAutoHits * n_guides && ctx->slabs_state >= 0) ctx->bound_mode = 1;
+    return FFH_OK;
+}
+
+int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm) { return scan_impl(ctx, guides, n_guides, max_mm, 0u); }
+
+int ffh_scan_bounded(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm, int max_offtargets) {
+    if (max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    return scan_impl(ctx, guides, n_guides, max_mm, (ctx && ctx->bound_mode) ? (uint32_t)max_offtargets : 0u);
+}
+
+int ffh_set_bounding(ffh_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) return FFH_E_ARG;
+    ctx->bound_auto = mode < 0;
+    ctx->bound_mode = mode > 0 ? 1 : 0;
+    return FFH_OK;
+}
+
+// a bounded scan holds, for a retired guide, only the hits up to the slab in which it reached bound_ot positions
+static int check_bound(ffh_ctx *ctx, int64_t limit) {
+    if (ctx->bound_ot && limit > (int64_t)ctx->bound_ot) { ctx->err = "the scan was bounded by a smaller maximumOffTargets than the one asked for now (ffh_scan_bounded)"; return FFH_E_STATE; }
     return FFH_OK;
 }
 
@@ -971,6 +1144,7 @@ static void finish_finalize_timing(ffh_ctx *ctx) {  // the stream-ordered shard 
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
     if (!ctx || !totals) return FFH_E_ARG;
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    { const int rc = check_bound(ctx, clamp); if (rc) return rc; }
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(ctx->totals.reserve((size_t)ctx->n_guides + 1));
     { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
@@ -986,6 +1160,7 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals, uint32_t clamp) {
 int ffh_shard_totals_device(ffh_ctx *ctx, uint32_t *device_totals, uint32_t clamp) {
     if (!ctx || !device_totals) return FFH_E_ARG;
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    { const int rc = check_bound(ctx, clamp); if (rc) return rc; }
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(hipDeviceSynchronize());  // the caller's buffer may still be written by another stream (its allocation's fill, a collective)
     { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
@@ -1018,6 +1193,7 @@ static hipError_t copy_out(ffh_ctx *, void *host, const void *dev, size_t bytes,
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets, unsigned flags, ffh_result **out) {
     if (!ctx || !out || max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
+    { const int rc = check_bound(ctx, max_offtargets); if (rc) return rc; }
     FFH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->st;
     const uint32_t G = ctx->n_guides;
@@ -1134,7 +1310,8 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
 }
 
 int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
-    int rc = ffh_scan(ctx, guides, n_guides, max_mismatch);
+    if (max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    int rc = ffh_scan_bounded(ctx, guides, n_guides, max_mismatch, max_offtargets);
     if (rc) return rc;
     return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
 }
@@ -1634,6 +1811,7 @@ static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, cons
                           uint32_t *d_totals) {
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
     if (max_offtargets < 0) { ctx->err = "bad argument"; return FFH_E_ARG; }
+    { const int rc = check_bound(ctx, max_offtargets); if (rc) return rc; }
     FFH_HIP(hipSetDevice(ctx->device));
     FFH_HIP(fence_in(ctx));
     const uint32_t G = ctx->n_guides;

@@ -91,6 +91,8 @@ struct CompareArgs {
     int tbits;                // hit key = (global guide << tbits) | database index
     int max_mm;
     uint32_t pad;
+    const uint32_t *gmap;     // nullable: number, in the caller's guide array, of every guide of this batch (a bounded scan's later
+                              // slabs run on the packed set of guides still active); null = guide_base + position in the batch
 };
 
 // before every compare launch: clears the per-launch statistics words (one launch in place of a memset)
@@ -170,6 +172,7 @@ struct HitStage {
         const uint64_t cap = A->cap;
         const uint32_t *__restrict__ tidx_p = A->side[0].tidx, *__restrict__ tidx_s = A->side[1].tidx;
         const uint32_t guide_base = A->guide_base;
+        const uint32_t *__restrict__ gmap = A->gmap;
         const int tbits = A->tbits;
         const unsigned long long old_pos = chunk_pos;
         const uint32_t old_left = chunk_left;
@@ -196,7 +199,8 @@ struct HitStage {
                 const uint64_t h = my[i];
                 const uint32_t lo = (uint32_t)h, slot = lo & 0x7FFFFFFFu;
                 const uint32_t ti = (lo >> 31) ? tidx_s[slot] : tidx_p[slot];
-                hits[dst] = ((uint64_t)((uint32_t)(h >> 32) + guide_base) << tbits) | ti;
+                const uint32_t g = gmap ? gmap[(uint32_t)(h >> 32)] : (uint32_t)(h >> 32) + guide_base;
+                hits[dst] = ((uint64_t)g << tbits) | ti;
             }
         }
         wave_lds_fence();
@@ -327,7 +331,8 @@ __global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, ui
     const uint32_t o = offs[t], n = offs[t + 1] - o;
     if (t == n_bat - 1) *n_out = offs[n_bat];
     if (!n) return;
-    const uint32_t b0 = t * NB, nbv = min(NB, nb - b0), gs = gstart[b0], ge = gstart[b0 + nbv];
+    const uint32_t b0 = t * NB, b1 = min(nb, b0 + NB);
+    const uint32_t nbv = b1 - b0, gs = gstart[b0], ge = gstart[b1];
     for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(b0, nbv, gs + k * split, min(ge, gs + (k + 1) * split));
 }
 

@@ -84,14 +84,14 @@ __global__ void k_image_hist(const uint64_t *__restrict__ targets, uint64_t n, G
 template <bool SUFFIX>
 __global__ void k_image_scatter(const uint64_t *__restrict__ targets, uint64_t n, Geometry geo, int width,
                                 const uint32_t *__restrict__ bstart, uint32_t *__restrict__ bfill, uint32_t *__restrict__ keys,
-                                uint32_t *__restrict__ tidx) {
+                                uint32_t *__restrict__ tidx, uint32_t base /* database index of targets[0]: an image over a slab of the database */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t pk = planar_key(targets[i], geo.c0, geo.lc);
     const uint32_t b = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
     const uint32_t pos = bstart[b] + atomicAdd(&bfill[b], 1u);
     keys[pos] = SUFFIX ? suffix_rest_key(pk, width) : prefix_rest_key(pk, geo.lc, width);   // the bucket holds the other bases
-    tidx[pos] = (uint32_t)i;
+    tidx[pos] = base + (uint32_t)i;
 }
 
 // The image the compare kernel reads: the targets of a bucket in GROUPS of 32, bit-sliced (ffh_compare.hpp).  A group is GW words:
@@ -173,7 +173,25 @@ struct ItemGeom {
     const uint32_t *range;   // {first, last} bucket of this image that holds a target: entries outside it are dropped while they are
                              // binned (a bin shard of a multi-GPU run holds a contiguous eighth of the prefix buckets: seven eighths
                              // of the (bucket, guide) entries would meet no target)
+    // one slab of a bounded scan (prefix image only): keep the entries whose bucket's first three bases, read as a number 0..63 in
+    // sequence order, lie in [rank_lo, rank_hi].  The bucket id holds the planes apart (all high bits, then all low bits), so a
+    // slab of the database order is not a range of bucket ids; {0, 63} = everything, and the partition sizes then still come from
+    // k_part_sizes.
+    uint32_t rank_lo, rank_hi, width;
 };
+
+// the first three bases of a prefix bucket as a number in sequence (= database) order
+__device__ __forceinline__ uint32_t bucket_rank(uint32_t b, uint32_t width) {
+    const uint32_t h = (b >> (2u * width - 3u)) & 7u, l = (b >> (width - 3u)) & 7u;
+    return ((h & 4u) << 3) | ((l & 4u) << 2) | ((h & 2u) << 2) | ((l & 2u) << 1) | ((h & 1u) << 1) | (l & 1u);
+}
+template <bool SLAB>
+__device__ __forceinline__ bool entry_kept(uint32_t b, uint32_t part, uint32_t part_lo, uint32_t part_hi, const ItemGeom &ig) {
+    if (part < part_lo || part > part_hi) return false;
+    if (!SLAB) return true;
+    const uint32_t r = bucket_rank(b, ig.width);
+    return r >= ig.rank_lo && r <= ig.rank_hi;
+}
 
 // first and last non-empty bucket of an image (range[0] starts at the bucket count, range[1] at 0)
 __global__ void k_bucket_range(const uint32_t *__restrict__ bstart, uint32_t nb, uint32_t *__restrict__ range) {
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__
     if (lane == 0) part_count[q] = (q >= (ig.range[0] >> ig.low_bits) && q <= (ig.range[1] >> ig.low_bits)) ? n : 0u;   // partitions without a target take no entries
 }
 
-template <bool WRITE>
+template <bool WRITE, bool SLAB>
 __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
                                                                  const uint32_t *__restrict__ part_start, uint32_t *__restrict__ part_fill,
                                                                  uint32_t *__restrict__ part_items) {
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig);
         const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
-        if (part >= part_lo && part <= part_hi) atomicAdd(&cur[lds_slot(part)], 1u);
+        if (entry_kept<SLAB>(b, part, part_lo, part_hi, ig)) atomicAdd(&cur[lds_slot(part)], 1u);
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t 
     for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
         const uint32_t x = j_first + o, q = div_pat(x, ig), g = g_first + q;
         const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
-        if (part < part_lo || part > part_hi) continue;
+        if (!entry_kept<SLAB>(b, part, part_lo, part_hi, ig)) continue;
         const uint32_t pos = atomicAdd(&cur[lds_slot(part)], 1u);
         part_items[pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
     }
@@ -777,6 +795,28 @@ __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint
     const uint64_t src = db_pos_off[tidx[i]], dst = out_off[i];
     const uint32_t c = cnt[i];
     for (uint32_t k = 0; k < c; ++k) out[dst + k] = db_pos[src + k];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Bounded scan (ffh_scan_bounded): the database is scanned slab by slab in database order; after every slab a guide whose
+// positions so far reach maximumOffTargets is retired -- the reference stops feeding such a guide as well
+// (crispr/ResultsAggregator.scala:61-69, LinearTraversal.scala:64-76).
+// ---------------------------------------------------------------------------------------------------------
+// total[g] += positions of the slab just scanned (both saturated at the limit); flag[g] = still below the limit
+__global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, uint32_t n, uint32_t limit, uint32_t *__restrict__ flag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint32_t t = min(limit, total[g] + min(limit, slab_total[g]));
+    total[g] = t;
+    flag[g] = t < limit ? 1u : 0u;
+}
+// the guides still active, packed: their longs and their numbers in the caller's guide array
+__global__ void k_bound_compact(const uint64_t *__restrict__ guides, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,
+                                uint64_t *__restrict__ active, uint32_t *__restrict__ gmap) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n || !flag[g]) return;
+    active[pos[g]] = guides[g];
+    gmap[pos[g]] = g;
 }
 
 }  // namespace ffh

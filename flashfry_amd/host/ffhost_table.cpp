@@ -324,7 +324,9 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     auto t1 = clk::now();
     ffh_db_load_stats(ctx[0], &st.load);
     parallel([&](size_t d) {
-        if (ffh_scan(ctx[d], longs.data(), (uint32_t)ng, maxMismatch)) { errs[d] = abiError(ctx[d]); return; }
+        // bounded by maximumOffTargets: a guide that reaches it inside a shard is not scanned against the rest of that shard (the
+        // reference stops feeding such a guide too, ResultsAggregator.scala:61-69); a no-op until a guide set makes bounding switch on
+        if (ffh_scan_bounded(ctx[d], longs.data(), (uint32_t)ng, maxMismatch, std::max(maximumOffTargets, 0))) { errs[d] = abiError(ctx[d]); return; }
         if (ffh_shard_totals(ctx[d], totals[d].data(), (uint32_t)std::max(maximumOffTargets, 0))) errs[d] = abiError(ctx[d]);
     });
     auto t2 = clk::now();

@@ -172,6 +172,18 @@ int ffh_set_plan(ffh_ctx *ctx, int prefix_bases, int prefix_radius);
  * or to device memory of the context's GPU: a guide set that already sits in HBM is not staged through the host again. */
 int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch);
 
+/* ffh_scan for a caller that will keep at most max_offtargets positions per guide (maximumOffTargets): the shard is scanned slab by
+ * slab in database order and a guide whose positions so far reach the limit is not scanned against the later slabs -- the
+ * reference stops feeding an overflowed guide as well (crispr/ResultsAggregator.scala:61-69, LinearTraversal.scala:64-76).  The
+ * retained hits, totals and aggregates are exactly those of ffh_scan for every ffh_finalize / ffh_shard_totals limit <= max_offtargets
+ * (a larger one is refused); the raw hits collected per guide stay within a small multiple of the limit instead of growing with
+ * the size of the guide's repeat family.  3'-PAM enzymes only (database order must follow the compared bases); elsewhere, and
+ * when bounding is switched off, it is ffh_scan.  ffh_discover scans this way when bounding is on.
+ * ffh_set_bounding: 0 = never, 1 = always, -1 (default) = switch itself on for the context once a scan has collected more than
+ * 2048 raw hits per guide. */
+int ffh_scan_bounded(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets);
+int ffh_set_bounding(ffh_ctx *ctx, int mode);
+
 /* per guide: sum of positions over ALL hits of this shard, saturated at `clamp` (pass max_offtargets) */
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t clamp);
 
@@ -315,8 +327,10 @@ typedef struct ffh_timings {
     uint64_t items_suffix;
     uint64_t tiles_prefix;
     uint64_t tiles_suffix;
-    uint32_t compare_launches; /* guide batches */
+    uint32_t compare_launches; /* guide batches (x slabs of a bounded scan) */
     int prefix_bases, prefix_radius, suffix_radius;
+    uint32_t bounded_slabs;   /* 0: every guide met the whole shard; else the slabs of the bounded scan (ffh_scan_bounded) */
+    uint32_t retired_guides;  /* guides that reached the limit before the last slab and were not scanned against it */
 } ffh_timings;
 int ffh_get_timings(const ffh_ctx *ctx, ffh_timings *out);
 

@@ -104,8 +104,34 @@ def test_randomised_parity_slice(capi, oracle):
     assert n >= 20, "the slice should get through a few dozen cases in a minute (%d)" % n
 
 
+_RAW_UNBOUNDED = {}   # raw hits of the unbounded runs of the repeat-genome test (the parametrisation runs bounding 0 first)
+
+
+def test_bounded_scan_on_a_uniform_database_changes_nothing(capi, oracle, chr22):
+    """ffh_scan_bounded forced on (ffh_set_bounding 1) at config C2: three slabs, (almost) nobody retires -- every hit must be found
+    exactly once across the slab boundaries of the prefix image and the per-slab suffix images"""
+    odb, t, p, g = chr22
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        ctx.set_bounding(1)
+        gpu = ctx.discover(g, 4, 2000, jost=True)
+        tm = ctx.timings()
+        lim = ctx.discover(g[:200], 5, 30)
+        with pytest.raises(capi.FlashFryHipError, match="bounded by a smaller"):
+            ctx.finalize(31)
+        ctx.scan(g[:200], 5)                                  # plain ffh_scan is never bounded: any limit may follow
+        un = ctx.finalize(30)
+    assert tm.bounded_slabs >= 3
+    ora = odb.discover(g, 4, 2000)
+    assert_same_hits(gpu, ora)
+    assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
+    assert_same_hits(lim, odb.discover(g[:200], 5, 30))
+    assert lim.summaries.tobytes() == un.summaries.tobytes() and np.array_equal(lim.hit_targets, un.hit_targets)
+
+
+@pytest.mark.parametrize("bounding", [0, 1])
 @pytest.mark.parametrize("max_mm,max_ot", [(4, 2000), (4, 100), (5, 2000)])
-def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_mm, max_ot):
+def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_mm, max_ot, bounding):
     """The heavy-tailed case a real genome is (synth.make_repeat_database: repeat families of thousands of near-copies at 1-14 %
     divergence, low-complexity tracts with counts in the hundreds) with the guides drawn FROM the genome by position, so that many
     guides sit inside a family: hundreds to thousands of raw hits per such guide, most of them beyond the ordered cut-off, buckets
@@ -116,6 +142,7 @@ def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_
     odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
     with capi.Context(3) as ctx:
         ctx.load_soa(t, p)
+        ctx.set_bounding(bounding)
         gpu = ctx.discover(g, max_mm, max_ot, jost=True)
         only = ctx.finalize(max_ot, summaries_only=True, jost=True)
         assert only.summaries.tobytes() == gpu.summaries.tobytes()
@@ -125,5 +152,11 @@ def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_
     assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
     n_over = int(gpu.summaries["overflow"].sum())
     assert n_over >= 20 and n_over < len(g), n_over                       # many guides reach the cut-off, most do not
+    if bounding:   # ffh_scan_bounded: guides that reached the limit in an early slab were not scanned against the later ones
+        assert tm.bounded_slabs >= 3 and tm.retired_guides > 0
+        _RAW_UNBOUNDED.setdefault((max_mm, max_ot), tm.n_raw_hits)
+        assert tm.n_raw_hits <= _RAW_UNBOUNDED[(max_mm, max_ot)]
+        return
+    _RAW_UNBOUNDED[(max_mm, max_ot)] = tm.n_raw_hits
     assert tm.n_raw_hits > 3 * gpu.n_hits or max_ot == 2000              # far more raw hits than retained ones under a tight cut-off
     assert int((t >> np.uint64(48)).max()) >= 100                        # multi-copy targets (low-complexity tracts) are in play
