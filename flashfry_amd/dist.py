@@ -198,3 +198,43 @@ class DeviceExchange:
             self.torch.cuda.current_stream().synchronize()
             return self._host.numpy().view(capi.SUMMARY_DTYPE)
         return self.summ.numpy().view(capi.SUMMARY_DTYPE)
+
+
+class MergedBulgeResult:
+    """the per-shard results of ffh_discover_bulge merged in rank (= database) order: same fields as capi.BulgeResult"""
+
+    def __init__(self, parts):
+        n = parts[0]["guide_offsets"].shape[0] - 1
+        counts = np.zeros(n, dtype=np.int64)
+        for p in parts:
+            counts += np.diff(p["guide_offsets"].astype(np.int64))
+        self.n_guides = n
+        self.guide_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        self.n_hits = int(self.guide_offsets[-1])
+        fields = (("hit_targets", np.uint64), ("hit_mismatches", np.uint8), ("hit_bulge_type", np.uint8), ("hit_bulge_position", np.uint8))
+        for f, dt in fields:
+            setattr(self, f, np.zeros(self.n_hits, dtype=dt))
+        fill = self.guide_offsets[:-1].astype(np.int64).copy()
+        for p in parts:   # shard after shard: a guide's hits of shard r follow its hits of the shards before it
+            off = p["guide_offsets"].astype(np.int64)
+            cnt = np.diff(off)
+            src = np.arange(int(off[-1]), dtype=np.int64)
+            dst = np.repeat(fill - off[:-1], cnt) + src
+            for f, _ in fields:
+                getattr(self, f)[dst] = p[f]
+            fill += cnt
+
+
+def discover_bulge_sharded(ctx, guides, max_mismatch=3, max_bulge=1, tttv=False, group=None):
+    """config C5 across bin shards (one rank per GPU): every rank runs ffh_discover_bulge on its resident shard -- there is no
+    cut-off and no score in this search, so nothing is exchanged on the data path -- and the per-guide hit lists are concatenated in
+    rank order, which is database order.  Returns the merged result on every rank."""
+    import torch.distributed as dist
+    res = ctx.discover_bulge(guides, max_mismatch, max_bulge, tttv=tttv)
+    mine = {f: getattr(res, f) for f in ("guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position")}
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return MergedBulgeResult([mine])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return MergedBulgeResult(parts)

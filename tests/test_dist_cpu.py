@@ -48,3 +48,27 @@ def test_shard_bins_balances_bytes():
         loads = [sizes[a:b].sum() for a, b in cuts]
         assert max(loads) - min(loads) <= 2 * sizes.max()
     assert ffdist.shard_bins([0, 0, 0, 0], 2) == [(0, 0), (0, 4)] or len(ffdist.shard_bins([0, 0, 0, 0], 2)) == 2
+
+
+def test_bulge_results_of_shards_merge_in_rank_order():
+    """flashfry_amd.dist.MergedBulgeResult: per guide, the hits of shard 0, then of shard 1, ... (database order)"""
+    import numpy as np
+    from flashfry_amd.dist import MergedBulgeResult
+    rng = np.random.default_rng(3)
+    parts, per_guide = [], [[] for _ in range(7)]
+    for shard in range(3):
+        cnt = rng.integers(0, 5, size=7)
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+        n = int(off[-1])
+        p = {"guide_offsets": off, "hit_targets": rng.integers(0, 1 << 40, size=n, dtype=np.uint64), "hit_mismatches": rng.integers(0, 4, size=n).astype(np.uint8),
+             "hit_bulge_type": rng.integers(0, 3, size=n).astype(np.uint8), "hit_bulge_position": rng.integers(0, 19, size=n).astype(np.uint8)}
+        parts.append(p)
+        for g in range(7):
+            for h in range(int(off[g]), int(off[g + 1])):
+                per_guide[g].append((int(p["hit_targets"][h]), int(p["hit_mismatches"][h]), int(p["hit_bulge_type"][h]), int(p["hit_bulge_position"][h])))
+    m = MergedBulgeResult(parts)
+    assert m.n_hits == sum(len(x) for x in per_guide)
+    for g in range(7):
+        a, b = int(m.guide_offsets[g]), int(m.guide_offsets[g + 1])
+        got = list(zip(m.hit_targets[a:b].tolist(), m.hit_mismatches[a:b].tolist(), m.hit_bulge_type[a:b].tolist(), m.hit_bulge_position[a:b].tolist()))
+        assert got == per_guide[g]

@@ -29,3 +29,18 @@ def test_hip_shards_plus_exchange_equal_the_unsharded_discover(tmp_path, world, 
     assert res["max_sum_err"] <= 1e-9, res
     if max_ot < 2000:   # the cut-off really crossed a shard boundary, and some guides reached it only in a later shard
         assert 0 < res["n_overflowed"] < res["n_guides"] and res["crossing"] > 0 and res["cut_in_later_shard"] > 0, res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cas12a_bulge_search_over_bin_shards_equals_the_unsharded_search(tmp_path, world):
+    """config C5's multi-GPU half: every rank searches its bin shard (HIP, seeded bulge search), the hit lists concatenated in rank
+    order are the unsharded search's (no cut-off, no score: nothing to exchange on the data path)"""
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", FFH_TEST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker_bulge.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.load(open(out))
+    assert res["world"] == world and res["ok"], res
+    assert res["n_hits"] > 1000 and res["types"] == [0, 1, 2], res
