@@ -182,6 +182,8 @@ struct ffh_ctx {
     uint64_t T = 0, P = 0;
     DevBuf<uint64_t> targets, positions, pos_off;
     Image img[2];  // 0 prefix, 1 suffix
+    Image alt[2];  // a second pair of images with another split (select_images: 11 + 9 suits 4 mismatches at hg38 scale, 10 + 10 suits 5)
+    bool auto_width = true;
     std::vector<std::string> contigs;
     std::vector<uint64_t> bin_bytes;
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
@@ -276,28 +278,36 @@ static const std::vector<uint32_t> &patterns_for(ffh_ctx *ctx, int n, int r) {
     return ctx->pattern_cache.emplace(key, std::move(v)).first->second;
 }
 
-static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
-    const int lc = ctx->geo.lc, a = ctx->img[0].width, s = ctx->img[1].width;
-    const double T = (double)std::max<uint64_t>(ctx->T, 1);
-    const double per_p = std::max(T / std::pow(4.0, a), 1.0), per_s = std::max(T / std::pow(4.0, s), 1.0);
-    Plan best{a, std::min(max_mm, a), s, -1};
-    // cost of a plan in pair tests per guide: every candidate entry meets the targets of its bucket and costs about as much as
-    // kEntryCost pair tests to generate and bin (measured at hg38 scale: 10.4 ps per entry against 0.24 ps per pair test)
+// cost of the best (r1, r2) for a prefix width a, in pair tests per guide: every candidate entry meets the slots of its bucket (the
+// targets rounded up to groups of 32: + 16 on average) and costs about as much as kEntryCost pair tests to generate and bin
+// (measured at hg38 scale: 10.4 ps per entry against 0.24 ps per pair test)
+static double plan_cost(double T, int lc, int a, int max_mm, Plan &best) {
     constexpr double kEntryCost = 40.0;
+    const int s = lc - a;
+    const double per_p = std::max(T / std::pow(4.0, a), 1.0) + 16.0, per_s = std::max(T / std::pow(4.0, s), 1.0) + 16.0;
+    best = Plan{a, std::min(max_mm, a), s, -1};
     double best_cost = ball_size(a, best.r1) * (per_p + kEntryCost);
-    if (ctx->plan_r1 >= 0) {  // forced
-        Plan p{a, std::min(ctx->plan_r1, a), s, max_mm - 1 - ctx->plan_r1};
-        if (p.r1 >= max_mm || p.r1 >= a) { p.r1 = std::min(max_mm, a); p.r2 = -1; }
-        if (p.r2 > s) p.r2 = s;
-        return p;
-    }
-    if (max_mm >= 1 && a + s == lc)
+    if (max_mm >= 1)
         for (int r1 = 0; r1 <= std::min(max_mm - 1, a); ++r1) {
             const int r2 = max_mm - 1 - r1;
             if (r2 > s) continue;
             const double cost = ball_size(a, r1) * (per_p + kEntryCost) + ball_size(s, r2) * (per_s + kEntryCost);
             if (cost < best_cost) { best_cost = cost; best = Plan{a, r1, s, r2}; }
         }
+    return best_cost;
+}
+
+static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
+    const int lc = ctx->geo.lc, a = ctx->img[0].width, s = ctx->img[1].width;
+    if (ctx->plan_r1 >= 0) {  // forced
+        Plan p{a, std::min(ctx->plan_r1, a), s, max_mm - 1 - ctx->plan_r1};
+        if (p.r1 >= max_mm || p.r1 >= a) { p.r1 = std::min(max_mm, a); p.r2 = -1; }
+        if (p.r2 > s) p.r2 = s;
+        return p;
+    }
+    Plan best;
+    (void)plan_cost((double)std::max<uint64_t>(ctx->T, 1), lc, a, max_mm, best);
+    if (a + s != lc) best = Plan{a, std::min(max_mm, a), s, -1};
     return best;
 }
 
@@ -380,6 +390,7 @@ static int prepare_database(ffh_ctx *ctx) {
     if (ctx->plan_a < 0) a = std::max(a, lc - 10);
     a = std::max(lc - 12, std::min(12, a));
     drop_slabs(ctx);   // (slab images of the database that was resident before)
+    ctx->alt[0] = Image(); ctx->alt[1] = Image();
     int rc = build_image(ctx, 0, a);
     if (rc) return rc;
     rc = build_image(ctx, 1, lc - a);
@@ -422,6 +433,11 @@ static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t
     // 1024 buckets per partition keep a partition's candidate ids (~13k at hg38 scale) inside the 56 KB LDS stage of k_item_bin,
     // which lets two of its blocks share a CU; 12-base images (24-bit bucket ids) need 4096 per partition to stay within 4096 partitions
     ig.low_bits = (uint32_t)std::max(std::min(2 * width, kMaxLowBits - 2), 2 * width - kMaxPartBits);
+    // ... and more, smaller partitions when that stage would overflow on average (a 10-base image at 5 mismatches: 4.4e7 entries in
+    // 1024 partitions took k_item_bin's two-pass path for every partition)
+    while (ig.low_bits > 2u && 2u * (uint32_t)width - (ig.low_bits - 1u) <= (uint32_t)kMaxPartBits &&
+           (double)ng * (double)np / (double)(1u << (2u * (uint32_t)width - ig.low_bits)) > 0.9 * (double)kBinStage)
+        --ig.low_bits;
     const uint32_t part_bits = 2u * (uint32_t)width - ig.low_bits;
     if (part_bits > (uint32_t)kMaxPartBits || ig.low_bits > (uint32_t)kMaxLowBits) { ctx->err = "bucket width too large for the candidate binning"; return FFH_E_ARG; }
     ig.n_part = 1u << part_bits;
@@ -873,6 +889,38 @@ static int ensure_slabs(ffh_ctx *ctx) {
     return FFH_OK;
 }
 
+// The split of the compared bases into prefix and suffix key is fixed when the images are built; the best split depends on
+// maxMismatch (at hg38 scale 11 + 9 for <= 4 mismatches, 10 + 10 for 5: 40 % fewer pair tests).  A large database therefore keeps
+// up to two pairs of images: when the cost model prefers another width by more than a fifth, that pair is built once (tens of ms)
+// and the two pairs are swapped per call.  Off for forced plans (ffh_set_plan) and small databases.
+static int select_images(ffh_ctx *ctx, int max_mm) {
+    if (!ctx->auto_width || ctx->plan_a >= 0 || ctx->plan_r1 >= 0 || ctx->T < (1ull << 24)) return FFH_OK;
+    const int lc = ctx->geo.lc, cur = ctx->img[0].width;
+    const double T = (double)ctx->T;
+    Plan p;
+    const double cost_cur = plan_cost(T, lc, cur, max_mm, p);
+    // among equally cheap widths (the model is symmetric in prefix and suffix) the one nearest to the default split wins
+    const int a_def = std::max(lc - 12, std::min(12, std::max((int)std::floor(std::log(T / 48.0) / std::log(4.0)), lc - 10)));
+    int best_a = cur;
+    double best = cost_cur;
+    for (int a = std::max(lc - 12, 8); a <= std::min(12, lc - 8); ++a) {
+        const double c = plan_cost(T, lc, a, max_mm, p);
+        if (c < best * (1.0 - 1e-9) || (c <= best * (1.0 + 1e-9) && std::abs(a - a_def) < std::abs(best_a - a_def))) { best = c; best_a = a; }
+    }
+    if (best_a == cur || best > 0.8 * cost_cur) return FFH_OK;
+    if (ctx->alt[0].width != best_a) {
+        int rc = build_image_into(ctx, ctx->alt[0], 0, best_a, 0, ctx->T);
+        if (!rc) rc = build_image_into(ctx, ctx->alt[1], 1, lc - best_a, 0, ctx->T);
+        FFH_HIP(hipStreamSynchronize(ctx->st));
+        ctx->tmp_keys.release(); ctx->tmp_tidx.release();
+        if (rc) { ctx->alt[0] = Image(); ctx->alt[1] = Image(); return rc; }
+    }
+    std::swap(ctx->img[0], ctx->alt[0]);
+    std::swap(ctx->img[1], ctx->alt[1]);
+    drop_slabs(ctx);   // (the slabs' suffix images have the other width)
+    return FFH_OK;
+}
+
 // bound_ot > 0: the caller will not ask for more than bound_ot positions per guide (maximumOffTargets), so a guide whose positions
 // reach it in the slabs scanned so far is retired from the later ones
 static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm, uint32_t bound_ot) {
@@ -891,6 +939,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyDefault, st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
 
+    { const int rc = select_images(ctx, std::min(max_mm, ctx->geo.lc)); if (rc) return rc; }
     ctx->tbits = 1;
     while (ctx->tbits < 32 && (1ull << ctx->tbits) < std::max<uint64_t>(ctx->T, 2)) ++ctx->tbits;
     int gbits = 1;   // 2^gbits > n_guides: the all-ones padding of the compare waves' chunks sorts behind every guide

@@ -130,3 +130,19 @@ def test_result_does_not_depend_on_the_candidate_split_or_on_sharding(world):
     assert np.array_equal(merged, np.concatenate([whole.hits(g) for g in range(0, G, 97)]))
     assert np.array_equal(r0.summaries["ot_count"] + r1.summaries["ot_count"], whole.summaries["ot_count"])
     assert np.array_equal(r0.summaries["overflow"] | r1.summaries["overflow"], whole.summaries["overflow"])
+
+
+def test_five_and_three_mismatches_take_the_10_10_images_and_four_the_11_9_ones(world):
+    """select_images: at hg38 scale the cost model prefers a 10 + 10 split for <= 5 (and <= 3) mismatches and 11 + 9 for <= 4; the context
+    builds the second pair of images on first use and swaps per call.  Complete hit sets of sampled guides against the brute-force
+    torch scan under both pairs."""
+    torch, ctx, db = world["torch"], world["ctx"], world["db"]
+    g = world["guides"][:3000]
+    ctx.set_plan(-1, -1)
+    for max_mm, width in ((5, 10), (4, 11), (3, 10), (4, 11)):
+        res = ctx.discover(g, max_mm, 2 ** 31 - 1, positions=False, hit_scores=False)
+        assert ctx.info().prefix_bases == width and ctx.timings().prefix_bases == width, (max_mm, ctx.info().prefix_bases)
+        for k in (0, 1, 100, 700, 1500, 2999):
+            mm = torch_mismatches(torch, int(g[k].astype(np.int64)), db["targets"])
+            idx = torch.nonzero(mm <= max_mm).flatten()
+            assert np.array_equal(res.hits(k), db["targets"][idx].cpu().numpy().view(np.uint64)), (max_mm, k)

@@ -18,24 +18,43 @@ rng = np.random.default_rng(12345)
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     seed = int(rng.integers(0, 1 << 30))
-    kind = int(rng.integers(0, 2))
+    kind = int(rng.integers(0, 3))
     max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
     max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
     if kind == 0:
         odb, t, p, g = make_case(oracle, int(rng.integers(100, 400000)), int(rng.integers(1, 600)), enzyme=3, seed=seed)
+    elif kind == 2:   # repeat-structured genome, guides sampled from it (families, multi-copy targets, many OVERFLOW guides)
+        from flashfry_amd import synth
+        db = synth.make_repeat_database(int(rng.integers(70000, 900000)), seed=seed, repeat_fraction=float(rng.uniform(0.1, 0.6)))
+        g = synth.as_u64(synth.make_guides_from_database(db, int(rng.integers(20, 400)), seed=seed + 1))
+        t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
+        odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+        max_mm = min(max_mm, 5)
     else:
         ng = int(rng.integers(10, 500))
         odb, t, p, g = dense_case(oracle, n_random=int(rng.integers(1000, 120000)), n_guides=ng,
                                   n_dense=int(rng.integers(1, min(60, ng))), variants=int(rng.integers(10, 200)), seed=seed)
     enz = 3
+    bounding = int(rng.choice([-1, 0, 1, 1]))     # ffh_scan_bounded engages for databases of >= 65536 targets
+    pos, sc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     with capi.Context(enz) as ctx:
         ctx.load_soa(t, p)
+        ctx.set_bounding(bounding)
         gpu = ctx.discover(g, max_mm, max_ot, jost=True)
+        slabs = ctx.timings().bounded_slabs
         only = ctx.finalize(max_ot, summaries_only=True, jost=True)
         assert only.summaries.tobytes() == gpu.summaries.tobytes()
+        lean = ctx.finalize(max_ot, jost=True, positions=pos, hit_scores=sc)   # the list path with its optional arrays left out
+        assert lean.summaries.tobytes() == gpu.summaries.tobytes() and np.array_equal(lean.hit_targets, gpu.hit_targets)
+        assert np.array_equal(lean.hit_mismatches, gpu.hit_mismatches) and np.array_equal(lean.guide_offsets, gpu.guide_offsets)
+        if pos:
+            assert np.array_equal(lean.positions, gpu.positions) and np.array_equal(lean.pos_offsets, gpu.pos_offsets)
+        if sc:
+            assert lean.hit_cfd.tobytes() == gpu.hit_cfd.tobytes()
     ora = odb.discover(g, max_mm, max_ot)
     assert_same_hits(gpu, ora)
     assert_same_scores(oracle, enz, g, gpu, ora)
     n += 1
-    print("ok %3d kind %d enzyme %d T %7d G %4d mm %d max_ot %4d hits %8d" % (n, kind, enz, len(t), len(g), max_mm, max_ot, gpu.n_hits), flush=True)
+    print("ok %3d kind %d enzyme %d T %7d G %4d mm %d max_ot %4d hits %8d bounding %2d slabs %d overflow %d" % (n, kind, enz, len(t), len(g), max_mm, max_ot, gpu.n_hits, bounding, slabs,
+                                                                                                                  int(gpu.summaries["overflow"].sum())), flush=True)
 print("all %d cases agree" % n)
