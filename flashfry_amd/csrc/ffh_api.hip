@@ -1080,7 +1080,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                 FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
                 SortScratch ss;
                 ss.alt = ctx->hits_alt.p + slab_start; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-                sp = radix_sort_u64(sp, n_new, 0, ctx->tbits + gbits, 64, 64, ss, st);   // (either buffer then holds a permutation of the slab's records)
+                // by guide only (three passes instead of six): the totals do not depend on the order inside a guide's segment
+                sp = radix_sort_u64(sp, n_new, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);   // (either buffer then holds a permutation of the slab's records)
             }
             hipLaunchKernelGGL(k_segments, dim3(blocks_for(n_new, 256)), dim3(256), 0, st, (const uint64_t *)sp, n_new, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
             FFH_HIP(ctx->hit_t.reserve(n_new + 1));
