@@ -841,8 +841,8 @@ __global__ void k_slab_cuts(const uint64_t *__restrict__ targets, uint64_t n, in
     const uint32_t r = (uint32_t)(t >> (2 * scan_len - 6)) & 63u;
     if (i == 0) { for (uint32_t k = 0; k <= r; ++k) cut[k] = 0u; return; }
     const uint64_t p = targets[i - 1] & M;
-    if (p > t) atomicAdd(bad, 1u);
     const uint32_t rp = (uint32_t)(p >> (2 * scan_len - 6)) & 63u;
+    if (p > t || rp > r) atomicAdd(bad, 1u);   // (rp > r: bits above the sequence are set and lead the order -- not a database the reference writes)
     for (uint32_t k = rp + 1; k <= r; ++k) cut[k] = (uint32_t)i;   // ranks without a target between rp and r start here too
 }
 

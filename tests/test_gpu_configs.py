@@ -160,3 +160,54 @@ def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_
     _RAW_UNBOUNDED[(max_mm, max_ot)] = tm.n_raw_hits
     assert tm.n_raw_hits > 3 * gpu.n_hits or max_ot == 2000              # far more raw hits than retained ones under a tight cut-off
     assert int((t >> np.uint64(48)).max()) >= 100                        # multi-copy targets (low-complexity tracts) are in play
+
+
+def test_bounded_scan_with_guide_batches_and_other_enzymes(capi, oracle, monkeypatch):
+    """the slabs of a bounded scan run on the packed set of guides still active, batch by batch: any batch size gives the oracle's
+    result; a 19-mer 3'-PAM pack is bounded as well, a 5'-PAM pack (Cpf1) silently stays unbounded"""
+    db = synth.make_repeat_database(400_000, seed=synth.DB_SEED + 11)
+    g = synth.as_u64(synth.make_guides_from_database(db, 300, seed=synth.GUIDE_SEED + 11))
+    t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
+    odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+    ora = odb.discover(g, 4, 150)
+    for batch in ("1000000", "53"):
+        monkeypatch.setenv("FFH_MAX_GUIDE_BATCH", batch)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            ctx.set_bounding(1)
+            gpu = ctx.discover(g, 4, 150, jost=True)
+            tm = ctx.timings()
+        assert tm.bounded_slabs == 6 and tm.retired_guides > 0 and tm.compare_launches >= 6
+        assert_same_hits(gpu, ora)
+        assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
+    monkeypatch.delenv("FFH_MAX_GUIDE_BATCH")
+    # spCas9-NGG 19-mers (22 bases, 3' PAM, sequence in bits 43:0): bounded like the 23-mers
+    rng = np.random.default_rng(66)
+    seq = np.unique((rng.integers(0, 1 << 38, size=160_000, dtype=np.uint64) << np.uint64(6)) | (rng.integers(0, 4, size=160_000, dtype=np.uint64) << np.uint64(4)) | np.uint64(0b1010))
+    t2 = seq | (np.uint64(1) << np.uint64(48))
+    p2 = rng.integers(0, 1 << 27, size=len(t2), dtype=np.uint64) | (np.uint64(3) << np.uint64(32))
+    g2 = t2[rng.integers(0, len(t2), size=150)] ^ (rng.integers(0, 4, size=150, dtype=np.uint64) << np.uint64(2 * 9 + 6))   # one base changed (or not)
+    odb2 = oracle.db_from_sorted(6, t2, p2, contigs=synth.CONTIGS_24)
+    with capi.Context(6) as ctx:
+        ctx.load_soa(t2, p2)
+        ctx.set_bounding(1)
+        gpu = ctx.discover(g2, 4, 3)
+        assert ctx.timings().bounded_slabs == 6
+    assert_same_hits(gpu, odb2.discover(g2, 4, 3))
+    # neither of these can be bounded, both silently stay plain scans: make_case's 22-base packs carry bits above the sequence, which
+    # lead their order (checked by k_slab_cuts); Cpf1 has a 5' PAM, its database order is (bin = the 7 bases after the PAM, sequence)
+    odb3, t3, p3, g3 = make_case(oracle, 150_000, 120, enzyme=5, seed=5)
+    from tests.test_gpu_parity import _cas12a_database
+    g40 = rng.integers(0, 1 << 40, size=120, dtype=np.uint64)
+    t4, p4 = _cas12a_database(rng, 150_000, g40, 6)
+    g4 = g40 | np.uint64(0b11111100 << 40) | np.uint64(1 << 48)
+    odb4 = oracle.db_from_sorted(1, t4, p4, contigs=synth.CONTIGS_24)
+    for enzyme, odb_, t_, p_, g_, max_ot in ((5, odb3, t3, p3, g3, 2000), (1, odb4, t4, p4, g4, 3)):
+        with capi.Context(enzyme) as ctx:
+            ctx.load_soa(t_, p_)
+            ctx.set_bounding(1)
+            gpu = ctx.discover(g_, 4, max_ot)
+            assert ctx.timings().bounded_slabs == 0
+        ora_ = odb_.discover(g_, 4, max_ot)
+        assert_same_hits(gpu, ora_)
+        assert gpu.n_hits > 0
