@@ -41,6 +41,19 @@ DEFKERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1")
 DEFKERNEL(k_dot4, "v_dot4_u32_u8 %0, %0, %1, %2")
 DEFKERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
 DEFKERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+DEFKERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %1")
+DEFKERNEL(k_mul24, "v_mul_u32_u24 %0, %0, %1")
+DEFKERNEL(k_bfe_i32, "v_bfe_i32 %0, %0, 3, 1")
+DEFKERNEL(k_bfe_u32, "v_bfe_u32 %0, %0, 3, 5")
+DEFKERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+DEFKERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
+DEFKERNEL(k_sub, "v_sub_u32 %0, %0, %1")
+DEFKERNEL(k_ashr, "v_ashrrev_i32 %0, 31, %0")
+DEFKERNEL(k_and, "v_and_b32 %0, %0, %1")
+DEFKERNEL(k_xor_lit, "v_xor_b32 %0, 0x12345678, %0")
+DEFKERNEL(k_add_inl, "v_add_u32 %0, 1, %0")
+DEFKERNEL(k_ffbl, "v_ffbl_b32 %0, %0")
+DEFKERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
 
 template <typename K>
 static void run(const char *name, K kern, uint32_t *out) {
@@ -65,5 +78,6 @@ int main() {
 #define RUN(K) run(#K, K, out);
     RUN(k_xor) RUN(k_xor_s) RUN(k_add) RUN(k_lshr) RUN(k_bcnt) RUN(k_bitop3) RUN(k_min) RUN(k_min3) RUN(k_and_or) RUN(k_or_sdwa) RUN(k_cmp)
     RUN(k_alignbit) RUN(k_perm) RUN(k_sad) RUN(k_mad24) RUN(k_fma) RUN(k_pk_add_u16) RUN(k_dot4) RUN(k_lshl_or) RUN(k_mov_dpp)
+    RUN(k_mul_lo) RUN(k_mul24) RUN(k_bfe_i32) RUN(k_bfe_u32) RUN(k_cndmask) RUN(k_lshl_add) RUN(k_sub) RUN(k_ashr) RUN(k_and) RUN(k_xor_lit) RUN(k_add_inl) RUN(k_ffbl) RUN(k_mbcnt)
     return 0;
 }
