@@ -315,7 +315,7 @@ void ffh_result_free(ffh_result *r);
  * Instrumentation of the last ffh_scan/ffh_finalize on this context (HIP events on the context's stream).
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct ffh_timings {
-    double prepare_ms;        /* guide encode + candidate lists + tiles */
+    double prepare_ms;        /* guide encode + candidate lists (CSR) of both images */
     double compare_ms;        /* the compare kernel (the dominant kernel): ONE launch per guide batch covering both images */
     double sort_ms;           /* hit ordering */
     double finalize_ms;       /* cut-off, scoring, aggregation, gathers */
@@ -325,7 +325,7 @@ typedef struct ffh_timings {
     uint64_t pairs_suffix;    /* ... by the suffix pass */
     uint64_t items_prefix;    /* (bucket, guide) candidate entries enumerated */
     uint64_t items_suffix;
-    uint64_t tiles_prefix;
+    uint64_t tiles_prefix;    /* work entries the compare launch walked for the prefix image (runs of buckets; field name kept from round 1) */
     uint64_t tiles_suffix;
     uint32_t compare_launches; /* guide batches (x slabs of a bounded scan) */
     int prefix_bases, prefix_radius, suffix_radius;
