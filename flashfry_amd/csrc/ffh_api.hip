@@ -317,6 +317,12 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
     const uint32_t nb = 1u << (2 * width);
     im.width = width;
     im.rest = ctx->geo.lc - width;
+    if (im.rest < kMinRest || im.rest > kMaxRest) {   // the compare kernel has one row form per rest width (ffh_compare.hpp)
+        ctx->err = "bucket width " + std::to_string(width) + " leaves a rest key of " + std::to_string(im.rest) + " bases; the scan supports " +
+                   std::to_string(kMinRest) + " .. " + std::to_string(kMaxRest);
+        im.width = -1;
+        return FFH_E_ARG;
+    }
     const uint32_t R = (uint32_t)im.rest, GW = (uint32_t)group_words(im.rest);
     // every bucket rounds its targets up to whole groups of 32: at most T / 32 + nb groups (no host round trip for the exact number)
     const uint64_t max_groups = t_n / 32 + nb;
@@ -936,7 +942,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     FFH_HIP(ctx->seg_begin.reserve((size_t)n_guides + 1));  // cleared per batch by k_guide_keys, filled by k_segments
     FFH_HIP(ctx->seg_end.reserve((size_t)n_guides + 1));
     // host or device memory (unified addressing tells): a caller whose guide set already sits in HBM passes the device pointer
-    if (n_guides) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyDefault, st));
+    if (n_guides && guides != ctx->guides.p) FFH_HIP(hipMemcpyAsync(ctx->guides.p, guides, (size_t)n_guides * 8, hipMemcpyDefault, st));
     if (ctx->hits.cap == 0) FFH_HIP(ctx->hits.reserve(std::max<size_t>(1u << 22, (size_t)n_guides * 256)));
 
     { const int rc = select_images(ctx, std::min(max_mm, ctx->geo.lc)); if (rc) return rc; }
@@ -957,7 +963,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     struct Slab { const Image *suffix; uint32_t rank_lo, rank_hi; uint64_t n_targets; };
     std::vector<Slab> slabs;
     bool bounded = bound_ot > 0 && ctx->bound_mode > 0 && n_guides > 0 && plan.r2 >= 0;
-    if (bounded) { const int rc = ensure_slabs(ctx); if (rc) return rc; bounded = ctx->slabs_state == 1; }
+    // (slab images that cannot be had -- out of memory for the six extra suffix images -- mean an unbounded scan, not a failed one)
+    if (bounded) { if (ensure_slabs(ctx) != FFH_OK) { ctx->err.clear(); (void)hipGetLastError(); } bounded = ctx->slabs_state == 1; }
     if (bounded)
         for (size_t k = 0; k + 1 < ctx->slab_t.size(); ++k)
             slabs.push_back(Slab{ctx->slab_img[k].get(), kSlabRank[k], kSlabRank[k + 1] - 1u, ctx->slab_t[k + 1] - ctx->slab_t[k]});
@@ -1154,9 +1161,12 @@ int ffh_set_bounding(ffh_ctx *ctx, int mode) {
 }
 
 // a bounded scan holds, for a retired guide, only the hits up to the slab in which it reached bound_ot positions
+// -- which is everything a caller with a limit <= bound_ot can ask for.  A larger limit (ffh_discover(A) followed by ffh_finalize /
+// ffh_shard_totals with B > A) needs hits the bounded scan never collected: the guide set is still resident, so the scan is redone
+// unbounded instead of making the answer depend on whether an earlier call happened to switch bounding on.
 static int check_bound(ffh_ctx *ctx, int64_t limit) {
-    if (ctx->bound_ot && limit > (int64_t)ctx->bound_ot) { ctx->err = "the scan was bounded by a smaller maximumOffTargets than the one asked for now (ffh_scan_bounded)"; return FFH_E_STATE; }
-    return FFH_OK;
+    if (!ctx->bound_ot || limit <= (int64_t)ctx->bound_ot) return FFH_OK;
+    return scan_impl(ctx, ctx->guides.p, ctx->n_guides, ctx->max_mm, 0u);
 }
 
 // hit_t[i] = target long of sorted hit i: needed by the paths that deliver hit lists or shard totals; the aggregates-only epilogue
@@ -1707,7 +1717,6 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
                         for (uint32_t d = 0; d < 4; ++d) pat.push_back(((hi << 1 | (d >> 1)) << w) | (lo << 1 | (d & 1u)));
                     }
                 }
-                if ((uint64_t)n_guides * ((pat.size() + 63) / 64) >= (1ull << 33)) { ctx->err = "too many guides x candidate buckets for one bulge search"; return FFH_E_ARG; }
                 FFH_HIP(d_pat[kind].reserve(pat.size()));
                 FFH_HIP(hipMemcpyAsync(d_pat[kind].p, pat.data(), pat.size() * 4, hipMemcpyHostToDevice, st));
                 FFH_HIP(hipStreamSynchronize(st));  // pat is a local
@@ -1727,9 +1736,17 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
                                    (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
             else
                 for (int i = 0; i < n_seeds; ++i) {
-                    const uint64_t waves = (uint64_t)n_guides * ((seeds[i].n_pat + 63) / 64);
-                    hipLaunchKernelGGL(k_bulge_seed, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, seeds[i], (const uint64_t *)ctx->targets.p, (const uint64_t *)d_guides.p,
-                                       n_guides, ctx->geo, max_mismatch, max_bulge, (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p, cursor, (uint64_t)cap);
+                    // one wave per (guide, 64 patterns); a launch holds at most 2^22 blocks of four waves (HIP refuses grids of 2^32
+                    // threads or more: ADVICE r2), so a large guide set goes in several launches
+                    const uint64_t slices = (seeds[i].n_pat + 63) / 64;
+                    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_guides, ((1ull << 24) - 4) / slices));
+                    for (uint32_t g0 = 0; g0 < n_guides; g0 += per) {
+                        const uint32_t ng = std::min(per, n_guides - g0);
+                        const uint64_t waves = (uint64_t)ng * slices;
+                        hipLaunchKernelGGL(k_bulge_seed, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, seeds[i], (const uint64_t *)ctx->targets.p,
+                                           (const uint64_t *)d_guides.p + g0, ng, g0, ctx->geo, max_mismatch, max_bulge, (flags & FFH_BULGE_PAM_TTTV) ? 1 : 0, tbits, key.p, val.p,
+                                           cursor, (uint64_t)cap);
+                    }
                 }
             FFH_HIP(hipGetLastError());
             unsigned long long found = 0;

@@ -142,7 +142,8 @@ struct BulgeSeed {
     int kind;             // 0 P, 1 D, 2 R
 };
 
-__global__ __launch_bounds__(256) void k_bulge_seed(BulgeSeed S, const uint64_t *__restrict__ targets, const uint64_t *__restrict__ guides, uint32_t n_guides, Geometry geo,
+__global__ __launch_bounds__(256) void k_bulge_seed(BulgeSeed S, const uint64_t *__restrict__ targets, const uint64_t *__restrict__ guides /* of this launch */,
+                                                    uint32_t n_guides, uint32_t guide_base /* number of guides[0] in the caller's array */, Geometry geo,
                                                     int max_mm, int max_bulge, int tttv, int tbits, uint64_t *__restrict__ hit_key, uint64_t *__restrict__ hit_val,
                                                     unsigned long long *__restrict__ cursor, uint64_t cap) {
     const uint32_t lane = threadIdx.x & 63;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_bulge_seed(BulgeSeed S, const uint64_t 
                 ti = S.tidx[(size_t)gg0 * 32 + k];
                 if (tttv && ((uint32_t)(targets[ti] >> 40) & 3u) == 3u) hit = false;
             }
-            bulge_emit(hit, ((uint64_t)g << tbits) | ti, (uint64_t)best | ((uint64_t)type << 8) | ((uint64_t)pos << 16), hit_key, hit_val, cursor, cap);
+            bulge_emit(hit, ((uint64_t)(guide_base + g) << tbits) | ti, (uint64_t)best | ((uint64_t)type << 8) | ((uint64_t)pos << 16), hit_key, hit_val, cursor, cap);
         }
     }
 }

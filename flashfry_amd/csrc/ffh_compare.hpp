@@ -59,6 +59,7 @@ constexpr int kKeyRegs = kKW / 256;        // 16-byte loads per lane and batch
 constexpr int kGidRegs = kKC / 64;
 constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is split into jobs of about this many groups
 constexpr int kMaxParts = 16;
+constexpr int kMinRest = 7, kMaxRest = 12;   // rest-key widths k_compare has a row form for (19-mers with a 12-base bucket key: 7)
 
 constexpr uint32_t kStatPairs = 4, kStatEntries = 6;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
 
@@ -278,11 +279,7 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
             hit &= g;
         }
         if (t >= trips) hit = 0;                        // a lane that is done (its reads ran into a neighbour's groups)
-#ifdef FFH_EXP_NOHIT   // timing experiment: no pair ever hits (results wrong)
-        const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit == 0x12345u && c0 == 77u);
-#else
         const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit != 0u);
-#endif
         if (lanes) {   // rare: the lanes with a non-zero mask stage one record per set bit (almost always one)
             const uint32_t slot0 = ((gabs + t) << 5) | c.side_bit;
             uint64_t more = lanes;
@@ -360,9 +357,6 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     // entries q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
     // describes it stays in scalar registers.
     for (int side = 1; side >= 0; --side) {
-#ifdef FFH_EXP_ONLY_SIDE   // timing experiment: one image only (results wrong)
-        if (side != FFH_EXP_ONLY_SIDE) continue;
-#endif
         const SideArgs S = A.side[side];
         if (!S.n_list) continue;
         const uint32_t n_total = *S.n_list;
@@ -487,12 +481,14 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                 const uint32_t x = cand.y ^ (e.b0 + i);
                 const uint32_t d = (uint32_t)__popc(((x >> rc.width) | x) & ((1u << rc.width) - 1u));   // mismatches inside the bucket key
                 const uint32_t gword = tb.x + g_lo * GW, gabs = tb.w + g_lo;
-                switch (S.rest) {   // uniform
+                switch (S.rest) {   // uniform; kMinRest .. kMaxRest, checked by the host when the images are built
+                    case 7: scan_row<7>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
                     case 8: scan_row<8>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
                     case 9: scan_row<9>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
                     case 10: scan_row<10>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
                     case 11: scan_row<11>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    default: scan_row<12>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    case 12: scan_row<12>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
+                    default: __builtin_trap();   // an image this kernel has no row form for: never a silently wrong hit set
                 }
             }
         };

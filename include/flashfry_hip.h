@@ -176,7 +176,7 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mi
  * slab in database order and a guide whose positions so far reach the limit is not scanned against the later slabs -- the
  * reference stops feeding an overflowed guide as well (crispr/ResultsAggregator.scala:61-69, LinearTraversal.scala:64-76).  The
  * retained hits, totals and aggregates are exactly those of ffh_scan for every ffh_finalize / ffh_shard_totals limit <= max_offtargets
- * (a larger one is refused); the raw hits collected per guide stay within a small multiple of the limit instead of growing with
+ * (a larger one makes the library redo the scan unbounded first: the guide set is still resident); the raw hits collected per guide stay within a small multiple of the limit instead of growing with
  * the size of the guide's repeat family.  3'-PAM enzymes only (database order must follow the compared bases); elsewhere, and
  * when bounding is switched off, it is ffh_scan.  ffh_discover scans this way when bounding is on.
  * ffh_set_bounding: 0 = never, 1 = always, -1 (default) = switch itself on for the context once a scan has collected more than

@@ -16,7 +16,9 @@
  * ONE change to the reference is needed: CRISPRSiteOT keeps maximumOffTargets as a constructor parameter (crispr/CRISPRSiteOT.scala:31,
  * `overflow: Int`), so it cannot be read back.  Add to that class:      val overflowValue: Int = overflow
  *
- * Not compiled in this repository (no JVM / scalac here); the call sequence is exercised by tests/test_jni_sequence.c.
+ * UNVERIFIED: never compiled or run (this repository's image has no JDK and no scalac).  What is tested is the call sequence
+ * below replayed as plain C against a database file and the oracle (tests/test_jni_sequence.c); treat this file and
+ * jni/flashfry_jni.c as the binding's specification until they have been built against a JDK.
  */
 package reference.traverser
 
@@ -43,8 +45,17 @@ object GPUTraverser extends Traverser with LazyLogging {
   @native private def resultFree(res: Long): Unit
   @native private def lastError(ctx: Long): String
 
-  /** guides per native call: keeps every returned Array[Long] far below the 2^31 elements a JVM array can hold */
-  val guidesPerCall = 200000
+  /** guides per native call, sized so that no returned Array[Long] can reach the 2^31 elements a JVM array holds: a guide keeps
+    * fewer than maxOffTargets + 32767 positions (the hit that crosses the limit is kept whole, BlockReader.scala:147-153 caps a
+    * target at 32767 positions) and never more hits than positions */
+  def guidesPerCall(maxOffTargets: Int): Int =
+    math.max(1L, math.min(200000L, (1L << 30) / (maxOffTargets.toLong + 32767L + 1L))).toInt
+
+  /** a native accessor returns null when the array would not fit a JVM array or could not be allocated */
+  private def need(a: Array[Long], what: String, ctx: Long): Array[Long] = {
+    if (a == null) throw new IllegalStateException("GPUTraverser: " + what + " could not be handed to the JVM (" + lastError(ctx) + ")")
+    a
+  }
 
   def scan(binaryFile: File,
            header: BinaryHeader,
@@ -67,14 +78,14 @@ object GPUTraverser extends Traverser with LazyLogging {
         // maximumOffTargets: the same for every guide of a run (OffTargetDiscovery.scala:100-102); needs CRISPRSiteOT.overflowValue
         val maxOffTargets = aggregator.wrappedGuides.head.otSite.overflowValue
 
-        guides.grouped(guidesPerCall).foreach { batch =>
+        guides.grouped(guidesPerCall(maxOffTargets)).foreach { batch =>
           val res = discover(ctx, batch.map(_.guide), maxMismatch, maxOffTargets)
           if (res == 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctx))
           try {
-            val off = resultOffsets(res)
-            val tg = resultTargets(res)
-            val po = resultPosOffsets(res)
-            val ps = resultPositions(res)
+            val off = need(resultOffsets(res), "guide offsets", ctx)
+            val tg = need(resultTargets(res), "hit targets", ctx)
+            val po = need(resultPosOffsets(res), "position offsets", ctx)
+            val ps = need(resultPositions(res), "positions", ctx)
             // replay in database order: exactly the updateOT sequence the CPU traversers produce.  The lists are already cut off by
             // the library (ordered cut-off, CRISPRSiteOT.scala:39-46), so updateOT's own `full` test never rejects a hit and the
             // overflow callback fires on the same hit it would have fired on

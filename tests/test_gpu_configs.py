@@ -117,8 +117,9 @@ def test_bounded_scan_on_a_uniform_database_changes_nothing(capi, oracle, chr22)
         gpu = ctx.discover(g, 4, 2000, jost=True)
         tm = ctx.timings()
         lim = ctx.discover(g[:200], 5, 30)
-        with pytest.raises(capi.FlashFryHipError, match="bounded by a smaller"):
-            ctx.finalize(31)
+        assert ctx.timings().bounded_slabs >= 3
+        more = ctx.finalize(31)                               # a larger limit than the scan was bounded by: rescanned unbounded, not refused
+        assert ctx.timings().bounded_slabs == 0
         ctx.scan(g[:200], 5)                                  # plain ffh_scan is never bounded: any limit may follow
         un = ctx.finalize(30)
     assert tm.bounded_slabs >= 3
@@ -126,6 +127,7 @@ def test_bounded_scan_on_a_uniform_database_changes_nothing(capi, oracle, chr22)
     assert_same_hits(gpu, ora)
     assert_same_scores(oracle, 3, g, gpu, ora, jost=True)
     assert_same_hits(lim, odb.discover(g[:200], 5, 30))
+    assert_same_hits(more, odb.discover(g[:200], 5, 31))
     assert lim.summaries.tobytes() == un.summaries.tobytes() and np.array_equal(lim.hit_targets, un.hit_targets)
 
 
