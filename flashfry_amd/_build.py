@@ -10,7 +10,7 @@ LIB = os.path.join(LIB_DIR, "libflashfry_hip.so")
 
 HIP_SOURCES = ["ffh_api.hip"]
 CXX_SOURCES = ["ffh_dbfile.cpp", "ffh_dbwrite.cpp"]
-DEPS = ["ffh_api.hip", "ffh_kernels.hpp", "ffh_compare.hpp", "ffh_prims.hpp", "ffh_dbfile.cpp", "ffh_dbfile.hpp", "ffh_dbwrite.cpp", "ffh_ingest.hpp", "ffh_index.hpp", "ffh_inflate.hpp", "ffh_bulge.hpp", "cfd_table.inc",
+DEPS = ["ffh_api.hip", "ffh_kernels.hpp", "ffh_compare.hpp", "ffh_prims.hpp", "ffh_dbfile.cpp", "ffh_dbfile.hpp", "ffh_dbwrite.cpp", "ffh_ingest.hpp", "ffh_index.hpp", "ffh_inflate.hpp", "ffh_bulge.hpp", "ffh_comm.hpp", "cfd_table.inc", "jost_table.inc",
         os.path.join("..", "..", "include", "flashfry_hip.h")]
 
 
@@ -34,9 +34,9 @@ def build_hip_library(force=False, verbose=False):
     if not force and not stale(LIB, deps):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-result", "-o", LIB]
+           "-Wall", "-Wno-unused-result", "-I/opt/rocm/include", "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES]
-    cmd += ["-lz", "-lpthread"]
+    cmd += ["-lz", "-lpthread", "-ldl"]   # (librccl is opened with dlopen when a communicator is created: ffh_comm.hpp)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

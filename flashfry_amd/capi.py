@@ -30,6 +30,9 @@ SYMBOLS = [
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
     "ffh_result_hit_targets", "ffh_result_hit_mismatches", "ffh_result_hit_cfd", "ffh_result_pos_offsets",
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
+    "ffh_comm_unique_id", "ffh_comm_create_rank", "ffh_comm_create_local", "ffh_comm_destroy", "ffh_comm_last_error", "ffh_comm_world",
+    "ffh_comm_first_shard", "ffh_comm_local_shards", "ffh_comm_transport", "ffh_discover_sharded", "ffh_comm_exchange", "ffh_comm_shard_lists",
+    "ffh_comm_device_summaries", "ffh_comm_timings",
 ]
 
 
@@ -175,6 +178,19 @@ def load_library(build=True):
         getattr(L, name).argtypes = [C.c_void_p]
     L.ffh_result_free.argtypes = [C.c_void_p]
     L.ffh_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    L.ffh_comm_unique_id.argtypes = [C.c_void_p]
+    L.ffh_comm_create_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.ffh_comm_create_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    L.ffh_comm_destroy.argtypes = [C.c_void_p]
+    L.ffh_comm_last_error.restype = C.c_char_p
+    L.ffh_comm_last_error.argtypes = [C.c_void_p]
+    for name in ("ffh_comm_world", "ffh_comm_first_shard", "ffh_comm_local_shards", "ffh_comm_transport"):
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.ffh_discover_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.c_void_p]
+    L.ffh_comm_exchange.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint, C.c_void_p]
+    L.ffh_comm_shard_lists.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.ffh_comm_device_summaries.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.ffh_comm_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -504,3 +520,111 @@ class Context:
         t = Timings()
         self._check(self.L.ffh_get_timings(self.h, C.byref(t)))
         return t
+
+
+TRANSPORTS = {0: "copy", 1: "rccl-all", 2: "rccl-rank"}
+
+
+def comm_unique_id():
+    """ffh_comm_unique_id: the 128 bytes one rank makes and every rank of ffh_comm_create_rank needs (ncclGetUniqueId)"""
+    L = load_library()
+    buf = (C.c_char * 128)()
+    rc = L.ffh_comm_unique_id(buf)
+    if rc:
+        raise FlashFryHipError(rc, L.ffh_comm_last_error(None).decode())
+    return bytes(buf)
+
+
+class Comm:
+    """ffh_comm: the bin-sharded discover with the collectives issued inside the library (RCCL, or device copies when the shards
+    share a GPU).  Comm.local(ctxs): one process drives all shards; Comm.rank(ctx, rank, world, id): one process per GPU."""
+
+    def __init__(self, L, h, ctxs):
+        self.L, self.h, self.ctxs = L, h, list(ctxs)   # (the contexts must outlive the communicator)
+
+    @classmethod
+    def local(cls, ctxs):
+        L = load_library()
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        out = C.c_void_p()
+        rc = L.ffh_comm_create_local(arr, len(ctxs), C.byref(out))
+        if rc:
+            raise FlashFryHipError(rc, L.ffh_comm_last_error(None).decode())
+        return cls(L, out.value, ctxs)
+
+    @classmethod
+    def rank(cls, ctx, rank, world, unique_id):
+        L = load_library()
+        assert len(unique_id) == 128
+        out = C.c_void_p()
+        rc = L.ffh_comm_create_rank(ctx.h, rank, world, C.c_char_p(unique_id), C.byref(out))
+        if rc:
+            raise FlashFryHipError(rc, L.ffh_comm_last_error(None).decode())
+        return cls(L, out.value, [ctx])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ffh_comm_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FlashFryHipError(rc, self.L.ffh_comm_last_error(self.h).decode())
+
+    @property
+    def world(self):
+        return self.L.ffh_comm_world(self.h)
+
+    @property
+    def first_shard(self):
+        return self.L.ffh_comm_first_shard(self.h)
+
+    @property
+    def transport(self):
+        return TRANSPORTS.get(self.L.ffh_comm_transport(self.h), "?")
+
+    def discover(self, guides, max_mismatch=4, max_offtargets=2000, jost=False, want_summaries=True):
+        """ffh_discover_sharded with host guides: returns the reduced summaries of all shards (numpy, SUMMARY_DTYPE) or None"""
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        return self._discover(g.ctypes.data, len(g), max_mismatch, max_offtargets, jost, want_summaries)
+
+    def discover_device(self, guides_ptr, n_guides, max_mismatch=4, max_offtargets=2000, jost=False, want_summaries=True, out=None):
+        return self._discover(guides_ptr, int(n_guides), max_mismatch, max_offtargets, jost, want_summaries, out)
+
+    def _discover(self, ptr, n, max_mismatch, max_offtargets, jost, want_summaries, out=None):
+        for c in self.ctxs:
+            c._n_guides = n
+        summ = None
+        if want_summaries:
+            summ = out if out is not None else np.zeros(n, dtype=SUMMARY_DTYPE)
+        self._check(self.L.ffh_discover_sharded(self.h, C.c_void_p(ptr), n, max_mismatch, max_offtargets, FINALIZE_JOST if jost else 0,
+                                                C.c_void_p(summ.ctypes.data) if summ is not None else None))
+        return summ
+
+    def exchange(self, n_guides, max_offtargets=2000, jost=False):
+        """ffh_comm_exchange: the exchange alone, after the caller scanned every local shard with the same guide set"""
+        summ = np.zeros(n_guides, dtype=SUMMARY_DTYPE)
+        self._check(self.L.ffh_comm_exchange(self.h, n_guides, max_offtargets, FINALIZE_JOST if jost else 0, C.c_void_p(summ.ctypes.data)))
+        return summ
+
+    def shard_lists(self, local_shard, positions=True, hit_scores=True, jost=False):
+        out = C.c_void_p()
+        self._check(self.L.ffh_comm_shard_lists(self.h, local_shard, Context._finalize_flags(False, jost, positions, hit_scores), C.byref(out)))
+        return Result(self.L, out.value, lists=True, positions=positions, hit_scores=hit_scores)
+
+    def timings(self):
+        a, b = C.c_double(), C.c_double()
+        self._check(self.L.ffh_comm_timings(self.h, C.byref(a), C.byref(b)))
+        return {"scan_ms": a.value, "exchange_ms": b.value}

@@ -76,7 +76,9 @@ struct Image {  // one bucketed scan image of the database
     DevBuf<uint32_t> bstart;  // 4^width + 1: first target of every bucket
     DevBuf<uint32_t> gstart;  // 4^width + 1: first group of every bucket
     DevBuf<uint32_t> gwords;  // the bucket's targets in bit-sliced groups of 32 (ffh_compare.hpp), padded by kKW + 64 words
-    DevBuf<uint32_t> tidx;    // database index of every slot (32 per group)
+    DevBuf<uint32_t> tidx;    // database index of every slot (32 per group); not kept by a direct image
+    bool direct = false;      // direct image (k_bucket_first): database index of a slot = slot + ddelta[bucket], ddelta = gstart + nb + 1
+    uint32_t *ddelta() const { return gstart.p + ((size_t)1 << (2 * width)) + 1; }
     int rest = 0;             // bases in the rest key (the ones the bucket id does not hold)
     DevBuf<uint32_t> range;   // {first, last} non-empty bucket
 };
@@ -95,6 +97,12 @@ struct PinnedPool {
     std::mutex m;
     std::vector<std::pair<void *, size_t>> free_blocks;
     void *get(size_t bytes, size_t &cap) {
+        // FFH_PINNED_LIMIT_MB: the most page-locked host memory ONE result block may take (page-locked memory is a resource the host
+        // shares with everything else on the node); a result that needs more fails with FFH_E_NOMEM instead of pinning it
+        if (const char *lim = std::getenv("FFH_PINNED_LIMIT_MB")) {
+            const long long mb = std::atoll(lim);
+            if (mb > 0 && bytes > (size_t)mb << 20) return nullptr;
+        }
         {
             std::lock_guard<std::mutex> g(m);
             for (size_t i = 0; i < free_blocks.size(); ++i)
@@ -180,6 +188,7 @@ struct ffh_ctx {
 
     // database
     uint64_t T = 0, P = 0;
+    bool db_sorted = false;   // targets are in sequence order (every database the reference writes is)
     DevBuf<uint64_t> targets, positions, pos_off;
     Image img[2];  // 0 prefix, 1 suffix
     Image alt[2];  // a second pair of images with another split (select_images: 11 + 9 suits 4 mismatches at hg38 scale, 10 + 10 suits 5)
@@ -245,6 +254,7 @@ struct ffh_ctx {
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 };
 
+static uint32_t S_nb_plus_1(int width) { return (1u << (2 * width)) + 1u; }
 static unsigned blocks_for(uint64_t n, unsigned threads) { return (unsigned)std::max<uint64_t>(1, (n + threads - 1) / threads); }
 
 // ---- ball sizes and patterns -----------------------------------------------------------------------------
@@ -329,12 +339,18 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
     if (max_groups * 32 >= (1ull << 31) - 64) { ctx->err = "too many target slots in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
     DevBuf<uint32_t> &keys = ctx->tmp_keys, &tidx_in = ctx->tmp_tidx;   // the counting sort's output, bit-sliced below (shared by the two images:
                                                                          // allocating and freeing GB-sized buffers costs tens of ms each)
+    // a prefix image over a 3'-PAM database in sequence order keeps its buckets in database order: no slot -> index array (k_bucket_first)
+    static const bool allow_direct = !(getenv("FFH_NO_DIRECT") && atoi(getenv("FFH_NO_DIRECT")) == 1);
+    im.direct = allow_direct && which == 0 && ctx->geo.c0 != 0 && ctx->db_sorted;
     FFH_HIP(im.bstart.reserve((size_t)nb + 1));
-    FFH_HIP(im.gstart.reserve((size_t)nb + 1));
-    FFH_HIP(keys.reserve(t_n + 1));
-    FFH_HIP(tidx_in.reserve(t_n + 1));
+    FFH_HIP(im.gstart.reserve(2 * ((size_t)nb + 1)));   // (+ ddelta behind it)
     FFH_HIP(im.gwords.reserve((size_t)max_groups * GW + kKW + 64));
-    FFH_HIP(im.tidx.reserve((size_t)max_groups * 32 + 64));
+    if (im.direct) im.tidx.release();
+    else {
+        FFH_HIP(keys.reserve(t_n + 1));
+        FFH_HIP(tidx_in.reserve(t_n + 1));
+        FFH_HIP(im.tidx.reserve((size_t)max_groups * 32 + 64));
+    }
     FFH_HIP(ctx->icount.reserve((size_t)nb + 1));
     FFH_HIP(ctx->ifill.reserve((size_t)nb + 1));
     FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
@@ -347,7 +363,8 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
         else hipLaunchKernelGGL(k_image_hist<true>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, ctx->icount.p);
     }
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.bstart.p, ctx->scan_tmp32.p, ctx->st);
-    if (t_n) {
+    if (t_n && im.direct) hipLaunchKernelGGL(k_bucket_first, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, ctx->ifill.p);
+    if (t_n && !im.direct) {
         if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
         else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
     }
@@ -360,7 +377,10 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
     }
     hipLaunchKernelGGL(k_group_count, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, ctx->icount.p);
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.gstart.p, ctx->scan_tmp32.p, ctx->st);
-    hipLaunchKernelGGL(k_group_build, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, keys.p, tidx_in.p, nb, R, GW, im.gwords.p, im.tidx.p);
+    if (im.direct)   // (ifill holds the buckets' first database indices; a slab never builds a prefix image, so t_lo is 0 here)
+        hipLaunchKernelGGL(k_group_build_direct, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, (const uint32_t *)ctx->ifill.p, tg, ctx->geo, width,
+                           nb, R, GW, im.gwords.p, im.ddelta());
+    else hipLaunchKernelGGL(k_group_build, dim3(blocks_for(nb, 4)), dim3(256), 0, ctx->st, im.bstart.p, im.gstart.p, keys.p, tidx_in.p, nb, R, GW, im.gwords.p, im.tidx.p);
     FFH_HIP(hipGetLastError());
     return FFH_OK;
 }
@@ -376,15 +396,18 @@ static int prepare_database(ffh_ctx *ctx) {
     FFH_HIP(ctx->out_cnt.reserve(ctx->T + 1));
     FFH_HIP(ctx->pos_off.reserve(ctx->T + 1));
     FFH_HIP(ctx->scan_tmp64.reserve(scan_scratch_elems_safe(ctx->T)));
-    uint32_t *bad = (uint32_t *)ctx->d_counters + 8;
-    FFH_HIP(hipMemsetAsync(bad, 0, 4, ctx->st));
-    if (ctx->T) hipLaunchKernelGGL(k_check_counts, dim3(blocks_for(ctx->T, 256)), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T, ctx->out_cnt.p, bad);
+    uint32_t *bad = (uint32_t *)ctx->d_counters + 16;   // two words: bad counts, neighbours out of sequence order
+    FFH_HIP(hipMemsetAsync(bad, 0, 8, ctx->st));
+    if (ctx->T) hipLaunchKernelGGL(k_check_counts, dim3(blocks_for(ctx->T, 256)), dim3(256), 0, ctx->st, ctx->targets.p, ctx->T,
+                                  (1ull << (2 * ctx->geo.scan_len)) - 1ull, ctx->out_cnt.p, bad);
     exclusive_scan<uint32_t, uint64_t>(ctx->out_cnt.p, ctx->T, ctx->pos_off.p, ctx->scan_tmp64.p, ctx->st);
-    uint32_t hbad = 0;
+    uint32_t hbad2[2] = {0, 0};
     uint64_t total = 0;
-    FFH_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->st));
+    FFH_HIP(hipMemcpyAsync(hbad2, bad, 8, hipMemcpyDeviceToHost, ctx->st));
     FFH_HIP(hipMemcpyAsync(&total, ctx->pos_off.p + ctx->T, 8, hipMemcpyDeviceToHost, ctx->st));
     FFH_HIP(hipStreamSynchronize(ctx->st));
+    const uint32_t hbad = hbad2[0];
+    ctx->db_sorted = hbad2[1] == 0;
     if (hbad) { ctx->err = "Encoded position count should be greater than zero (and fit a signed short)"; return FFH_E_FORMAT; }
     if (total != ctx->P) { ctx->err = "positions array length does not equal the sum of the target counts"; return FFH_E_FORMAT; }
     // bucket widths: ~48 targets per prefix bucket, both keys <= 12 bases
@@ -977,7 +1000,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // strip take the kernel's piecewise path.
     auto side_plan = [&](int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S) -> int {
         S = SideArgs{};
-        S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.tidx.p; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
+        S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.direct ? nullptr : im.tidx.p; S.dd_off = im.direct ? S_nb_plus_1(width) : 0u; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
         S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
         const double cap_g = std::floor((double)kKW / group_words(im.rest));
         const double avg_t = (double)n_targets / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
@@ -1037,7 +1060,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
             ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
             ca.gmap = act_map ? act_map + g0 : nullptr;
-            hipLaunchKernelGGL(k_compare<0>, dim3(ctx->compare_grid), dim3(kCmpThreads), 0, st, ca, ctx->d_counters);
+            launch_compare(ca, ctx->d_counters, ctx->compare_grid, st);
             FFH_HIP(hipGetLastError());
             FFH_HIP(hipEventRecord(ctx->ev[4], st));
             unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
@@ -1706,6 +1729,7 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
             const int a = ctx->img[0].width, sfx = ctx->img[1].width;
             for (int kind = 0; kind < (max_bulge ? 3 : 1); ++kind) {
                 const Image &im = ctx->img[kind == 0 ? 0 : 1];
+                if (im.direct) { ctx->err = "internal: direct image in a bulge search"; return FFH_E_STATE; }   // (Cpf1 has a 5' PAM: never direct)
                 const int w = kind == 0 ? a : sfx;
                 if (kind == 2 && w == 0) continue;  // one suffix bucket: seed D already visits it
                 std::vector<uint32_t> pat;
@@ -1941,3 +1965,8 @@ int ffh_exchange_unpack(ffh_ctx *ctx, void *d_summaries, uint32_t n, const doubl
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// the bin-sharded discover with the collectives inside the library (RCCL; ffh_comm.hpp)
+// =====================================================================================================================
+#include "ffh_comm.hpp"

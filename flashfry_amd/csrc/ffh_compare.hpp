@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ffh_prims.hpp"
 
 namespace ffh {
@@ -49,6 +51,12 @@ namespace ffh {
 #ifndef FFH_GPL
 #define FFH_GPL 6
 #endif
+#ifndef FFH_ODD_PER
+#define FFH_ODD_PER 1
+#endif
+#ifndef FFH_PIPE_TRIPS
+#define FFH_PIPE_TRIPS 2   // 16-byte pieces of a group's words requested one group ahead (0: none; more cost registers)
+#endif
 constexpr int kCmpThreads = 256;           // four waves, each with its own LDS strip: no block-level synchronisation in the kernel
 constexpr int kCmpWaves = kCmpThreads / 64;
 constexpr int kKW = FFH_KW;                // group words parked per wave (4 KB: 51 groups of 20 words, 42 of 24)
@@ -58,7 +66,7 @@ constexpr int kMaxNB = 15;                 // buckets per batch: lanes 0..15 (on
 constexpr int kKeyRegs = kKW / 256;        // 16-byte loads per lane and batch
 constexpr int kGidRegs = kKC / 64;
 constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is split into jobs of about this many groups
-constexpr int kMaxParts = 16;
+constexpr int kMaxParts = 16;             // jobs per candidate at most (park: fewer when a piece has many candidates)
 constexpr int kMinRest = 7, kMaxRest = 12;   // rest-key widths k_compare has a row form for (19-mers with a 12-base bucket key: 7)
 
 constexpr uint32_t kStatPairs = 4, kStatEntries = 6;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
@@ -68,7 +76,9 @@ __host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 +
 struct SideArgs {
     const uint32_t *gstart;   // [nb + 1] first group of every bucket
     const uint32_t *gwords;   // [groups * GW + kKW + 64] bit-sliced groups (padded: a batch is fetched in whole 16-byte pieces)
-    const uint32_t *tidx;     // [groups * 32] database index of every slot (looked up when a hit leaves the wave)
+    const uint32_t *tidx;     // [groups * 32] database index of every slot (looked up when a hit leaves the wave); null for a direct image
+    uint32_t dd_off;          // direct image (k_bucket_first): gstart[dd_off + b] = ddelta[b], database index of a slot = slot + ddelta[bucket]
+                              // (the table sits behind gstart in one allocation: one base address for both loads); else 0
     const uint32_t *istart;   // [nb + 1] first candidate of every bucket (absolute index into gids)
     const uint2 *gtab;        // [guides of this batch] {rest key H << 16 | L, bucket id} of every guide on this side
     uint32_t nb;              // buckets
@@ -199,7 +209,11 @@ struct HitStage {
             if (dst < cap) {
                 const uint64_t h = my[i];
                 const uint32_t lo = (uint32_t)h, slot = lo & 0x7FFFFFFFu;
-                const uint32_t ti = (lo >> 31) ? tidx_s[slot] : tidx_p[slot];
+                // (a direct image's records already hold the database index: no lookup, no 128-byte line per hit)
+                const bool sfx = (lo >> 31) != 0u;
+                uint32_t ti = slot;
+                if (sfx && tidx_s) ti = tidx_s[slot];
+                if (!sfx && tidx_p) ti = tidx_p[slot];
                 const uint32_t g = gmap ? gmap[(uint32_t)(h >> 32)] : (uint32_t)(h >> 32) + guide_base;
                 hits[dst] = ((uint64_t)g << tbits) | ti;
             }
@@ -234,11 +248,30 @@ struct RowCtx {
 
 // One row: 64 jobs, one per lane -- one candidate guide against `trips` consecutive groups of its bucket.
 //   rest: the guide's rest key (H << 16 | L), d: its mismatches inside the bucket key, gid: its id; strip: the wave's parked group
-//   words; gword: strip word of the lane's first group; gabs: absolute index of that group (for the hit's slot)
-template <int R>
-__device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t gabs,
+//   words; gword: strip word of the lane's first group; sbase: slot number of that group's first target (a direct image: its
+//   database index)
+//   FAR: what is known at compile time about the suffix image's extra condition "more than r1 mismatches in the rest key":
+//   0 none (prefix image), 1 .. 4 count >= FAR as one or two v_bitop3 on the count's bit planes, -1 taken from c.r_far at run time
+//   EARLY: 16-byte pieces of a group's words requested one group ahead (registers: the any-width instance cannot afford them)
+template <int R, int FAR, int EARLY>
+__device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t sbase,
                                          const uint32_t *strip) {
     constexpr int GW = group_words(R);
+    lds_c4 *gp = (lds_c4 *)(strip + gword);            // per lane, 16-byte aligned (GW is a multiple of 4)
+    uint32_t w[GW];
+    // the group's words come in GW / 4 16-byte LDS reads; the first kEarly of them are requested one group ahead (below)
+    constexpr int kEarly = EARLY < GW / 4 ? EARLY : GW / 4;
+    auto fetch = [&](auto from, auto to) {
+#pragma unroll
+        for (int q = decltype(from)::value; q < decltype(to)::value; ++q) {
+            const u32x4 v = gp[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IE = std::integral_constant<int, kEarly>;
+    using IN = std::integral_constant<int, GW / 4>;
+    fetch(I0{}, IE{});                                 // the first group is requested before the masks are set up
     // the guide's plane bits as masks, its mismatch budget inside this bucket as threshold masks
     uint32_t GH[R], GL[R];
 #pragma unroll
@@ -252,17 +285,17 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
     const uint32_t t0 = 0u - (tcl & 1u), t1 = 0u - ((tcl >> 1) & 1u), t2 = 0u - ((tcl >> 2) & 1u), t3 = 0u - ((tcl >> 3) & 1u);
     const uint32_t far = (uint32_t)(c.r_far + 1);      // suffix image: at least this many rest mismatches (0: no condition)
     const uint32_t f0 = 0u - (far & 1u), f1 = 0u - ((far >> 1) & 1u), f2 = 0u - ((far >> 2) & 1u), f3 = 0u - ((far >> 3) & 1u);
-    lds_c4 *gp = (lds_c4 *)(strip + gword);            // per lane, 16-byte aligned (GW is a multiple of 4)
-    for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < trips); ++t, gp += GW / 4) {
-        uint32_t w[GW];
-#pragma unroll
-        for (int q = 0; q < GW / 4; ++q) {
-            const u32x4 v = gp[q];
-            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-        }
+    for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < trips); ++t) {
+        fetch(IE{}, IN{});
         uint32_t m[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) m[i] = BITOP3(w[2 * i + 1], GL[i], w[2 * i] ^ GH[i], 0xBE);   // (L ^ GL) | (H ^ GH): base i differs
+        const uint32_t valid = w[2 * R];
+        gp += GW / 4;
+        // The first words of the NEXT group are requested here: w[] is dead from this point on, so their LDS round trip runs under the
+        // adder tree and the hit handling of this group, and the rest of the group is requested while they are being used.  (After its
+        // last group a lane reads the group behind it -- a neighbour's, or the strip's padding -- and drops it.)
+        fetch(I0{}, IE{});
         uint32_t c0, c1, c2, c3;
         count_planes<R>(m, c0, c1, c2, c3);
         // count <= thr, bit-serially from the low end: e_k = "the low k + 1 bits of count <= those of thr"
@@ -270,18 +303,24 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
         e = BITOP3(c1, t1, e, 0x8E);                    // (~c & t) | (~(c ^ t) & e)
         e = BITOP3(c2, t2, e, 0x8E);
         e = BITOP3(c3, t3, e, 0x8E);
-        uint32_t hit = e & w[2 * R];                    // & valid
-        if (c.r_far >= 0) {                             // uniform: count >= far, the same way
-            uint32_t g = BITOP3(c0, f0, f0, 0xF3);      // c0 | ~f0
-            g = BITOP3(c1, f1, g, 0xB2);                // (c & ~f) | (~(c ^ f) & g)
-            g = BITOP3(c2, f2, g, 0xB2);
-            g = BITOP3(c3, f3, g, 0xB2);
-            hit &= g;
+        uint32_t hit = e & valid;
+        if constexpr (FAR == 1) hit = BITOP3(BITOP3(c0, c1, c2, 0xFE), c3, hit, 0xA8);         // count >= 1: (c0 | c1 | c2 | c3) & hit
+        else if constexpr (FAR == 2) hit &= BITOP3(c1, c2, c3, 0xFE);                          // count >= 2: c1 | c2 | c3
+        else if constexpr (FAR == 3) hit = BITOP3(BITOP3(c0, c1, c2, 0xEA), c3, hit, 0xA8);    // count >= 3: ((c0 & c1) | c2 | c3) & hit
+        else if constexpr (FAR == 4) hit = BITOP3(c2, c3, hit, 0xA8);                          // count >= 4: (c2 | c3) & hit
+        else if constexpr (FAR < 0) {
+            if (c.r_far >= 0) {                         // uniform: count >= far, bit-serially like the threshold
+                uint32_t g = BITOP3(c0, f0, f0, 0xF3);  // c0 | ~f0
+                g = BITOP3(c1, f1, g, 0xB2);            // (c & ~f) | (~(c ^ f) & g)
+                g = BITOP3(c2, f2, g, 0xB2);
+                g = BITOP3(c3, f3, g, 0xB2);
+                hit &= g;
+            }
         }
         if (t >= trips) hit = 0;                        // a lane that is done (its reads ran into a neighbour's groups)
         const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit != 0u);
         if (lanes) {   // rare: the lanes with a non-zero mask stage one record per set bit (almost always one)
-            const uint32_t slot0 = ((gabs + t) << 5) | c.side_bit;
+            const uint32_t slot0 = (sbase + (t << 5)) | c.side_bit;
             uint64_t more = lanes;
             do {
                 c.hs->push(more, hit != 0u, gid, slot0 + (uint32_t)__ffs((int)hit) - 1u);
@@ -333,20 +372,24 @@ __global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, ui
     for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(b0, nbv, gs + k * split, min(ge, gs + (k + 1) * split));
 }
 
-template <int UNUSED>
+// job -> bucket lookup of a parked piece: kMaxRows words of 64 marker bits, one bit per non-empty bucket at the job before its first
+constexpr int kMaxRows = 16;               // rows (of 64 jobs) of one parked piece at most: park() caps the jobs of a piece at 1024
+
+// R0 / R1: the rest widths of the prefix / suffix image this instance is compiled for (the row form is then fixed and the kernel's
+// registers are those of max(R0, R1) instead of the widest form); 0 = any width, chosen per row.  FAR1: r1 + 1 of the suffix image
+// when the instance is compiled for it (scan_row), -1 = read from the arguments.  The host picks the instance (launch_compare).
+template <int R0, int R1, int FAR1>
 __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(const CompareArgs A, unsigned long long *__restrict__ cursor) {
     __shared__ __attribute__((aligned(16))) uint32_t strip_lds[kCmpWaves][kKW + 64];
     __shared__ __attribute__((aligned(16))) uint2 cand_lds[kCmpWaves][kKC];
     __shared__ uint32_t gid_lds[kCmpWaves][kKC];
     __shared__ __attribute__((aligned(16))) uint4 tab_lds[kCmpWaves][2][16];
     __shared__ uint64_t stage[kCmpWaves][kStage];
-    __shared__ uint32_t inv_lds[kMaxParts + 1];    // ceil(65536 / P): x / P == (x * inv) >> 16 for x < 4096, P <= 16
+    __shared__ uint64_t mark_lds[kCmpWaves][kMaxRows];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kCmpWaves;
     const uint32_t *__restrict__ gids = A.gids;
-    if (threadIdx.x >= 1 && threadIdx.x <= kMaxParts) inv_lds[threadIdx.x] = (65536u + threadIdx.x - 1u) / threadIdx.x;
-    __syncthreads();
     HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor, 0ull, 0u, 0ull};
     RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
 
@@ -356,16 +399,20 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     // The suffix image's work entries come first (they are the heavier ones), then the prefix image's; inside a side the wave takes the
     // entries q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
     // describes it stays in scalar registers.
-    for (int side = 1; side >= 0; --side) {
+    auto run_side = [&](auto side_tag) {
+        constexpr int side = decltype(side_tag)::value;
+        constexpr int RC = side ? R1 : R0;             // compiled rest width of this side (0: any)
+        constexpr int FARC = side ? FAR1 : 0;          // the prefix image has no far condition
         const SideArgs S = A.side[side];
-        if (!S.n_list) continue;
+        if (!S.n_list) return;
         const uint32_t n_total = *S.n_list;
         uint32_t q = blockIdx.x * kCmpWaves + wave;
-        if (q >= n_total) continue;
+        if (q >= n_total) return;
         const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ gwords = S.gwords;
         const uint32_t *__restrict__ list = reinterpret_cast<const uint32_t *>(S.list);
         const uint2 *__restrict__ gtab = S.gtab;
-        const uint32_t GW = (uint32_t)group_words((int)S.rest);
+        const uint32_t dd_off = S.dd_off;
+        const uint32_t GW = RC ? (uint32_t)group_words(RC) : (uint32_t)group_words((int)S.rest);
         rc.r_far = S.r_far;
         rc.side_bit = (uint32_t)side << 31;
         rc.width = S.width;
@@ -376,12 +423,13 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             dE = 0;
             if (qq < n_total && lane < 4) dE = list[(size_t)qq * 4 + lane];
         };
-        // bucket boundaries of the entry: lane l <= nbv holds gstart / istart of bucket b0 + l
+        // bucket boundaries of the entry: lane l <= nbv holds gstart / istart of bucket b0 + l; on a direct image lane 16 + l holds
+        // ddelta of that bucket in dG (the second DPP row of the same register: no register of its own in the pipeline)
         auto load_desc = [&](uint32_t qq, uint32_t dE, uint32_t &dG, uint32_t &dI) {
             dG = 0; dI = 0;
             if (qq < n_total) {
-                const uint32_t idx = lane_of(dE, 0) + min(lane, lane_of(dE, 1));
-                dG = gstart[idx];
+                const uint32_t idx = lane_of(dE, 0) + min(lane & 15u, lane_of(dE, 1));
+                dG = gstart[idx + ((lane & 48u) == 16u ? dd_off : 0u)];
                 dI = istart[idx];
             }
         };
@@ -438,39 +486,89 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                     gid_lds[wave][(uint32_t)j * 64u + lane] = greg[j];
                 }
             }
+            if (lane < (uint32_t)kMaxRows) mark_lds[wave][lane] = 0ull;
             // bucket i: its groups and candidates clipped to the piece; P jobs per candidate
             const uint32_t nG = row_next(dG), nI = row_next(dI);
             const uint32_t lo_g = min(max(dG, g0), g1), hi_g = min(max(nG, g0), g1);
             const uint32_t lo_c = min(max(dI, c0), c1), hi_c = min(max(nI, c0), c1);
             const bool act = lane < e.nbv;
             const uint32_t ngr = act ? hi_g - lo_g : 0u, ng = (act && ngr) ? hi_c - lo_c : 0u;
-            uint32_t P = (ngr + (uint32_t)kGroupsPerLane / 2u) / (uint32_t)kGroupsPerLane;   // ~ ngr / 6, rounded
-            P = min(max(P, 1u), (uint32_t)kMaxParts);
-            const uint32_t per = ngr ? (ngr + P - 1u) / P : 0u;                                // (small integer divisions, once per batch)
+            // Jobs per candidate: P parts of `per` groups each.  At most kMaxParts, and few enough that the piece stays within kMaxRows
+            // rows of jobs.  (Divisions by a per-lane P <= 16 of numbers < 4096 go through v_rcp_f32: the quotients' fractional parts
+            // are multiples of 1/P >= 1/16, far above the reciprocal's error, so a small bias makes floor / ceil exact; the integer
+            // division the compiler emits instead costs ~30 instructions, and there were three per batch.)
+            const uint32_t ncand = c1 - c0, pmax = ncand <= 64u ? 16u : ncand <= 128u ? 8u : 4u;
+            auto ceil_div = [](uint32_t a, uint32_t b) { return (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b) + 0.99f); };   // a < 4096, 1 <= b <= 16
+            uint32_t P, per;
+            if (e.nbv == 1u) {
+                // One bucket in the piece (the suffix image, a large prefix bucket): lanes 0..15 price P = lane + 1 -- rows of 64 jobs
+                // x groups per job -- and the cheapest wins.  (~ngr / 6 regardless of the candidates left every second piece of the
+                // suffix image with a second row of two jobs that ran as long as the full one.)
+                const uint32_t ngr0 = lane_of(ngr, 0), ng0 = lane_of(ng, 0);
+                uint32_t Pc = min((lane & 15u) + 1u, pmax), perc = ngr0 ? ceil_div(ngr0, Pc) : 0u;
+#if FFH_ODD_PER
+                if (Pc > 1u) perc |= 1u;     // (an odd number of groups per part keeps the parts out of each other's LDS banks: below)
+#endif
+                Pc = perc ? ceil_div(ngr0, perc) : 1u;
+                const uint32_t rows_c = (ng0 * Pc + 63u) >> 6;
+                uint32_t best = ((rows_c * perc) << 16) | (rows_c << 8) | Pc;    // fewest row-steps, then fewest rows, then fewest parts
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x141, 0xf, 0xf, false));   // row_half_mirror
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x140, 0xf, 0xf, false));   // row_mirror
+                P = lane_of(best, 0) & 0xFFu;
+                per = ngr ? ceil_div(ngr, P) : 0u;
+#if FFH_ODD_PER
+                if (P > 1u) per |= 1u;
+#endif
+            } else {
+                P = (ngr + (uint32_t)kGroupsPerLane / 2u) / (uint32_t)kGroupsPerLane;   // ~ ngr / 6, rounded
+                P = min(max(P, 1u), pmax);
+                per = ngr ? ceil_div(ngr, P) : 0u;
+#if FFH_ODD_PER
+                // The parts of one candidate are read by neighbouring lanes at the same time, `per` groups apart: with GW = 24 words per
+                // group and an even `per` the parts p and p + 4 (per = 6: 144 p words) start in the same LDS bank with different
+                // addresses -- a two-way conflict on every read of the row.  An odd number of groups per part spreads the parts.
+                if (P > 1u) { per |= 1u; P = ceil_div(ngr, per); }
+#endif
+            }
             const uint32_t jobs = ng * P;
             uint32_t incl = jobs;   // inclusive scan over the row of 16 lanes
             incl += row_prev<1>(incl);
             incl += row_prev<2>(incl);
             incl += row_prev<4>(incl);
             incl += row_prev<8>(incl);
-            if (lane < 16) {
-                tab_lds[wave][0][lane] = make_uint4(incl - jobs, lo_c - c0, ng, P);
-                tab_lds[wave][1][lane] = make_uint4((lo_g - g0) * GW, ngr, per, lo_g);
+            // first slot of the bucket's part of the piece; a direct image: the database index of that slot
+            const uint32_t dd = dd_off ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 16u) << 2), (int)dG) : 0u;
+            // The tables hold the buckets that have jobs, in order; a job finds its bucket by counting the buckets that begin at or
+            // before it: one marker bit per such bucket at the job BEFORE its first (the first bucket's jobs begin at 0 and need
+            // none), so that "markers below my lane" + "markers of the rows before" is the table index (rows()).
+            const bool ne = lane < 16u && jobs != 0u;
+            const uint32_t slot = __builtin_amdgcn_mbcnt_lo((uint32_t)__builtin_amdgcn_ballot_w64(ne), 0u);
+            const uint32_t js = incl - jobs;
+            wave_lds_fence();   // (the markers are cleared)
+            if (ne) {
+                const uint32_t inv = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)P) + 0.999f);                 // ceil(65536 / P)
+                tab_lds[wave][0][slot] = make_uint4(js, lo_c - c0, e.b0 + lane, P | (inv << 8));   // x / P == (x * inv) >> 16 for x < 4096, P <= 16
+                tab_lds[wave][1][slot] = make_uint4((lo_g - g0) * GW, ngr, per, (lo_g << 5) + dd);
+                if (js) atomicOr((unsigned long long *)&mark_lds[wave][(js - 1u) >> 6], 1ull << ((js - 1u) & 63u));
             }
             wave_lds_fence();
             return lane_of(incl, 15);
         };
 
         // every row of the parked piece's jobs
-        auto rows = [&](const Extent &e, uint32_t n_jobs) {
-            const uint32_t js = lane < 16 ? tab_lds[wave][0][lane].x : 0xFFFFFFFFu;   // first job of bucket `lane`
+        auto rows = [&](uint32_t n_jobs) {
+            uint32_t before = 0;   // buckets begun in the rows before this one
             for (uint32_t j0 = 0; j0 < n_jobs; j0 += 64) {
                 const uint32_t J = j0 + lane;
-                uint32_t i = 0;
-                for (uint32_t k = 1; k < e.nbv; ++k) i += (J >= lane_of(js, k)) ? 1u : 0u;   // the bucket of job J
+                const uint64_t M = mark_lds[wave][j0 >> 6];
+                const uint32_t mlo = (uint32_t)M, mhi = (uint32_t)(M >> 32);
+                const uint32_t i = before + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // the bucket of job J
+                before += (uint32_t)__popc(uni(mlo)) + (uint32_t)__popc(uni(mhi));
                 const uint4 ta = tab_lds[wave][0][i], tb = tab_lds[wave][1][i];
-                const uint32_t jj = J - ta.x, P = ta.w;
-                const uint32_t k = (jj * inv_lds[P]) >> 16, p = jj - k * P;                   // candidate k of the bucket, part p of it
+                const uint32_t jj = J - ta.x, P = ta.w & 31u;
+                const uint32_t k = (jj * (ta.w >> 8)) >> 16, p = jj - k * P;                   // candidate k of the bucket, part p of it
                 const bool valid = J < n_jobs;
                 const uint32_t slot = min(ta.y + k, (uint32_t)kKC - 1u);
                 const uint2 cand = cand_lds[wave][slot];
@@ -478,18 +576,20 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                 const uint32_t g_lo = p * tb.z;
                 uint32_t trips = 0;
                 if (valid && g_lo < tb.y) trips = min(tb.z, tb.y - g_lo);
-                const uint32_t x = cand.y ^ (e.b0 + i);
+                const uint32_t x = cand.y ^ ta.z;
                 const uint32_t d = (uint32_t)__popc(((x >> rc.width) | x) & ((1u << rc.width) - 1u));   // mismatches inside the bucket key
-                const uint32_t gword = tb.x + g_lo * GW, gabs = tb.w + g_lo;
-                switch (S.rest) {   // uniform; kMinRest .. kMaxRest, checked by the host when the images are built
-                    case 7: scan_row<7>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    case 8: scan_row<8>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    case 9: scan_row<9>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    case 10: scan_row<10>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    case 11: scan_row<11>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    case 12: scan_row<12>(rc, cand.x, d, gid, trips, gword, gabs, strip_lds[wave]); break;
-                    default: __builtin_trap();   // an image this kernel has no row form for: never a silently wrong hit set
-                }
+                const uint32_t gword = tb.x + g_lo * GW, sbase = tb.w + (g_lo << 5);
+                if constexpr (RC != 0) scan_row<RC, FARC, FFH_PIPE_TRIPS>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]);
+                else
+                    switch (S.rest) {   // uniform; kMinRest .. kMaxRest, checked by the host when the images are built
+                        case 7: scan_row<7, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        case 8: scan_row<8, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        case 9: scan_row<9, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        case 10: scan_row<10, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        case 11: scan_row<11, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        case 12: scan_row<12, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
+                        default: __builtin_trap();   // an image this kernel has no row form for: never a silently wrong hit set
+                    }
             }
         };
 
@@ -535,7 +635,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                         load_gids(c0, c1, greg_a);
                         load_entries(c0, c1, greg_a, ereg);
                         const uint32_t nj = park(e, t0, t1, c0, c1, kreg, greg_a, ereg, dG0, dI0);
-                        rows(e, nj);
+                        rows(nj);
                     }
                 }
             }
@@ -551,12 +651,32 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             load_entries(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_a, ereg);
             load_groups(e1.g0, min(e1.g1, e1.g0 + cap_g), kreg);
             // ---- compute this batch out of LDS ----
-            if (n_jobs) rows(e, n_jobs);
+            if (n_jobs) rows(n_jobs);
             dE0 = dE1; dE1 = dE2; dE2 = dE3; dE3 = dE4;
             dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
         }
-    }
+    };
+    run_side(std::integral_constant<int, 1>{});
+    run_side(std::integral_constant<int, 0>{});
     hs.finish();
+}
+
+// The instances: one per plan the cost model picks at genome scale for a 20-base pack (choose_plan / select_images: 11 + 9 with radii
+// 2 + 1 for <= 4 mismatches, 10 + 10 with 1 + 1 and 2 + 2 for <= 3 and <= 5), and the any-width one for everything else.
+template <int R0, int R1, int FAR1>
+inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_compare<R0, R1, FAR1>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+}
+inline void launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
+    static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;
+    const bool two = ca.side[1].n_list != nullptr;
+    const int r0 = (int)ca.side[0].rest, r1 = two ? (int)ca.side[1].rest : 0, far = two ? ca.side[1].r_far + 1 : 0;
+    if (!generic_only && two) {
+        if (r0 == 9 && r1 == 11 && far == 3) return launch_compare_as<9, 11, 3>(ca, cursor, grid, st);
+        if (r0 == 10 && r1 == 10 && far == 2) return launch_compare_as<10, 10, 2>(ca, cursor, grid, st);
+        if (r0 == 10 && r1 == 10 && far == 3) return launch_compare_as<10, 10, 3>(ca, cursor, grid, st);
+    }
+    launch_compare_as<0, 0, -1>(ca, cursor, grid, st);
 }
 
 }  // namespace ffh

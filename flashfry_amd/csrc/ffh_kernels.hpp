@@ -64,12 +64,18 @@ __host__ __device__ __forceinline__ uint32_t suffix_bucket(uint64_t pk, int s) {
 // ---------------------------------------------------------------------------------------------------------
 // database residency: SoA -> bucketed scan image (counting sort by bucket id)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_check_counts(const uint64_t *__restrict__ targets, uint64_t n, uint32_t *__restrict__ counts, uint32_t *__restrict__ bad) {
+// bad[0]: counts the reference would refuse; bad[1]: neighbours that are not in sequence order (a database the reference writes is:
+// BinWriter / BlockReader sort every bin, the bins are written in prefix order; ffh_db_load_soa takes what it is given)
+__global__ void k_check_counts(const uint64_t *__restrict__ targets, uint64_t n, uint64_t seq_mask /* the 2 x scan length sequence bits */,
+                               uint32_t *__restrict__ counts, uint32_t *__restrict__ bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = (uint32_t)(targets[i] >> 48);
+    const uint64_t t = targets[i];
+    const uint32_t c = (uint32_t)(t >> 48);
     counts[i] = c;
     if (c == 0 || c > 32767) atomicAdd(bad, 1u);  // getCount is a signed short and must be > 0 (BlockManager.scala:232-234)
+    // (bits above the sequence -- some synthetic packs carry them -- would lead a plain comparison and hide an unordered sequence)
+    if (i && ((targets[i - 1] & seq_mask) > (t & seq_mask) || ((targets[i - 1] ^ t) & 0xFFFFFFFFFFFFull & ~seq_mask))) atomicAdd(bad + 1, 1u);
 }
 
 template <bool SUFFIX>
@@ -92,6 +98,46 @@ __global__ void k_image_scatter(const uint64_t *__restrict__ targets, uint64_t n
     const uint32_t pos = bstart[b] + atomicAdd(&bfill[b], 1u);
     keys[pos] = SUFFIX ? suffix_rest_key(pk, width) : prefix_rest_key(pk, geo.lc, width);   // the bucket holds the other bases
     tidx[pos] = base + (uint32_t)i;
+}
+
+// DIRECT prefix image.  In a database in sequence order whose compared bases lead the sequence (every 3'-PAM pack: the PAM sits in the
+// low bits) the targets of a prefix bucket are CONSECUTIVE in the database.  The image then keeps them in database order inside the
+// bucket, and the database index of a slot is slot + ddelta[bucket] -- arithmetic on a 4^a-entry table the compare kernel fetches
+// with the bucket boundaries -- instead of a 4-byte-per-slot array gathered once per hit (a 128-byte line each: 60 % of the hits of a
+// <= 4-mismatch scan come from this image).  first[b] = database index of bucket b's first target.
+__global__ void k_bucket_first(const uint64_t *__restrict__ targets, uint64_t n, Geometry geo, int width, uint32_t *__restrict__ first) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = prefix_bucket(planar_key(targets[i], geo.c0, geo.lc), geo.lc, width);
+    if (i == 0 || prefix_bucket(planar_key(targets[i - 1], geo.c0, geo.lc), geo.lc, width) != b) first[b] = (uint32_t)i;
+}
+// one wave per bucket: bit-slices the bucket's targets straight from the database (no counting sort in between) and leaves
+// ddelta[b] = first[b] - 32 * gstart[b], so that slot s of the image is target s + ddelta[b]
+__global__ __launch_bounds__(256) void k_group_build_direct(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ first,
+                                                            const uint64_t *__restrict__ targets, Geometry geo, int width, uint32_t nb, uint32_t R, uint32_t GW,
+                                                            uint32_t *__restrict__ gwords, uint32_t *__restrict__ ddelta) {
+    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const uint32_t nt = bstart[b + 1] - bstart[b], g0 = gstart[b], ngr = gstart[b + 1] - g0;
+    const uint32_t k0 = nt ? first[b] : 0u;
+    if (lane == 0) ddelta[b] = k0 - 32u * g0;
+    for (uint32_t c = 0; 2 * c < ngr; ++c) {
+        const uint32_t k = c * 64 + lane;
+        const bool valid = k < nt;
+        const uint32_t key = valid ? prefix_rest_key(planar_key(targets[k0 + k], geo.c0, geo.lc), geo.lc, width) : 0u;
+        uint64_t mine = 0;
+        for (uint32_t i = 0; i < R; ++i) {
+            const uint64_t h = __ballot((key >> (16 + i)) & 1u), l = __ballot((key >> i) & 1u);
+            if (lane == 2 * i) mine = h;
+            if (lane == 2 * i + 1) mine = l;
+        }
+        const uint64_t v = __ballot(valid);
+        if (lane == 2 * R) mine = v;
+        if (lane < GW) {
+            gwords[(size_t)(g0 + 2 * c) * GW + lane] = (uint32_t)mine;
+            if (2 * c + 1 < ngr) gwords[(size_t)(g0 + 2 * c + 1) * GW + lane] = (uint32_t)(mine >> 32);
+        }
+    }
 }
 
 // The image the compare kernel reads: the targets of a bucket in GROUPS of 32, bit-sliced (ffh_compare.hpp).  A group is GW words:

@@ -164,6 +164,7 @@ struct ScanStats {
     double createMs = 0, loadMs = 0, scanMs = 0, finalizeMs = 0, deliverMs = 0;
     ffh_load_stats load{};  // stages of loadMs on the first shard
     int gpus = 1;
+    int transport = 0;      // ffh_comm_transport of the shards' exchange: 0 copies (shards share a device), 1 RCCL
 };
 class GpuTraverser {
 public:

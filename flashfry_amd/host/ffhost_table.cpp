@@ -302,9 +302,10 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     }
     std::vector<ffh_ctx *> ctx(nd, nullptr);
     std::vector<std::string> errs(nd);
-    std::vector<std::vector<uint32_t>> totals(nd, std::vector<uint32_t>(ng, 0));
     std::vector<ffh_result *> res(nd, nullptr);
-    auto cleanup = [&]() { for (auto r : res) if (r) ffh_result_free(r); for (auto c : ctx) if (c) ffh_destroy(c); };
+    ffh_comm *comm = nullptr;   // the shards' exchange runs inside the library (RCCL over xGMI between distinct devices; ffh_comm_*)
+    std::vector<ffh_guide_summary> reduced(ng);
+    auto cleanup = [&]() { for (auto r : res) if (r) ffh_result_free(r); if (comm) ffh_comm_destroy(comm); for (auto c : ctx) if (c) ffh_destroy(c); };
     auto parallel = [&](const std::function<void(size_t)> &fn) {
         std::vector<std::thread> th;
         for (size_t d = 1; d < nd; ++d) th.emplace_back(fn, d);
@@ -323,20 +324,18 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     });
     auto t1 = clk::now();
     ffh_db_load_stats(ctx[0], &st.load);
-    parallel([&](size_t d) {
-        // bounded by maximumOffTargets: a guide that reaches it inside a shard is not scanned against the rest of that shard (the
-        // reference stops feeding such a guide too, ResultsAggregator.scala:61-69); a no-op until a guide set makes bounding switch on
-        if (ffh_scan_bounded(ctx[d], longs.data(), (uint32_t)ng, maxMismatch, std::max(maximumOffTargets, 0))) { errs[d] = abiError(ctx[d]); return; }
-        if (ffh_shard_totals(ctx[d], totals[d].data(), (uint32_t)std::max(maximumOffTargets, 0))) errs[d] = abiError(ctx[d]);
-    });
+    // ONE library call: every shard scans all guides (bounded by maximumOffTargets: a guide that reaches it inside a shard is not
+    // scanned against the rest of that shard, as the reference stops feeding such a guide, ResultsAggregator.scala:61-69), then the
+    // shards exchange their per-guide totals (ordered cut-off across shards) and aggregates -- the collectives are the library's
+    const int maxOT = std::max(maximumOffTargets, 0);
+    if (ffh_comm_create_local(ctx.data(), (int)nd, &comm)) { const std::string e = ffh_comm_last_error(nullptr); cleanup(); throw Error(e); }
+    if (ffh_discover_sharded(comm, longs.data(), (uint32_t)ng, maxMismatch, maxOT, 0u, reduced.data())) { const std::string e = ffh_comm_last_error(comm); cleanup(); throw Error(e); }
+    st.transport = ffh_comm_transport(comm);
     auto t2 = clk::now();
-    // ordered cut-off across shards: shard d starts from the (saturated) totals of the shards before it
-    std::vector<std::vector<uint32_t>> prior(nd, std::vector<uint32_t>(ng, 0));
-    for (size_t d = 1; d < nd; ++d)
-        for (size_t g = 0; g < ng; ++g) prior[d][g] = (uint32_t)std::min<uint64_t>((uint64_t)prior[d - 1][g] + totals[d - 1][g], (uint64_t)std::max(maximumOffTargets, 0));
     parallel([&](size_t d) {
-        // without --positionOutput the table prints sequence_count_mismatches only: the position arrays stay on the device
-        if (ffh_finalize(ctx[d], d ? prior[d].data() : nullptr, maximumOffTargets, FFH_FINALIZE_NO_HIT_SCORES | (wantPositions ? 0u : FFH_FINALIZE_NO_POSITIONS), &res[d])) errs[d] = abiError(ctx[d]);
+        // every shard's retained hits under the cut-off continued from the shards before it; without --positionOutput the table
+        // prints sequence_count_mismatches only and the position arrays stay on the device
+        if (ffh_comm_shard_lists(comm, (int)d, FFH_FINALIZE_NO_HIT_SCORES | (wantPositions ? 0u : FFH_FINALIZE_NO_POSITIONS), &res[d])) errs[d] = ffh_comm_last_error(comm);
     });
     auto t3 = clk::now();
     // deliver the hits in database order = shard order (what aggregator.updateOT would have received)
@@ -344,14 +343,11 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     for (size_t g = g0; g < g1; ++g) {
         CRISPRSiteOT &ot = guides[g];
         ot.overflow = maximumOffTargets;
-        ffh_guide_summary sum{};
-        sum.closest = 0xFFFFFFFFu;
         size_t nHits = 0;
         for (size_t d = 0; d < nd; ++d) nHits += (size_t)(ffh_result_guide_offsets(res[d])[g + 1] - ffh_result_guide_offsets(res[d])[g]);
         ot.offTargets.reserve(nHits);
         for (size_t d = 0; d < nd; ++d) {
             const ffh_result *r = res[d];
-            const ffh_guide_summary &s = ffh_result_summaries(r)[g];
             const uint64_t *go = ffh_result_guide_offsets(r), *ht = ffh_result_hit_targets(r), *pp = ffh_result_positions(r);
             const uint64_t *po = wantPositions ? ffh_result_pos_offsets(r) : nullptr;
             // discover attaches no per-hit scores (they come from `score`, which calls ffh_score_lists): FFH_FINALIZE_NO_HIT_SCORES
@@ -364,14 +360,8 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
                 ot.currentTotal += (long)hit.nCoordinates;
                 ot.offTargets.push_back(std::move(hit));
             }
-            sum.n_hits += s.n_hits; sum.ot_count += s.ot_count; sum.overflow |= s.overflow;
-            for (int k = 0; k < 5; ++k) sum.hist[k] += s.hist[k];
-            if (s.closest < sum.closest) { sum.closest = s.closest; sum.closest_count = s.closest_count; }
-            else if (s.closest == sum.closest && s.closest != 0xFFFFFFFFu) sum.closest_count += s.closest_count;
-            sum.in_genome += s.in_genome; sum.n_scored += s.n_scored;
-            sum.cfd_max = std::max(sum.cfd_max, s.cfd_max); sum.cfd_sum += s.cfd_sum; sum.hsu_sum += s.hsu_sum;   // shard order = database order
-            sum.jost_max = std::max(sum.jost_max, s.jost_max); sum.jost_sum += s.jost_sum;
         }
+        const ffh_guide_summary &sum = reduced[g];   // reduced over the shards by the library (f64 sums added in shard = database order)
         ot.summary = sum;
     }
     });

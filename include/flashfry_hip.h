@@ -269,6 +269,49 @@ int ffh_exchange_prior(ffh_ctx *ctx, const uint32_t *device_all_totals /* [world
 int ffh_finalize_shard_fixup(ffh_ctx *ctx, int max_offtargets, unsigned flags, const uint32_t *device_prior, const uint32_t *device_totals,
                              void *device_summaries);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The bin-sharded discover as ONE library call (BASELINE.json configs[3]): every shard scans all
+ * guides, then the shards exchange (1) their per-guide position totals (all-gather) so that the ordered cut-off of
+ * CRISPRSiteOT.addOT / full (crispr/CRISPRSiteOT.scala:39-46) continues across shards in database order and (2) the
+ * per-guide aggregates (all-reduce MAX, all-reduce SUM, all-gather of the f64 sums, added in shard order).  The collectives
+ * are issued BY THE LIBRARY on the contexts' streams -- RCCL over xGMI (librccl is opened on first use) -- so a JVM host
+ * (GPUTraverser) or the C++ CLI gets the reduce without any framework above the C ABI.  Replaces, for N GPUs, the one
+ * traverser chosen in modules/OffTargetDiscovery.scala:119-135.
+ *   ffh_comm_create_rank   one process per GPU: `ctx` holds shard `rank` of `world`; id128 = the 128 bytes ffh_comm_unique_id
+ *                          produced on one rank, distributed by the caller (MPI, torch.distributed, a file) -> ncclCommInitRank
+ *   ffh_comm_create_local  one process drives all shards: ctxs[i] holds shard i (database order).  Distinct devices ->
+ *                          ncclCommInitAll + grouped collectives; several shards on one device (a rehearsal of an N-way run on
+ *                          one GPU: RCCL refuses duplicate devices) -> device-to-device copies and local reduction kernels.
+ *                          FFH_COMM=copy in the environment forces the latter.
+ * The contexts stay the caller's (destroy the communicator first).  Errors: ffh_comm_last_error (NULL: of a failed create).
+ * ------------------------------------------------------------------------------------------------------- */
+struct ffh_guide_summary;
+typedef struct ffh_comm ffh_comm;
+int ffh_comm_unique_id(void *id128);
+int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, ffh_comm **out);
+int ffh_comm_create_local(ffh_ctx *const *ctxs, int n_shards, ffh_comm **out);
+void ffh_comm_destroy(ffh_comm *comm);
+const char *ffh_comm_last_error(const ffh_comm *comm);
+int ffh_comm_world(const ffh_comm *comm);          /* shards in total */
+int ffh_comm_first_shard(const ffh_comm *comm);    /* number of this process's first shard */
+int ffh_comm_local_shards(const ffh_comm *comm);   /* shards held by this process */
+int ffh_comm_transport(const ffh_comm *comm);      /* 0 copies (shards share a device), 1 RCCL ncclCommInitAll, 2 RCCL ncclCommInitRank */
+/* ffh_scan_bounded on every local shard (one host thread each) + the exchange; the reduced per-guide aggregates of ALL shards
+ * land in summaries_out[n_guides] (host memory; may be NULL on ranks that do not want them).  `guides`: host or device memory
+ * (device: of every local shard's GPU, i.e. one local shard).  flags: FFH_FINALIZE_JOST. */
+int ffh_discover_sharded(ffh_comm *comm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags,
+                         struct ffh_guide_summary *summaries_out);
+/* the exchange alone, after the caller scanned every local shard itself with the same guide set */
+int ffh_comm_exchange(ffh_comm *comm, uint32_t n_guides, int max_offtargets, unsigned flags, struct ffh_guide_summary *summaries_out);
+/* after ffh_discover_sharded: the retained hit list of a local shard under the cut-off continued from the shards before it
+ * (ffh_finalize with the prior the exchange left on the device); concatenated in shard order the lists are the reference's.
+ * flags: FFH_FINALIZE_NO_POSITIONS / _NO_HIT_SCORES / _JOST */
+int ffh_comm_shard_lists(ffh_comm *comm, int local_shard, unsigned flags, ffh_result **out);
+/* the reduced aggregates as they sit on a local shard's device (n_guides x ffh_guide_summary), valid until the next exchange */
+int ffh_comm_device_summaries(ffh_comm *comm, int local_shard, const void **device_summaries);
+/* host wall time of the last ffh_discover_sharded: the scans (slowest local shard), the exchange incl. the copy-out */
+int ffh_comm_timings(const ffh_comm *comm, double *scan_ms, double *exchange_ms);
+
 /* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
  * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the
  * lists are taken as they are (no cut-off, overflow = 0).  No database needs to be loaded.  The result carries
@@ -310,6 +353,8 @@ const uint64_t *ffh_result_pos_offsets(const ffh_result *r);             /* [n_h
                                                                             folded from that on the host the first time they are asked for */
 const uint64_t *ffh_result_positions(const ffh_result *r);               /* [n_positions] BitPosition longs */
 void ffh_result_free(ffh_result *r);
+/* Result arrays live in page-locked host memory (pooled per context).  FFH_PINNED_LIMIT_MB in the environment caps what ONE result
+ * block may take; a discover whose lists need more returns FFH_E_NOMEM ("out of (pinned) host memory") and leaves the context usable. */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Instrumentation of the last ffh_scan/ffh_finalize on this context (HIP events on the context's stream).

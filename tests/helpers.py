@@ -13,6 +13,33 @@ def make_case(oracle, n_targets, n_guides, enzyme=3, seed=0, max_linear=500, pla
     return odb, targets, positions, synth.as_u64(g)
 
 
+SCAN_LEN = {1: 24, 2: 23, 3: 23, 4: 23, 5: 22, 6: 22}   # StandardScanParameters.scala:90-215
+
+
+def make_enzyme_case(oracle, enzyme, n_targets, n_guides, seed=0, max_mut=5):
+    """a database of random sites of ANY of the six packs in the reference's database order (3' PAM: by sequence; Cpf1: bin = the 7
+    bases after the 5' PAM, then sequence) with counts 1..3, and guides that are mutated database members (0 .. max_mut - 1
+    substitutions anywhere in the site), so that hits exist at every level.  Returns (oracle db, targets, positions, guides)."""
+    rng = np.random.default_rng(1000 * enzyme + seed)
+    L = SCAN_LEN[enzyme]
+    raw = np.unique(rng.integers(0, 1 << (2 * L), size=n_targets, dtype=np.uint64))
+    counts = rng.integers(1, 4, size=len(raw)).astype(np.uint64)
+    targets = raw | (counts << np.uint64(48))
+    if enzyme == 1:
+        binkey = (raw >> np.uint64(2 * (24 - 11))) & np.uint64(0x3FFF)
+        order = np.lexsort((raw, binkey))
+        targets, raw = targets[order], raw[order]
+    n_pos = int((targets >> np.uint64(48)).sum())
+    positions = rng.integers(0, 1 << 27, size=n_pos, dtype=np.uint64) | (np.uint64(L) << np.uint64(52)) | (np.uint64(1) << np.uint64(32))
+    odb = oracle.db_from_sorted(enzyme, targets, positions, contigs=["c1"])
+    guides = raw[rng.integers(0, len(raw), size=n_guides)].copy()
+    for k in range(len(guides)):
+        for _ in range(int(rng.integers(0, max_mut))):
+            guides[k] ^= np.uint64(int(rng.integers(1, 4)) << (2 * int(rng.integers(0, L))))
+    guides |= np.uint64(1) << np.uint64(48)
+    return odb, targets, positions, guides
+
+
 def assert_same_hits(gpu, ora, targets=None):
     """bit-identical hit sets: same retained targets per guide in the same (database) order, same positions,
     same totals and overflow flags"""

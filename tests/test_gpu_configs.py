@@ -78,30 +78,38 @@ def test_config_c1_one_guide_vs_chr22_scale(capi, oracle, chr22):
 
 
 def test_randomised_parity_slice(capi, oracle):
-    """tools/stress_parity.py for a bounded time: seeds x database sizes x guide counts x 0-6 mismatches x cut-offs"""
+    """tools/stress_parity.py for a bounded time: seeds x database sizes x guide counts x 0-6 mismatches x cut-offs x ALL SIX
+    packs (every third case walks through the enzymes 1 .. 6 in turn)"""
     from tests.test_gpu_parity import dense_case
+    from tests.helpers import make_enzyme_case
     rng = np.random.default_rng(20260928)
-    t0, n = time.time(), 0
-    while time.time() - t0 < 60.0:
+    t0, n, seen = time.time(), 0, set()
+    while time.time() - t0 < 60.0 or len(seen) < 6:
         seed = int(rng.integers(0, 1 << 30))
         max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
         max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
-        if int(rng.integers(0, 2)) == 0:
+        enz = 3
+        kind = n % 3
+        if kind == 2:
+            enz = (n // 3) % 6 + 1
+            odb, t, p, g = make_enzyme_case(oracle, enz, int(rng.integers(500, 200000)), int(rng.integers(1, 300)), seed=seed)
+        elif kind == 0:
             odb, t, p, g = make_case(oracle, int(rng.integers(100, 400000)), int(rng.integers(1, 600)), enzyme=3, seed=seed)
         else:
             ng = int(rng.integers(10, 500))
             odb, t, p, g = dense_case(oracle, n_random=int(rng.integers(1000, 120000)), n_guides=ng,
                                       n_dense=int(rng.integers(1, min(60, ng))), variants=int(rng.integers(10, 200)), seed=seed)
-        with capi.Context(3) as ctx:
+        with capi.Context(enz) as ctx:
             ctx.load_soa(t, p)
             gpu = ctx.discover(g, max_mm, max_ot, jost=True)
             only = ctx.finalize(max_ot, summaries_only=True, jost=True)
             assert only.summaries.tobytes() == gpu.summaries.tobytes()
         ora = odb.discover(g, max_mm, max_ot)
         assert_same_hits(gpu, ora)
-        assert_same_scores(oracle, 3, g, gpu, ora)
+        assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
+        seen.add(enz)
         n += 1
-    assert n >= 20, "the slice should get through a few dozen cases in a minute (%d)" % n
+    assert n >= 20 and seen == {1, 2, 3, 4, 5, 6}, "the slice should get through a few dozen cases in a minute (%d, enzymes %s)" % (n, sorted(seen))
 
 
 _RAW_UNBOUNDED = {}   # raw hits of the unbounded runs of the repeat-genome test (the parametrisation runs bounding 0 first)

@@ -146,3 +146,60 @@ def test_five_and_three_mismatches_take_the_10_10_images_and_four_the_11_9_ones(
             mm = torch_mismatches(torch, int(g[k].astype(np.int64)), db["targets"])
             idx = torch.nonzero(mm <= max_mm).flatten()
             assert np.array_equal(res.hits(k), db["targets"][idx].cpu().numpy().view(np.uint64)), (max_mm, k)
+
+
+def test_c4_eight_bin_shards_through_the_library_exchange_equal_the_unsharded_discover(world):
+    """Config C4 of BASELINE.json at its stated shape on the one GPU of the test box: the SAME 3.0e8-target database split into EIGHT
+    contiguous bin shards balanced by payload (dist.shard_bins, the role of BinaryHeader.uncompressedSize, BinaryHeader.scala:54),
+    eight contexts, ONE ffh_discover_sharded (scan of every shard + totals all-gather + prior + fix-up + the three reductions; the
+    copy transport, since RCCL refuses eight ranks on one device).  maximumOffTargets is set so low that for most guides the
+    ordered cut-off (CRISPRSiteOT.scala:39-46) is reached only after the running total has crossed several shard boundaries.  The
+    reduced aggregates and the concatenated per-shard hit lists must be the unsharded discover's."""
+    torch, capi, ctx, db = world["torch"], world["capi"], world["ctx"], world["db"]
+    from flashfry_amd import dist as ffdist
+    guides = world["guides"]
+    W, max_ot = 8, 60
+    T = db["T"]
+    bins = (db["targets"] >> 32) & 0x3FFF                               # 7-base bin = bits 45:32 of a Cas9 23-mer
+    per_bin_t = torch.bincount(bins, minlength=16384)
+    first = torch.cumsum(per_bin_t, 0) - per_bin_t
+    bin_pos = db["pos_offsets"][torch.clamp(first + per_bin_t, max=T)] - db["pos_offsets"][torch.clamp(first, max=T)]
+    payload = ((per_bin_t + bin_pos) * 8).cpu().numpy()
+    cuts = ffdist.shard_bins(payload, W)
+    assert all(b1 > b0 for b0, b1 in cuts)
+    whole = ctx.discover(guides, 4, max_ot, jost=True, positions=False, hit_scores=False)
+    ctxs = []
+    try:
+        for b0, b1 in cuts:
+            lo = int(first[b0]) if b0 < 16384 else T
+            hi = int(first[b1]) if b1 < 16384 else T
+            plo, phi = int(db["pos_offsets"][lo]), int(db["pos_offsets"][hi])
+            c = capi.Context(3)
+            c.load_soa_device(db["targets"][lo:hi].data_ptr(), hi - lo, db["positions"][plo:phi].data_ptr(), phi - plo)
+            ctxs.append(c)
+        assert sum(c.info().n_targets for c in ctxs) == T
+        with capi.Comm.local(ctxs) as comm:
+            assert comm.world == W and comm.transport == "copy"
+            summ = comm.discover(guides, 4, max_ot, jost=True)
+            lists = [comm.shard_lists(i, positions=False, hit_scores=False) for i in range(W)]
+    finally:
+        for c in ctxs:
+            c.close()
+    s = whole.summaries
+    ints = ("n_hits", "ot_count", "overflow", "hist", "closest", "closest_count", "in_genome", "n_scored")
+    h0, h1 = hashlib.sha256(), hashlib.sha256()
+    for f in ints + ("cfd_max", "jost_max"):
+        assert np.array_equal(s[f], summ[f]), f
+        h0.update(np.ascontiguousarray(s[f]).tobytes()); h1.update(np.ascontiguousarray(summ[f]).tobytes())
+    assert h0.hexdigest() == h1.hexdigest()
+    for f in ("cfd_sum", "hsu_sum", "jost_sum"):      # added shard by shard: equal up to the association of the additions
+        assert np.abs(s[f] - summ[f]).max() <= 1e-9 * max(1.0, float(np.abs(s[f]).max())), f
+    counts = np.stack([np.diff(l.guide_offsets.astype(np.int64)) for l in lists])       # [shard][guide] retained hits
+    assert np.array_equal(counts.sum(0), np.diff(whole.guide_offsets.astype(np.int64)))
+    for g in range(0, G, 97):
+        assert np.array_equal(np.concatenate([l.hits(g) for l in lists]), whole.hits(g)), g
+    # the cut-off really was decided across shards: overflowed guides whose retained hits span at least four shards (three boundaries)
+    over = s["overflow"].astype(bool)
+    spans = (counts > 0).sum(0)
+    assert over.sum() > G // 2 and int((over & (spans >= 4)).sum()) > 1000, (int(over.sum()), int((over & (spans >= 4)).sum()))
+    assert int((~over).sum()) > 0                                               # ... and guides that never reached it

@@ -777,3 +777,89 @@ def test_cas12a_seeded_bulge_search_equals_brute_force_at_scale(capi, n_random, 
     for name in ("guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position"):
         assert np.array_equal(getattr(res, name), getattr(bf, name)), name
     assert len(res.hit_targets) >= 400 and {0, 1, 2} <= set(res.hit_bulge_type.tolist())
+
+
+@pytest.mark.parametrize("enzyme,prefix", [(5, 12), (5, 7), (6, 12), (6, 9)])
+def test_19mer_packs_with_forced_splits_down_to_a_7_base_rest_key(capi, oracle, enzyme, prefix):
+    """a 19-base pack with a 12-base bucket key leaves a 7-base rest key on the other image (group_words(7) = 16 words per
+    group); the compare kernel has a row form for every rest width 7 .. 12 and the host refuses an image outside that range.  A
+    database of clean 22-base sites in sequence order also makes the prefix image a DIRECT one (no slot -> index array)."""
+    from tests.helpers import make_enzyme_case
+    odb, t, p, g = make_enzyme_case(oracle, enzyme, 120000, 200, seed=3)
+    with capi.Context(enzyme) as ctx:
+        ctx.set_plan(prefix, 1)
+        ctx.load_soa(t, p)
+        info = ctx.info()
+        assert (info.prefix_bases, info.suffix_bases) == (prefix, 19 - prefix)
+        gpu = ctx.discover(g, 3, 2000, jost=True)
+        gpu4 = ctx.discover(g[:50], 4, 40)
+    ora = odb.discover(g, 3, 2000)
+    assert_same_hits(gpu, ora)
+    assert gpu.n_hits >= 50
+    assert_same_scores(oracle, enzyme, g, gpu, ora, jost=True)
+    assert_same_hits(gpu4, odb.discover(g[:50], 4, 40))
+
+
+def test_direct_prefix_image_equals_the_indexed_one(capi, oracle, monkeypatch):
+    """a 3'-PAM database in sequence order keeps its prefix buckets in database order and drops the slot -> index array
+    (k_bucket_first); FFH_NO_DIRECT=1 builds the round-2 image with the array.  Same hits either way, and a database that is NOT in
+    sequence order (ffh_db_load_soa takes what it is given) silently gets the indexed image."""
+    odb, t, p, g = make_case(oracle, 100000, 300, enzyme=3, seed=9)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        a = ctx.discover(g, 4, 60, jost=True)
+    assert_same_hits(a, odb.discover(g, 4, 60))
+    monkeypatch.setenv("FFH_NO_DIRECT", "1")      # (read once per process: a no-op if another test built an image before; kept for A/B runs)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        b = ctx.discover(g, 4, 60, jost=True)
+    monkeypatch.delenv("FFH_NO_DIRECT")
+    assert a.summaries.tobytes() == b.summaries.tobytes() and np.array_equal(a.hit_targets, b.hit_targets)
+    perm = np.random.default_rng(1).permutation(len(t))
+    cnt = (t >> np.uint64(48)).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    p2 = np.concatenate([p[off[i]:off[i + 1]] for i in perm])
+    with capi.Context(3) as ctx:                                  # shuffled database order: hits per guide in THAT order
+        ctx.load_soa(t[perm], p2)
+        sh = ctx.discover(g, 4, 2 ** 31 - 1)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        full = ctx.discover(g, 4, 2 ** 31 - 1)
+    order = {int(v): i for i, v in enumerate(t[perm])}
+    for k in range(len(g)):
+        assert sorted(sh.hits(k).tolist()) == sorted(full.hits(k).tolist()), k
+        idx = [order[int(v)] for v in sh.hits(k)]
+        assert idx == sorted(idx)
+
+
+def test_error_paths_added_since_round_1(capi, oracle, monkeypatch):
+    """(1) a scan that would collect 2^32 raw hits or more is refused, not wrapped; (2) a result whose page-locked block would exceed
+    FFH_PINNED_LIMIT_MB fails with FFH_E_NOMEM and leaves the context usable; (3) image widths the compare kernel has no row form
+    for are refused when the database is made resident"""
+    rng = np.random.default_rng(77)
+    raw = np.unique(rng.integers(0, 1 << 40, size=4_400_000, dtype=np.uint64))
+    t = (raw << np.uint64(6)) | np.uint64(0b101010) | (np.uint64(1) << np.uint64(48))
+    p = np.arange(len(t), dtype=np.uint64)
+    g = (rng.integers(0, 1 << 40, size=1024, dtype=np.uint64) << np.uint64(6)) | np.uint64(0b101010) | (np.uint64(1) << np.uint64(48))
+    assert len(t) * len(g) >= 2 ** 32
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        with pytest.raises(capi.FlashFryHipError, match="2\\^32 raw hits") as e:
+            ctx.discover(g, 20, 2000, summaries_only=True)            # maxMismatch >= the guide length: every pair is a hit
+        assert e.value.code == -1
+        ok = ctx.discover(g[:16], 3, 2000)                            # the context survives the refusal
+        monkeypatch.setenv("FFH_PINNED_LIMIT_MB", "1")
+        with pytest.raises(capi.FlashFryHipError, match="pinned") as e:
+            ctx.discover(g[:256], 9, 2 ** 31 - 1)                     # ~4e6 hits: a result block of tens of MB
+        assert e.value.code == -6
+        monkeypatch.delenv("FFH_PINNED_LIMIT_MB")
+        again = ctx.discover(g[:16], 3, 2000)
+        assert again.summaries.tobytes() == ok.summaries.tobytes()
+    odb, t2, p2, g2 = make_case(oracle, 5000, 10, enzyme=3, seed=1)
+    with capi.Context(3) as ctx:
+        with pytest.raises(capi.FlashFryHipError, match="prefix_bases"):
+            ctx.set_plan(13, 1)
+        ctx.set_plan(6, 1)                                             # clamped to the supported range when the images are built
+        ctx.load_soa(t2, p2)
+        assert ctx.info().prefix_bases == 8 and ctx.info().suffix_bases == 12
+        assert_same_hits(ctx.discover(g2, 4, 2000), odb.discover(g2, 4, 2000))

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from flashfry_amd import capi
 import oracle_lib
-from helpers import make_case, assert_same_hits, assert_same_scores
+from helpers import make_case, make_enzyme_case, assert_same_hits, assert_same_scores
 from test_gpu_parity import dense_case
 
 oracle = oracle_lib.load()
@@ -18,7 +18,8 @@ rng = np.random.default_rng(12345)
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     seed = int(rng.integers(0, 1 << 30))
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
+    enz = 3
     max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
     max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
     if kind == 0:
@@ -30,11 +31,13 @@ while time.time() - t0 < budget:
         t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
         odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
         max_mm = min(max_mm, 5)
+    elif kind == 3:   # any of the six packs (Cpf1's 5' PAM and bin order, NAG, the 19-mers with their 7 .. 12-base rest keys)
+        enz = int(rng.integers(1, 7))
+        odb, t, p, g = make_enzyme_case(oracle, enz, int(rng.integers(500, 300000)), int(rng.integers(1, 400)), seed=seed)
     else:
         ng = int(rng.integers(10, 500))
         odb, t, p, g = dense_case(oracle, n_random=int(rng.integers(1000, 120000)), n_guides=ng,
                                   n_dense=int(rng.integers(1, min(60, ng))), variants=int(rng.integers(10, 200)), seed=seed)
-    enz = 3
     bounding = int(rng.choice([-1, 0, 1, 1]))     # ffh_scan_bounded engages for databases of >= 65536 targets
     pos, sc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     with capi.Context(enz) as ctx:
@@ -53,7 +56,7 @@ while time.time() - t0 < budget:
             assert lean.hit_cfd.tobytes() == gpu.hit_cfd.tobytes()
     ora = odb.discover(g, max_mm, max_ot)
     assert_same_hits(gpu, ora)
-    assert_same_scores(oracle, enz, g, gpu, ora)
+    assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
     n += 1
     print("ok %3d kind %d enzyme %d T %7d G %4d mm %d max_ot %4d hits %8d bounding %2d slabs %d overflow %d" % (n, kind, enz, len(t), len(g), max_mm, max_ot, gpu.n_hits, bounding, slabs,
                                                                                                                   int(gpu.summaries["overflow"].sum())), flush=True)
