@@ -449,7 +449,20 @@ def main():
         del a, b
         torch.cuda.empty_cache()
 
-    exch = ffdist.DeviceExchange(G, dev) if sharded else None
+    # The sharded step: by default ONE library call per step (ffh_discover_sharded: scan + totals all-gather + prior + fix-up + the
+    # three reductions, the collectives issued by the library itself through RCCL on its own stream; torch.distributed only carries
+    # the 128-byte unique id once).  FFH_BENCH_EXCHANGE=torch keeps the round-2 form (library kernels + torch.distributed
+    # collectives on torch's stream) -- also what the gloo rehearsal of several ranks on ONE GPU has to use (RCCL refuses duplicate
+    # devices).
+    exchange_kind = os.environ.get("FFH_BENCH_EXCHANGE", "torch" if os.environ.get("FFH_BENCH_SAME_GPU") == "1" else "native") if sharded else None
+    exch, comm, reduced = None, None, None
+    if sharded and exchange_kind == "native":
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = capi.Comm.rank(ctx, rank, world if world > 1 else 1, uid[0])
+        reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
+    elif sharded:
+        exch = ffdist.DeviceExchange(G, dev)
 
     class _Reduced:  # the sharded step's result: the reduced per-guide aggregates, on rank 0
         summaries = None
@@ -464,12 +477,15 @@ def main():
             if host_guides:
                 return ctx.discover(guides_np, args.max_mismatch, args.max_offtargets, summaries_only=True)  # ffh_discover = ffh_scan + ffh_finalize
             return ctx.discover_device(gptr, G_dev, args.max_mismatch, args.max_offtargets, summaries_only=True)
+        res = _Reduced()
+        if comm is not None:   # scan + exchange inside the library; rank 0 takes the reduced aggregates to the host like the single-GPU step does
+            comm.discover_device(gptr, G_dev, args.max_mismatch, args.max_offtargets, want_summaries=(rank == 0), out=reduced)
+            res.summaries = reduced if rank == 0 else None
+            return res
         ctx.scan_device(gptr, G_dev, args.max_mismatch)
         # bin shards: every shard aggregates on its own and reports its totals -> all-gather -> the guides whose ordered cut-off the
-        # earlier shards move are aggregated again -> reduction of the aggregates; all on device memory over RCCL, stream-ordered.
-        # Rank 0 takes the reduced aggregates to the host like the single-GPU step does
+        # earlier shards move are aggregated again -> reduction of the aggregates; all on device memory, stream-ordered
         exch.step(ctx, args.max_offtargets)
-        res = _Reduced()
         if rank == 0:
             res.summaries = exch.summaries_numpy()
         return res
@@ -574,7 +590,9 @@ def main():
                                                     "strong scaling (BASELINE.json configs[3]: the same database, bins sharded)" if args.scaling == "strong" else
                                                     "weak scaling (every rank its own hg38-sized shard)"),
                        "guides": G, "targets_per_gpu": T, "targets_total": T_total, "positions_per_gpu": P,
-                       "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world},
+                       "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world,
+                       "exchange": ({"native": "ffh_discover_sharded: RCCL collectives issued by libflashfry_hip (%s)" % (comm.transport if comm else "?"),
+                                     "torch": "library kernels + torch.distributed collectives"}[exchange_kind] if sharded else None)},
             # executed full-length comparisons (the pigeonhole candidate generation visits ~1/4300 of the nominal G x T pairs): the figure
             # comparable with the reference's BitEncoding.allComparisons counter
             "executed_pair_tests_per_step": pairs, "executed_pair_tests_per_s": pairs * args.steps / dt,
@@ -616,6 +634,8 @@ def main():
         }
     else:
         out = None
+    if comm is not None:
+        comm.close()
     ctx.close()
     import ctypes
     ctypes.CDLL(None).fflush(None)  # RCCL prints a version banner into the C stdio buffer of stdout: every rank gets it out first

@@ -228,7 +228,7 @@ struct ffh_ctx {
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
     DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
-    DevBuf<uint32_t> sort_table, sort_offs;
+    DevBuf<uint32_t> sort_table, sort_offs, heavy_list;
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
 
     // finalize scratch
@@ -1105,9 +1105,9 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             else {
                 const uint32_t nbk = sort_nblocks(n_new);
                 FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
-                FFH_HIP(ctx->sort_table.reserve((size_t)256 * nbk + 1));
-                FFH_HIP(ctx->sort_offs.reserve((size_t)256 * nbk + 1));
-                FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
+                FFH_HIP(ctx->sort_table.reserve((size_t)kSortTableDigits * nbk + 1));
+                FFH_HIP(ctx->sort_offs.reserve((size_t)kSortTableDigits * nbk + 1));
+                FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
                 SortScratch ss;
                 ss.alt = ctx->hits_alt.p + slab_start; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
                 // by guide only (three passes instead of six): the totals do not depend on the order inside a guide's segment
@@ -1138,21 +1138,39 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     ctx->n_raw = cursor_before;
     FFH_HIP(hipEventRecord(ctx->ev[5], st));
     // ---- order the hits by (guide, database index) ----
+    // Two device-wide passes group them by guide, then one wave per guide orders its segment by ranking (ffh_prims.hpp: k_segsort;
+    // guides inside repeat families go to k_segsort_heavy).  FFH_SORT=lsd keeps the six-pass LSD sort over all key bits (A/B).
+    static const bool full_lsd = getenv("FFH_SORT") && std::strcmp(getenv("FFH_SORT"), "lsd") == 0;
     ctx->hits_sorted = ctx->hits.p;
+    bool segments_done = false;
     if (ctx->n_raw && ctx->n_raw <= kSmallSort) {
         hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, ctx->hits.p, (uint32_t)ctx->n_raw);
     } else if (ctx->n_raw) {
         const uint32_t nbk = sort_nblocks(ctx->n_raw);
         FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
-        FFH_HIP(ctx->sort_table.reserve((size_t)256 * nbk + 1));
-        FFH_HIP(ctx->sort_offs.reserve((size_t)256 * nbk + 1));
-        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)256 * nbk)));
+        FFH_HIP(ctx->sort_table.reserve((size_t)kSortTableDigits * nbk + 1));
+        FFH_HIP(ctx->sort_offs.reserve((size_t)kSortTableDigits * nbk + 1));
+        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
         SortScratch ss;
         ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
+        if (full_lsd) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
+        else {
+            FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
+            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);
+            FFH_HIP(hipMemsetAsync(n_heavy, 0, 4, st));
+            uint64_t *by_guide = radix_sort_u64(ctx->hits.p, ctx->n_raw, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);
+            uint64_t *other = by_guide == ctx->hits.p ? ctx->hits_alt.p : ctx->hits.p;
+            hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, by_guide, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
+            hipLaunchKernelGGL(k_segsort, dim3(blocks_for(n_guides, 4)), dim3(256), 0, st, by_guide, (const uint32_t *)ctx->seg_begin.p, (const uint32_t *)ctx->seg_end.p, n_guides,
+                               ctx->tbits, ctx->heavy_list.p, n_heavy);
+            hipLaunchKernelGGL(k_segsort_heavy, dim3(512), dim3(256), 0, st, by_guide, other, (const uint32_t *)ctx->seg_begin.p, (const uint32_t *)ctx->seg_end.p,
+                               (const uint32_t *)ctx->heavy_list.p, (const uint32_t *)n_heavy, ctx->tbits);
+            ctx->hits_sorted = by_guide;
+            segments_done = true;
+        }
     }
     // seg_begin / seg_end were cleared by the prefix-side k_guide_keys of every batch
-    if (ctx->n_raw)
+    if (ctx->n_raw && !segments_done)
         hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
     ctx->hit_t_ready = false;  // the target longs of the hits are gathered on demand (gather_hit_targets)
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
@@ -1639,8 +1657,8 @@ int ffh_indexer_finish(ffh_indexer *ctx, const char *db_path, int bin_width, ffh
         // stable sort of (sequence, position) by sequence: CRISPRSite.compare = the bases (crispr/CRISPRSite.scala:44)
         const uint32_t nb = sort_nblocks(S);
         FFH_HIP(alt_k.reserve(S)); FFH_HIP(alt_v.reserve(S));
-        FFH_HIP(table.reserve((size_t)256 * nb + 8)); FFH_HIP(offs.reserve((size_t)256 * nb + 8));
-        FFH_HIP(scr32.reserve(scan_scratch_elems_safe(std::max<uint64_t>((uint64_t)256 * nb, S + 1))));
+        FFH_HIP(table.reserve((size_t)kSortTableDigits * nb + 8)); FFH_HIP(offs.reserve((size_t)kSortTableDigits * nb + 8));
+        FFH_HIP(scr32.reserve(scan_scratch_elems_safe(std::max<uint64_t>((uint64_t)kSortTableDigits * nb, S + 1))));
         SortScratch ss;
         ss.alt = alt_k.p; ss.val_alt = alt_v.p; ss.table = table.p; ss.offs = offs.p; ss.scan_tmp = scr32.p;
         uint64_t *sk = nullptr, *sv = nullptr;
@@ -1784,8 +1802,8 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
         if (n_hits >= (1ull << 32) - 64) { ctx->err = "more than 2^32 bulge hits"; return FFH_E_ARG; }
         const uint32_t nb = sort_nblocks(n_hits);
         FFH_HIP(alt_k.reserve(n_hits)); FFH_HIP(alt_v.reserve(n_hits));
-        FFH_HIP(table.reserve((size_t)256 * nb + 8)); FFH_HIP(offs.reserve((size_t)256 * nb + 8));
-        FFH_HIP(scr32.reserve(scan_scratch_elems_safe((uint64_t)256 * nb)));
+        FFH_HIP(table.reserve((size_t)kSortTableDigits * nb + 8)); FFH_HIP(offs.reserve((size_t)kSortTableDigits * nb + 8));
+        FFH_HIP(scr32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nb)));
         SortScratch ss;
         ss.alt = alt_k.p; ss.val_alt = alt_v.p; ss.table = table.p; ss.offs = offs.p; ss.scan_tmp = scr32.p;
         uint64_t *sk = nullptr, *sv = nullptr;

@@ -54,6 +54,9 @@ namespace ffh {
 #ifndef FFH_ODD_PER
 #define FFH_ODD_PER 1
 #endif
+#ifndef FFH_PICK_P
+#define FFH_PICK_P 1
+#endif
 #ifndef FFH_PIPE_TRIPS
 #define FFH_PIPE_TRIPS 2   // 16-byte pieces of a group's words requested one group ahead (0: none; more cost registers)
 #endif
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             const uint32_t ncand = c1 - c0, pmax = ncand <= 64u ? 16u : ncand <= 128u ? 8u : 4u;
             auto ceil_div = [](uint32_t a, uint32_t b) { return (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b) + 0.99f); };   // a < 4096, 1 <= b <= 16
             uint32_t P, per;
-            if (e.nbv == 1u) {
+            if (FFH_PICK_P && e.nbv == 1u) {
                 // One bucket in the piece (the suffix image, a large prefix bucket): lanes 0..15 price P = lane + 1 -- rows of 64 jobs
                 // x groups per job -- and the cheapest wins.  (~ngr / 6 regardless of the candidates left every second piece of the
                 // suffix image with a second row of two jobs that ran as long as the full one.)

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 namespace ffh {
 
 constexpr int kWave = 64;
@@ -166,40 +168,45 @@ inline uint64_t scan_scratch_elems_safe(uint64_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LSD radix sort of u64 keys, 8 bits per pass, only over the caller-given bit ranges.
+// LSD radix sort of u64 keys, BITS (8 or 9) bits per pass, only over the caller-given bit ranges.
 // A 256-thread block owns a contiguous chunk of 4096 keys.  Per pass: histogram -> scan of the digit-major
-// (256 x nblocks) table -> scatter.  The scatter ranks the chunk stably (wave w owns rows w*16..w*16+15, ranked row
+// (2^BITS x nblocks) table -> scatter.  The scatter ranks the chunk stably (wave w owns rows w*16..w*16+15, ranked row
 // by row with ballots), stages it digit-ordered in LDS and writes every digit's run contiguously, so the global
 // stores are coalesced runs instead of 8-byte scatters.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
 constexpr int kSortRows = 16;                               // rows of 64 keys per wave
 constexpr int kSortChunk = kSortThreads * kSortRows;        // 4096 keys per block
+constexpr int kSortMaxBits = 9;
 
+template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
-                                                             uint32_t *__restrict__ table /* [256][nblocks] */, uint32_t nblocks) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+                                                             uint32_t *__restrict__ table /* [2^BITS][nblocks] */, uint32_t nblocks) {
+    constexpr uint32_t DIG = 1u << BITS;
+    __shared__ uint32_t h[DIG];
+    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) h[d] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
 #pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
         const uint64_t i = base + (uint64_t)r * kSortThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (DIG - 1u)], 1u);
     }
     __syncthreads();
-    table[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) table[(uint64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 // VALS: a u64 payload travels with every key (same stable permutation), staged through the same LDS buffer after the keys
-template <bool VALS>
+template <bool VALS, int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
-                                                                const uint32_t *__restrict__ offs /* scanned [256][nblocks] */, uint32_t nblocks,
+                                                                const uint32_t *__restrict__ offs /* scanned [2^BITS][nblocks] */, uint32_t nblocks,
                                                                 const uint64_t *__restrict__ vals, uint64_t *__restrict__ vout) {
+    constexpr uint32_t DIG = 1u << BITS, PER = DIG / kSortThreads;   // digits owned by a thread: 2t .. 2t + PER - 1
+    static_assert(BITS >= 8 && BITS <= kSortMaxBits, "256 or 512 digits per pass");
     __shared__ uint64_t staged[kSortChunk];      // the chunk, digit-ordered
-    __shared__ uint32_t wave_cnt[4][256];        // per-wave digit counts -> per-wave start inside the digit's run
-    __shared__ uint32_t dig_start[256];          // start of every digit's run inside the chunk
-    __shared__ uint32_t dig_goff[256];           // global offset of every digit's run
+    __shared__ uint32_t wave_cnt[4][DIG];        // per-wave digit counts -> per-wave start inside the digit's run
+    __shared__ uint32_t dig_start[DIG];          // start of every digit's run inside the chunk
+    __shared__ uint32_t dig_goff[DIG];           // global offset of every digit's run
     __shared__ uint32_t scan_lds[8];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
@@ -212,27 +219,35 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
         const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
         kreg[r] = i < here ? keys[base + i] : 0;
     }
+    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
-    dig_goff[threadIdx.x] = offs[(uint64_t)threadIdx.x * nblocks + blockIdx.x];
+        for (int w = 0; w < 4; ++w) wave_cnt[w][d] = 0;
+        dig_goff[d] = offs[(uint64_t)d * nblocks + blockIdx.x];
+    }
     __syncthreads();
     // pass 1: per-wave digit counts
 #pragma unroll
     for (int r = 0; r < kSortRows; ++r) {
         const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
-        if (i < here) atomicAdd(&wave_cnt[wave][(uint32_t)(kreg[r] >> shift) & 0xFF], 1u);
+        if (i < here) atomicAdd(&wave_cnt[wave][(uint32_t)(kreg[r] >> shift) & (DIG - 1u)], 1u);
     }
     __syncthreads();
-    // digit d (= threadIdx.x): run start inside the chunk, and each wave's start inside that run
+    // digits PER t .. PER t + PER - 1 (t = threadIdx.x): run start inside the chunk, and each wave's start inside that run
     {
-        const uint32_t c0 = wave_cnt[0][threadIdx.x], c1 = wave_cnt[1][threadIdx.x], c2 = wave_cnt[2][threadIdx.x], c3 = wave_cnt[3][threadIdx.x];
+        uint32_t c[PER][4], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { c[k][w] = wave_cnt[w][PER * threadIdx.x + k]; sum += c[k][w]; }
         uint32_t tot;
-        const uint32_t start = block_exclusive_scan<uint32_t>(c0 + c1 + c2 + c3, scan_lds, tot);
-        dig_start[threadIdx.x] = start;
-        wave_cnt[0][threadIdx.x] = start;
-        wave_cnt[1][threadIdx.x] = start + c0;
-        wave_cnt[2][threadIdx.x] = start + c0 + c1;
-        wave_cnt[3][threadIdx.x] = start + c0 + c1 + c2;
+        uint32_t start = block_exclusive_scan<uint32_t>(sum, scan_lds, tot);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t d = PER * threadIdx.x + k;
+            dig_start[d] = start;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { wave_cnt[w][d] = start; start += c[k][w]; }
+        }
     }
     __syncthreads();
     // pass 2: stable rank inside the wave, row by row; wave_cnt[wave][d] is the wave's running cursor
@@ -240,10 +255,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
     for (int r = 0; r < kSortRows; ++r) {
         const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
         const bool valid = i < here;
-        const uint32_t d = (uint32_t)(kreg[r] >> shift) & 0xFF;
+        const uint32_t d = (uint32_t)(kreg[r] >> shift) & (DIG - 1u);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const uint64_t bal = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? bal : ~bal;
         }
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
     if (!VALS) {
         for (uint32_t i = threadIdx.x; i < here; i += kSortThreads) {
             const uint64_t key = staged[i];
-            const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+            const uint32_t d = (uint32_t)(key >> shift) & (DIG - 1u);
             out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
         }
     } else {
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
             dest[k] = 0;
             if (i < here) {
                 const uint64_t key = staged[i];
-                const uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+                const uint32_t d = (uint32_t)(key >> shift) & (DIG - 1u);
                 dest[k] = dig_goff[d] + (i - dig_start[d]);
                 out[dest[k]] = key;
             }
@@ -317,31 +332,169 @@ __global__ __launch_bounds__(1024) void k_sort_small(uint64_t *__restrict__ keys
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = s[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ordering the hits: keys = (guide << tbits) | database index.  A full LSD sort makes six device-wide passes over them.  The
+// guide bits alone take two (9 + 8 bits for 100 000 guides); after them every guide's hits are contiguous, in arbitrary order, and a
+// guide has ~116 of them -- few enough for ONE WAVE to order by ranking: every key counts the keys of its segment that are smaller
+// (all pairs, the segment's low words broadcast from LDS), which is its position.  No exchange network, no dependent steps, one read
+// and one write of the keys.  Segments beyond kSegWaveMax keys (guides inside repeat families) are listed and ordered by
+// k_segsort_heavy, one block each, with an LSD sort of its own over the segment.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSegWaveMax = 1024;
+constexpr int kSegRows = kSegWaveMax / 64;
+
+__global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end,
+                                                 uint32_t n_guides, int tbits, uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ n_heavy) {
+    __shared__ uint32_t low[4][kSegWaveMax];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
+    if (g >= n_guides) return;
+    const uint32_t b = seg_begin[g], n = seg_end[g] - b;
+    if (n <= 1u) return;
+    if (n > kSegWaveMax) {
+        if (lane == 0) heavy_list[atomicAdd(n_heavy, 1u)] = g;
+        return;
+    }
+    const uint32_t mask = tbits >= 32 ? 0xFFFFFFFFu : (1u << tbits) - 1u;
+    const uint32_t K = (n + 63u) >> 6;   // keys per lane (uniform)
+    uint64_t k[kSegRows];
+    uint32_t rank[kSegRows];
+#pragma unroll
+    for (int r = 0; r < kSegRows; ++r) {
+        k[r] = ~0ull; rank[r] = 0;
+        if ((uint32_t)r < K) {
+            const uint32_t i = (uint32_t)r * 64u + lane;
+            if (i < n) { k[r] = keys[b + i]; low[wave][i] = (uint32_t)k[r] & mask; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (K <= 2u) {   // the usual segment: two keys per lane
+        const uint32_t a0 = (uint32_t)k[0] & mask, a1 = (uint32_t)k[1] & mask;
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t v = low[wave][j];   // uniform address: one broadcast read
+            r0 += v < a0 ? 1u : 0u;
+            r1 += v < a1 ? 1u : 0u;
+        }
+        rank[0] = r0; rank[1] = r1;
+    } else {
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t v = low[wave][j];
+#pragma unroll
+            for (int r = 0; r < kSegRows; ++r)
+                if ((uint32_t)r < K) rank[r] += v < ((uint32_t)k[r] & mask) ? 1u : 0u;
+        }
+    }
+    // (the whole segment is in registers: writing it back in place is safe; the keys of a segment are distinct -- a (guide, target)
+    // pair is found once -- so the ranks are a permutation)
+#pragma unroll
+    for (int r = 0; r < kSegRows; ++r)
+        if ((uint32_t)r < K && (uint32_t)r * 64u + lane < n) keys[b + rank[r]] = k[r];
+}
+
+// one block per listed segment: LSD radix sort over the low `tbits` bits, 8 bits per pass, 256 keys per step, ping-pong between the
+// segment's ranges of `keys` and `alt`; the result ends in `keys`
+__global__ __launch_bounds__(256) void k_segsort_heavy(uint64_t *__restrict__ keys, uint64_t *__restrict__ alt, const uint32_t *__restrict__ seg_begin,
+                                                       const uint32_t *__restrict__ seg_end, const uint32_t *__restrict__ heavy_list,
+                                                       const uint32_t *__restrict__ n_heavy, int tbits) {
+    __shared__ uint32_t cursor[256];
+    __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t scan_lds[8];
+    const uint32_t t = threadIdx.x, wave = t >> 6;
+    const uint32_t nh = *n_heavy;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t g = heavy_list[h], b = seg_begin[g], n = seg_end[g] - b;
+        uint64_t *src = keys + b, *dst = alt + b;
+        for (int shift = 0; shift < tbits; shift += 8) {
+            cursor[t] = 0;
+            __syncthreads();
+            for (uint32_t i = t; i < n; i += 256) atomicAdd(&cursor[(uint32_t)(src[i] >> shift) & 255u], 1u);
+            __syncthreads();
+            uint32_t tot;
+            const uint32_t start = block_exclusive_scan<uint32_t>(cursor[t], scan_lds, tot);
+            cursor[t] = start;
+            __syncthreads();
+            for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+                const uint32_t i = c0 + t;
+                const bool valid = i < n;
+                const uint64_t key = valid ? src[i] : 0ull;
+                const uint32_t d = (uint32_t)(key >> shift) & 255u;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) wcnt[w][t] = 0;
+                __syncthreads();
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const uint64_t bal = __ballot((d >> bb) & 1);
+                    peers &= ((d >> bb) & 1) ? bal : ~bal;
+                }
+                const uint32_t rank = mbcnt(peers);
+                if (valid && rank == (uint32_t)__popcll(peers) - 1u) wcnt[wave][d] = rank + 1u;   // this wave's keys with digit d
+                __syncthreads();
+                if (valid) {
+                    uint32_t off = cursor[d] + rank;
+                    for (uint32_t w = 0; w < wave; ++w) off += wcnt[w][d];
+                    dst[off] = key;
+                }
+                __syncthreads();
+                cursor[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+                __syncthreads();
+            }
+            uint64_t *x = src; src = dst; dst = x;
+        }
+        if (src != keys + b)
+            for (uint32_t i = t; i < n; i += 256) keys[b + i] = src[i];
+        __syncthreads();
+    }
+}
+
 struct SortScratch {
     uint64_t *alt = nullptr;     // n keys
     uint64_t *val_alt = nullptr; // n payloads (radix_sort_pairs only)
-    uint32_t *table = nullptr;   // 256*nblocks + 1
-    uint32_t *offs = nullptr;    // 256*nblocks + 1
+    uint32_t *table = nullptr;   // 512*nblocks + 1
+    uint32_t *offs = nullptr;    // 512*nblocks + 1
     uint32_t *scan_tmp = nullptr;
 };
+constexpr uint32_t kSortTableDigits = 1u << kSortMaxBits;   // table / offs hold this many digits x nblocks (+ 1)
 
 inline uint32_t sort_nblocks(uint64_t n) { return (uint32_t)((n + kSortChunk - 1) / kSortChunk); }
+
+// one stable pass over `bits` (8 or 9) bits from `shift` on: src -> dst
+template <bool VALS>
+inline void radix_pass(const uint64_t *src, uint64_t *dst, const uint64_t *vsrc, uint64_t *vdst, uint64_t n, int shift, int bits, SortScratch &s, hipStream_t st) {
+    const uint32_t nb = sort_nblocks(n);
+    if (bits > 8) {
+        hipLaunchKernelGGL(k_sort_hist<9>, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
+        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)512 * nb, s.offs, s.scan_tmp, st);
+        hipLaunchKernelGGL((k_sort_scatter<VALS, 9>), dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, vsrc, vdst);
+    } else {
+        hipLaunchKernelGGL(k_sort_hist<8>, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
+        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
+        hipLaunchKernelGGL((k_sort_scatter<VALS, 8>), dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, vsrc, vdst);
+    }
+}
+
+// passes needed for a range of `len` bits with digits of at most 9 bits, and the width of pass k (the widths differ by at most one)
+inline int radix_passes(int len) { return len <= 0 ? 0 : (len + kSortMaxBits - 1) / kSortMaxBits; }
+inline int radix_width(int len, int k) { const int p = radix_passes(len); return len / p + (k < len % p ? 1 : 0); }
 
 // sorts keys[0..n) ascending considering only bits [lo_a, hi_a) and [lo_b, hi_b) (lo_b >= hi_a); returns the
 // pointer (keys or scratch.alt) that holds the sorted result.
 inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, int lo_b, int hi_b, SortScratch &s, hipStream_t st) {
     if (n == 0) return keys;
-    const uint32_t nb = sort_nblocks(n);
     uint64_t *src = keys, *dst = s.alt;
     int ranges[2][2] = {{lo_a, hi_a}, {lo_b, hi_b}};
-    for (int rg = 0; rg < 2; ++rg)
-        for (int shift = ranges[rg][0]; shift < ranges[rg][1]; shift += 8) {
-            hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
-            exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
-            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, (const uint64_t *)nullptr,
-                               (uint64_t *)nullptr);
+    for (int rg = 0; rg < 2; ++rg) {
+        const int len = ranges[rg][1] - ranges[rg][0];
+        int shift = ranges[rg][0];
+        for (int k = 0; k < radix_passes(len); ++k) {
+            const int w = radix_width(len, k);
+            radix_pass<false>(src, dst, nullptr, nullptr, n, shift, std::max(w, 8), s, st);   // (a digit narrower than 8 bits reads bits above the range: zeros or already-sorted bits)
+            shift += w;
             uint64_t *t = src; src = dst; dst = t;
         }
+    }
     return src;
 }
 
@@ -350,12 +503,13 @@ inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, 
 inline void radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, int lo, int hi, SortScratch &s, hipStream_t st, uint64_t *&keys_out, uint64_t *&vals_out) {
     keys_out = keys; vals_out = vals;
     if (n == 0) return;
-    const uint32_t nb = sort_nblocks(n);
     uint64_t *src = keys, *dst = s.alt, *vsrc = vals, *vdst = s.val_alt;
-    for (int shift = lo; shift < hi; shift += 8) {
-        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
-        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
-        hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, (const uint64_t *)vsrc, vdst);
+    const int len = hi - lo;
+    int shift = lo;
+    for (int k = 0; k < radix_passes(len); ++k) {
+        const int w = radix_width(len, k);
+        radix_pass<true>(src, dst, vsrc, vdst, n, shift, std::max(w, 8), s, st);
+        shift += w;
         uint64_t *t = src; src = dst; dst = t;
         t = vsrc; vsrc = vdst; vdst = t;
     }

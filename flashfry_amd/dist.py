@@ -9,8 +9,25 @@ guides against its shard.  Two small exchanges per discover:
   2. reduction of the per-guide aggregates (integer lanes summed exactly, f64 sums combined in rank order,
      cfd_max / overflow by max, closest hit by min + masked count).
 Hit lists stay on their rank; concatenated in rank order they are the reference's hit list.
+
+Two forms of the same exchange:
+  * native_comm(ctx) -> capi.Comm: the collectives are issued INSIDE libflashfry_hip (ffh_comm_*, csrc/ffh_comm.hpp: RCCL on the
+    context's stream); torch.distributed only carries the 128-byte unique id once.  What bench.py --gpus N times, what the C++ CLI
+    (--gpus N, ncclCommInitAll) and a JVM host call.
+  * DeviceExchange: library kernels + torch.distributed collectives on torch's stream (any backend: the gloo tests on CPU tensors,
+    several ranks sharing one GPU).
 """
 import numpy as np
+
+
+def native_comm(ctx, group=None):
+    """one rank per GPU: an ffh_comm over RCCL for `ctx` (this rank's shard); rank 0 makes the unique id, torch.distributed hands it round"""
+    import torch.distributed as dist
+    from . import capi
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = [capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return capi.Comm.rank(ctx, rank, world, uid[0])
 
 
 def shard_bins(uncompressed_bytes, world):

@@ -202,4 +202,4 @@ def test_c4_eight_bin_shards_through_the_library_exchange_equal_the_unsharded_di
     over = s["overflow"].astype(bool)
     spans = (counts > 0).sum(0)
     assert over.sum() > G // 2 and int((over & (spans >= 4)).sum()) > 1000, (int(over.sum()), int((over & (spans >= 4)).sum()))
-    assert int((~over).sum()) > 0                                               # ... and guides that never reached it
+    assert np.array_equal(summ["ot_count"] >= max_ot, over)                     # CRISPRSiteOT.full on the reduced totals
