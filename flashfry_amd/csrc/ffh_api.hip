@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -215,6 +216,11 @@ struct ffh_ctx {
     uint64_t n_raw = 0;
     int tbits = 1;   // hit key = (guide << tbits) | database index
     DevBuf<uint32_t> seg_begin, seg_end;
+    // the two waits of a discover step -- for the compare launch's counters, for the epilogue's summaries -- poll a word in
+    // page-locked memory that a one-wave kernel writes behind the work (k_publish): a hipStreamSynchronize wake-up costs 20-50 us
+    // on this stack, which is 2-4 % of a 2.3 ms step.  Bounded spin, then the blocking call (spin_wait).
+    unsigned long long *h_pub = nullptr, *d_pub = nullptr;   // [0..15] published counters, [16] sequence number
+    unsigned long long pub_seq = 0;
     unsigned long long *d_counters = nullptr;  // [0] hit cursor, [1] pairs prefix, [2] pairs suffix, [3] a zero word, [4] load-time check counter
 
     // per-pass scratch
@@ -223,7 +229,7 @@ struct ffh_ctx {
     DevBuf<unsigned long long> part_pairs[2];  // per candidate partition: targets x candidates of its buckets (k_item_bin)
     uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
-    DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32;
+    DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32, gp_start, by_part;
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
     DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
@@ -285,6 +291,7 @@ static const std::vector<uint32_t> &patterns_for(ffh_ctx *ctx, int n, int r) {
     std::vector<uint32_t> v;
     v.reserve((size_t)ball_size(n, r));
     enum_patterns(n, r, 0, 0, v);
+    std::sort(v.begin(), v.end());   // numeric order: patterns with equal high (partition) bits are neighbours (k_item_bin_direct)
     return ctx->pattern_cache.emplace(key, std::move(v)).first->second;
 }
 
@@ -486,17 +493,39 @@ static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t
                             (uint32_t *)nullptr, ctx->part_hist.p, ig.n_part);
     FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
     FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
-    FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
     uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
-    const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
     hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
-    if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
-    else hipLaunchKernelGGL((k_item_partition<false, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
-    exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
-    if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
-    else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
-    hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
-                       (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
+    static const bool old_binning = getenv("FFH_BINNING") && std::strcmp(getenv("FFH_BINNING"), "records") == 0;   // A/B: the round-2 form
+    if (!old_binning) {
+        // guides grouped by partition (counting sort on the histogram), then every partition's block enumerates its own entries from
+        // those runs: no intermediate records (ffh_kernels.hpp: k_item_bin_direct)
+        FFH_HIP(ctx->gp_start.reserve((size_t)ig.n_part + 2));
+        FFH_HIP(ctx->by_part.reserve((size_t)ng + 1));
+        exclusive_scan<uint32_t, uint32_t>(ctx->part_hist.p, ig.n_part, ctx->gp_start.p, ctx->scan_tmp32.p, st);
+        hipLaunchKernelGGL(k_guide_by_part, dim3(blocks_for(ng, 1024)), dim3(1024), 0, st, (const uint32_t *)gbucket.p, ng, ig.low_bits, ig.n_part,
+                           (const uint32_t *)ctx->gp_start.p, part_fill, ctx->by_part.p);
+        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+        else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
+                                (const uint32_t *)patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                (unsigned long long *)nullptr);
+        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
+        if (!filtered) hipLaunchKernelGGL((k_item_bin_direct<false, false>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
+                                          (const uint32_t *)patterns.p, ig, (const uint32_t *)ctx->part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p,
+                                          (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
+        else hipLaunchKernelGGL((k_item_bin_direct<false, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
+                                (const uint32_t *)patterns.p, ig, (const uint32_t *)ctx->part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p, (const uint32_t *)im.bstart.p,
+                                ctx->part_pairs[which].p);
+    } else {
+        FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
+        const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
+        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+        else hipLaunchKernelGGL((k_item_partition<false, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
+        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
+        if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
+        else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
+        hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
+                           (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
+    }
     ctx->n_part[which] = ig.n_part;
     FFH_HIP(hipGetLastError());
     return FFH_OK;
@@ -507,6 +536,40 @@ static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t
 // on the caller's stream (ffh_use_stream) stream order does the same for free.
 static hipError_t fence_in(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : hipDeviceSynchronize(); }
 static hipError_t fence_out(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : hipStreamSynchronize(ctx->st); }
+
+// copies the counter block to page-locked memory and, after it, the sequence number the host is polling for
+__global__ void k_publish(const unsigned long long *__restrict__ counters, volatile unsigned long long *__restrict__ host, unsigned long long seq) {
+    if (counters && threadIdx.x < 16) host[threadIdx.x] = counters[threadIdx.x];
+    __threadfence_system();
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) host[16] = seq;
+}
+// everything issued on the stream so far has completed (and `out`, if given, holds the device counters)
+static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, nullable */) {
+    static const bool no_spin = getenv("FFH_NO_SPIN") && atoi(getenv("FFH_NO_SPIN")) == 1;
+    if (no_spin || !ctx->h_pub) {
+        if (out) { hipError_t e = hipMemcpyAsync(out, ctx->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st); if (e != hipSuccess) return e; }
+        return hipStreamSynchronize(ctx->st);
+    }
+    const unsigned long long seq = ++ctx->pub_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->st, out ? (const unsigned long long *)ctx->d_counters : (const unsigned long long *)nullptr,
+                       (volatile unsigned long long *)ctx->d_pub, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    volatile unsigned long long *h = ctx->h_pub;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0; h[16] != seq; ++it) {
+        __builtin_ia32_pause();
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {   // a long kernel, a fault: block
+            e = hipStreamSynchronize(ctx->st);
+            if (e != hipSuccess) return e;
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (out) for (int i = 0; i < 16; ++i) out[i] = h[i];
+    return hipSuccess;
+}
 
 // =============================================================================================================
 // C ABI
@@ -557,6 +620,8 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_pub, 32 * sizeof(unsigned long long), hipHostMallocMapped);
+    if (e == hipSuccess) { std::memset(ctx->h_pub, 0, 32 * sizeof(unsigned long long)); e = hipHostGetDevicePointer((void **)&ctx->d_pub, ctx->h_pub, 0); }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
     if (e == hipSuccess) {
         ScoreTables h;
@@ -582,6 +647,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->st);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
@@ -1064,8 +1130,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             FFH_HIP(hipGetLastError());
             FFH_HIP(hipEventRecord(ctx->ev[4], st));
             unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
-            FFH_HIP(hipMemcpyAsync(cnt, ctx->d_counters, sizeof cnt, hipMemcpyDeviceToHost, st));
-            FFH_HIP(hipStreamSynchronize(st));
+            FFH_HIP(spin_wait(ctx, cnt));
             FFH_HIP(hipGetLastError());
             first_launch = false;
             const unsigned long long cursor = cnt[0];
@@ -1140,7 +1205,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // ---- order the hits by (guide, database index) ----
     // Two device-wide passes group them by guide, then one wave per guide orders its segment by ranking (ffh_prims.hpp: k_segsort;
     // guides inside repeat families go to k_segsort_heavy).  FFH_SORT=lsd keeps the six-pass LSD sort over all key bits (A/B).
-    static const bool full_lsd = getenv("FFH_SORT") && std::strcmp(getenv("FFH_SORT"), "lsd") == 0;
+    const char *sort_env = getenv("FFH_SORT");   // "lsd" / "seg": force one of the two (A/B runs, tests of the heavy-segment path)
+    const bool full_lsd = sort_env && std::strcmp(sort_env, "lsd") == 0, force_seg = sort_env && std::strcmp(sort_env, "seg") == 0;
     ctx->hits_sorted = ctx->hits.p;
     bool segments_done = false;
     if (ctx->n_raw && ctx->n_raw <= kSmallSort) {
@@ -1153,7 +1219,10 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
         SortScratch ss;
         ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        if (full_lsd) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
+        // (segments of thousands of hits -- a 5-mismatch scan, guides inside repeat families -- are what the device-wide passes are
+        // good at: beyond 256 raw hits per guide on average the six-pass sort is taken)
+        const bool many = ctx->n_raw > 256ull * std::max<uint32_t>(n_guides, 1u);
+        if (full_lsd || (many && !force_seg)) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
         else {
             FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
             uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);
@@ -1331,7 +1400,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         hipError_t e = hipEventRecord(ctx->ev[1], st);
         if (e == hipSuccess) e = hipGetLastError();
         if (G && e == hipSuccess && !zero_copy) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = spin_wait(ctx, nullptr);
         if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
         r->offsets_pending = true;
         float ms = 0;

@@ -442,6 +442,122 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same CSR without the intermediate records (round 3).  bucket = guide bucket ^ pattern acts on the partition bits and on the low
+// bits separately, so the entries of partition q come, for every pattern p, from the guides of ONE partition, q ^ high(p).  With the
+// guides grouped by partition (k_guide_by_part: a counting sort on the histogram k_guide_part_hist leaves anyway; 100 000 guides)
+// the block of partition q enumerates its own entries straight from those runs -- once to count its buckets, once to place the
+// guide ids -- and the 4-byte record per entry that k_item_partition wrote (2.4 x its size in half-filled sectors) and k_item_bin
+// read back is gone: 0.33 -> ~0.15 ms for the 5.3e7 entries of the hg38-scale prefix image.
+// ---------------------------------------------------------------------------------------------------------
+// guides grouped by partition: by_part[gp_start[part] + k] = (low bucket bits << kGidBits) | guide.  A block of 1024 guides counts
+// its guides per partition in LDS and reserves one run per partition it touches (an image with few partitions -- the suffix side --
+// put ~400 same-address global atomics on every counter: 47 us; this way a few per block)
+__global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
+                                                        const uint32_t *__restrict__ gp_start, uint32_t *__restrict__ gp_fill /* zeroed */,
+                                                        uint32_t *__restrict__ by_part) {
+    __shared__ uint32_t cnt[1 << kMaxPartBits];
+    for (uint32_t q = threadIdx.x; q < n_part; q += blockDim.x) cnt[q] = 0;
+    __syncthreads();
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = 0, part = 0, local = 0;
+    if (g < n_guides) { b = gbucket[g]; part = b >> low_bits; local = atomicAdd(&cnt[part], 1u); }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < n_part; q += blockDim.x) {
+        const uint32_t c = cnt[q];
+        if (c) cnt[q] = gp_start[q] + atomicAdd(&gp_fill[q], c);
+    }
+    __syncthreads();
+    if (g < n_guides) by_part[cnt[part] + local] = ((b & ((1u << low_bits) - 1u)) << kGidBits) | g;
+}
+
+// One block per partition.  COUNT: only the number of entries the partition keeps (the exact sizes a slab of a bounded scan needs:
+// its rank filter looks at the low bucket bits, so the XOR convolution of k_part_sizes does not apply) -> part_count[d].
+template <bool COUNT, bool SLAB>
+__global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint32_t *__restrict__ gp_start, const uint32_t *__restrict__ by_part,
+                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, const uint32_t *__restrict__ part_start,
+                                                                  uint32_t *__restrict__ part_count, uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid,
+                                                                  const uint32_t *__restrict__ bstart, unsigned long long *__restrict__ part_pairs) {
+    __shared__ uint32_t cnt[1 << kMaxLowBits];
+    __shared__ uint32_t stage[COUNT ? 1 : kBinStage];
+    __shared__ uint32_t scan_lds[16];
+    __shared__ unsigned long long pair_lds[16];
+    const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits, lowmask = nlow - 1u;
+    const uint32_t part_lo = ig.range[0] >> ig.low_bits, part_hi = ig.range[1] >> ig.low_bits;
+    const bool live = d >= part_lo && d <= part_hi;   // partitions without a target take no entries
+    // The patterns are in numeric order, so the ones that share their partition bits -- and with them the source run q ^ high(p) --
+    // are neighbours.  A wave walks a contiguous slice of the patterns; its lanes take the guides of the source run side by side
+    // (coalesced, and L1-hot for the next pattern of the same run).  fn(low bucket bits, guide).
+    auto enumerate = [&](auto &&fn) {
+        if (!live) return;
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kPartThreads / 64;
+        const uint32_t per_w = (ig.n_pat + nw - 1) / nw, pa = wave * per_w, pb = min(ig.n_pat, pa + per_w);
+        for (uint32_t p = pa; p < pb; ++p) {
+            const uint32_t pat = patterns[p], src = d ^ (pat >> ig.low_bits), plo = pat & lowmask;
+            const uint32_t k1 = gp_start[src + 1];
+            for (uint32_t k = gp_start[src] + lane; k < k1; k += 64) {
+                const uint32_t rec = by_part[k], low = (rec >> kGidBits) ^ plo;
+                if (SLAB) {
+                    const uint32_t r = bucket_rank((d << ig.low_bits) | low, ig.width);
+                    if (r < ig.rank_lo || r > ig.rank_hi) continue;
+                }
+                fn(low, rec & ((1u << kGidBits) - 1u));
+            }
+        }
+    };
+    for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
+    __syncthreads();
+    enumerate([&](uint32_t low, uint32_t) { atomicAdd(&cnt[lds_slot(low)], 1u); });
+    __syncthreads();
+    const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
+    if (COUNT) {
+        uint32_t mine = 0;
+        for (uint32_t k = 0; k < per; ++k)
+            if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
+        uint32_t tot;
+        (void)block_exclusive_scan_1024(mine, scan_lds, tot);
+        if (threadIdx.x == 0) part_count[d] = tot;
+        return;
+    }
+    const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
+    const uint32_t gbase = ig.item_base + p0;  // the entries of partition d occupy CSR slots [item_base + p0, + n)
+    {   // exclusive scan of the nlow counters: CSR offsets out, counters become placement cursors; the executed-pair statistic
+        uint32_t mine = 0;
+        for (uint32_t k = 0; k < per; ++k)
+            if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
+        uint32_t tot;
+        uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
+        unsigned long long pairs = 0;
+        for (uint32_t k = 0; k < per; ++k)
+            if (l0 + k < nlow) {
+                const uint32_t c = cnt[lds_slot(l0 + k)];
+                const uint64_t bucket = ((uint64_t)d << ig.low_bits) + l0 + k;
+                istart[bucket] = gbase + off;
+                cnt[lds_slot(l0 + k)] = off;
+                off += c;
+                if (c) pairs += (unsigned long long)c * (bstart[bucket + 1] - bstart[bucket]);
+            }
+        if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) pairs += __shfl_xor(pairs, sft, 64);
+        if ((threadIdx.x & 63) == 0) pair_lds[threadIdx.x >> 6] = pairs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kPartThreads / 64; ++w) t += pair_lds[w];
+            part_pairs[d] = t;
+        }
+    }
+    __syncthreads();
+    if (n <= (uint32_t)kBinStage) {   // the usual case: the ids are put in bucket order inside LDS and leave as one coalesced copy
+        enumerate([&](uint32_t low, uint32_t g) { stage[atomicAdd(&cnt[lds_slot(low)], 1u)] = g; });
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) item_gid[gbase + k] = stage[k];
+    } else {
+        enumerate([&](uint32_t low, uint32_t g) { item_gid[gbase + atomicAdd(&cnt[lds_slot(low)], 1u)] = g; });
+    }
+}
+
 // (the compare kernel lives in ffh_compare.hpp)
 
 // ---------------------------------------------------------------------------------------------------------

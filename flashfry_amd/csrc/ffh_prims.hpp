@@ -345,7 +345,7 @@ constexpr int kSegRows = kSegWaveMax / 64;
 
 __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end,
                                                  uint32_t n_guides, int tbits, uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ n_heavy) {
-    __shared__ uint32_t low[4][kSegWaveMax];
+    __shared__ __attribute__((aligned(16))) uint32_t low[4][kSegWaveMax];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
     const uint32_t b = seg_begin[g], n = seg_end[g] - b;
@@ -369,21 +369,40 @@ __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (K <= 2u) {   // the usual segment: two keys per lane
-        const uint32_t a0 = (uint32_t)k[0] & mask, a1 = (uint32_t)k[1] & mask;
+    if (K <= 2u) {
+        // the usual segment (<= 128 keys, two per lane): the other keys come through v_readlane, four per step -- no memory round trip
+        // in the loop (an LDS broadcast per key made the wave wait ~100 cycles 116 times: 370 us for the 100 000 guides of the
+        // hg38-scale step; one v_readlane per key 205 us)
+        const uint32_t a0 = (uint32_t)k[0] & mask, a1 = K > 1u ? (uint32_t)k[1] & mask : 0u;   // (a lane without a second key never writes rank[1])
+        const uint32_t n0 = min(n, 64u), n1 = n - n0;
         uint32_t r0 = 0, r1 = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t v = low[wave][j];   // uniform address: one broadcast read
-            r0 += v < a0 ? 1u : 0u;
-            r1 += v < a1 ? 1u : 0u;
-        }
+        // (lanes past the segment hold all-ones keys: never below a real key, so the steps run in fours without a remainder)
+        auto steps = [&](uint32_t src, uint32_t cnt) {
+            for (uint32_t j = 0; j < cnt; j += 4) {
+                const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)j), v1 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 1u));
+                const uint32_t v2 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 2u)), v3 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 3u));
+                r0 += (v0 < a0 ? 1u : 0u) + (v1 < a0 ? 1u : 0u) + (v2 < a0 ? 1u : 0u) + (v3 < a0 ? 1u : 0u);
+                r1 += (v0 < a1 ? 1u : 0u) + (v1 < a1 ? 1u : 0u) + (v2 < a1 ? 1u : 0u) + (v3 < a1 ? 1u : 0u);
+            }
+        };
+        steps(lane < n0 ? ((uint32_t)k[0] & mask) : 0xFFFFFFFFu, n0);
+        steps(lane < n1 ? ((uint32_t)k[1] & mask) : 0xFFFFFFFFu, n1);
         rank[0] = r0; rank[1] = r1;
     } else {
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t v = low[wave][j];
+        // larger segments: the low words from LDS, four per (broadcast) read
+        const uint32_t n4 = (n + 3u) & ~3u;
+        for (uint32_t i = n + lane; i < n4; i += 64) low[wave][i] = 0xFFFFFFFFu;   // (tbits < 32: never below a real key's low word)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j = 0; j < n4; j += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&low[wave][j]);
 #pragma unroll
             for (int r = 0; r < kSegRows; ++r)
-                if ((uint32_t)r < K) rank[r] += v < ((uint32_t)k[r] & mask) ? 1u : 0u;
+                if ((uint32_t)r < K) {
+                    const uint32_t a = (uint32_t)k[r] & mask;
+                    rank[r] += (v.x < a ? 1u : 0u) + (v.y < a ? 1u : 0u) + (v.z < a ? 1u : 0u) + (v.w < a ? 1u : 0u);
+                }
         }
     }
     // (the whole segment is in registers: writing it back in place is safe; the keys of a segment are distinct -- a (guide, target)
@@ -393,15 +412,16 @@ __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, co
         if ((uint32_t)r < K && (uint32_t)r * 64u + lane < n) keys[b + rank[r]] = k[r];
 }
 
-// one block per listed segment: LSD radix sort over the low `tbits` bits, 8 bits per pass, 256 keys per step, ping-pong between the
-// segment's ranges of `keys` and `alt`; the result ends in `keys`
+// one block per listed segment: LSD radix sort over the low `tbits` bits, 8 bits per pass, 4096 keys per step (the ranking of
+// k_sort_scatter with the digits' running cursors kept in LDS), ping-pong between the segment's ranges of `keys` and `alt`; the result
+// ends in `keys`
 __global__ __launch_bounds__(256) void k_segsort_heavy(uint64_t *__restrict__ keys, uint64_t *__restrict__ alt, const uint32_t *__restrict__ seg_begin,
                                                        const uint32_t *__restrict__ seg_end, const uint32_t *__restrict__ heavy_list,
                                                        const uint32_t *__restrict__ n_heavy, int tbits) {
     __shared__ uint32_t cursor[256];
     __shared__ uint32_t wcnt[4][256];
     __shared__ uint32_t scan_lds[8];
-    const uint32_t t = threadIdx.x, wave = t >> 6;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t nh = *n_heavy;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t g = heavy_list[h], b = seg_begin[g], n = seg_end[g] - b;
@@ -415,30 +435,51 @@ __global__ __launch_bounds__(256) void k_segsort_heavy(uint64_t *__restrict__ ke
             const uint32_t start = block_exclusive_scan<uint32_t>(cursor[t], scan_lds, tot);
             cursor[t] = start;
             __syncthreads();
-            for (uint32_t c0 = 0; c0 < n; c0 += 256) {
-                const uint32_t i = c0 + t;
-                const bool valid = i < n;
-                const uint64_t key = valid ? src[i] : 0ull;
-                const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            for (uint32_t c0 = 0; c0 < n; c0 += kSortChunk) {
+                const uint32_t here = min((uint32_t)kSortChunk, n - c0);
+                uint64_t kreg[kSortRows];
+#pragma unroll
+                for (int r = 0; r < kSortRows; ++r) {
+                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                    kreg[r] = i < here ? src[c0 + i] : 0ull;
+                }
 #pragma unroll
                 for (int w = 0; w < 4; ++w) wcnt[w][t] = 0;
                 __syncthreads();
-                uint64_t peers = __ballot(valid);
 #pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const uint64_t bal = __ballot((d >> bb) & 1);
-                    peers &= ((d >> bb) & 1) ? bal : ~bal;
-                }
-                const uint32_t rank = mbcnt(peers);
-                if (valid && rank == (uint32_t)__popcll(peers) - 1u) wcnt[wave][d] = rank + 1u;   // this wave's keys with digit d
-                __syncthreads();
-                if (valid) {
-                    uint32_t off = cursor[d] + rank;
-                    for (uint32_t w = 0; w < wave; ++w) off += wcnt[w][d];
-                    dst[off] = key;
+                for (int r = 0; r < kSortRows; ++r) {
+                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                    if (i < here) atomicAdd(&wcnt[wave][(uint32_t)(kreg[r] >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                cursor[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+                {   // digit t: where each wave's keys of this step go; the digit's cursor moves on
+                    const uint32_t c0w = wcnt[0][t], c1w = wcnt[1][t], c2w = wcnt[2][t], c3w = wcnt[3][t], base = cursor[t];
+                    wcnt[0][t] = base; wcnt[1][t] = base + c0w; wcnt[2][t] = base + c0w + c1w; wcnt[3][t] = base + c0w + c1w + c2w;
+                    cursor[t] = base + c0w + c1w + c2w + c3w;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kSortRows; ++r) {
+                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                    const bool valid = i < here;
+                    const uint32_t d = (uint32_t)(kreg[r] >> shift) & 255u;
+                    uint64_t peers = __ballot(valid);
+#pragma unroll
+                    for (int bb = 0; bb < 8; ++bb) {
+                        const uint64_t bal = __ballot((d >> bb) & 1);
+                        peers &= ((d >> bb) & 1) ? bal : ~bal;
+                    }
+                    const uint32_t rank = mbcnt(peers);
+                    uint32_t pos = 0;
+                    if (valid) pos = wcnt[wave][d] + rank;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && rank == (uint32_t)__popcll(peers) - 1u) wcnt[wave][d] = pos + 1u;   // last peer advances the wave's cursor
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (valid) dst[pos] = kreg[r];
+                }
                 __syncthreads();
             }
             uint64_t *x = src; src = dst; dst = x;

@@ -221,3 +221,26 @@ def test_bounded_scan_with_guide_batches_and_other_enzymes(capi, oracle, monkeyp
         ora_ = odb_.discover(g_, 4, max_ot)
         assert_same_hits(gpu, ora_)
         assert gpu.n_hits > 0
+
+
+@pytest.mark.parametrize("sort", ["seg", "lsd"])
+def test_hit_ordering_by_segments_and_by_six_passes_agree_with_the_oracle(capi, oracle, monkeypatch, sort):
+    """the hits are ordered by two device-wide passes over the guide bits + one wave per guide ranking its segment (k_segsort), guides
+    with more than 1024 raw hits by a block-level sort of their own (k_segsort_heavy); scans with many hits per guide take the
+    six-pass LSD sort.  FFH_SORT forces either: both must give the oracle's lists on a genome whose repeat families put thousands of
+    raw hits on some guides and a handful on others."""
+    monkeypatch.setenv("FFH_SORT", sort)
+    db = synth.make_repeat_database(900_000, seed=synth.DB_SEED + 21)
+    g = synth.as_u64(synth.make_guides_from_database(db, 500, seed=synth.GUIDE_SEED + 21))
+    t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
+    odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        ctx.set_bounding(0)
+        gpu = ctx.discover(g, 4, 2 ** 31 - 1, jost=True)                 # no cut-off: every raw hit is delivered, in database order
+        tm = ctx.timings()
+        cut = ctx.discover(g, 5, 300)
+    per_guide = np.diff(gpu.guide_offsets.astype(np.int64))
+    assert per_guide.max() > 1024 and (per_guide <= 128).sum() > 50 and ((per_guide > 128) & (per_guide <= 1024)).sum() > 5, (per_guide.max(), tm.n_raw_hits)
+    assert_same_hits(gpu, odb.discover(g, 4, 2 ** 31 - 1))
+    assert_same_hits(cut, odb.discover(g, 5, 300))

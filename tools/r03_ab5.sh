@@ -1,0 +1,20 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03e
+O=gpurun_out/r03e
+timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -5 $O/pytest.log
+run() { # name, env...
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --no-traffic --cpu-seconds 0 --no-verify --no-skewed --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$name', round(d['ms_per_step'], 3), {k: round(v, 3) for k, v in d['breakdown_ms'].items()}, 'raw', d['hits']['raw'])" | tee -a $O/ab.txt
+}
+for rep in 1 2; do
+  run segsort X=1
+  run lsd FFH_SORT=lsd
+done
+env FFH_SORT=seg timeout 600 python bench.py --no-traffic --cpu-seconds 0 --steps 5 --warmup 2 --no-verify 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('forced seg: skewed', round(d['skewed']['ms_per_step'], 3), d['skewed']['breakdown_ms'], 'unbounded', round(d['skewed']['unbounded']['ms_per_step'], 3), d['skewed']['unbounded']['breakdown_ms'])" | tee -a $O/ab.txt
+bash tools/timeline.sh > $O/timeline.txt 2>&1; grep -E "k_seg|k_sort|span" $O/timeline.txt
