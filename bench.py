@@ -129,27 +129,27 @@ def pair_step_valu(rest_bases, far):
     return 2 * rest_bases + ops + 5 + (5 if far else 0)
 
 
-def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single_rate, filt, per_bin):
-    """The same port with one thread per usable host core, each scanning its own sample of bins at the same time (ctypes releases
-    the GIL inside the C call).  What is measured is how much slower a thread gets when all cores run (memory bandwidth, clocks):
-    wall time of the concurrent runs against the single-thread model F + c * bins for the same sample.  The all-core rate quoted
-    is single-thread rate x threads x that efficiency, i.e. a run that splits the 16384 bins (and their share of the prefix filter)
-    evenly over the threads."""
+def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, nb_sample, sample_targets):
+    """The same port on all usable host cores as an actual run split over the bins (bins are independent): the
+    sample's bins are dealt to one thread per core in contiguous ranges, every thread runs the reference's linear traversal --
+    guide x bin prefix filter + block compare -- over ITS bins only (oracle/ff_oracle.c: ffo_discover_bin_range; ctypes releases the
+    GIL inside the C call) and the wall time of the slowest thread is what counts.  A full run over the 16384 bins splits the same
+    way, so the rate of the sample is the rate of the full run."""
     import ctypes
     import threading
     from flashfry_amd import capi
-    from tests import oracle_lib
     threads = max(1, int(capi.load_library().ffh_host_threads()))
-    bins_each = int(max(4, min(64, 4.0 / max(per_bin, 1e-6))))   # ~4 s of scan per thread on top of the filter
     lib = oracle.lib
     g = np.ascontiguousarray(guides_np, dtype=np.uint64)
     gp = g.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
-    dbs = [run.build(bins_each) for _ in range(threads)]          # every thread owns a database object (same sample)
+    nb = max(threads, nb_sample)
+    odb = run.build(nb)
+    cuts = [nb * t // threads for t in range(threads + 1)]
     times = [0.0] * threads
 
     def work(k):
         t0 = time.perf_counter()
-        r = lib.ffo_discover(dbs[k].h, gp, len(g), max_mm, max_ot, 0)
+        r = lib.ffo_discover_bin_range(odb.h, gp, len(g), max_mm, max_ot, cuts[k], cuts[k + 1])
         times[k] = time.perf_counter() - t0
         if r:
             lib.ffo_result_free(r)
@@ -161,13 +161,12 @@ def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single_rate, 
     for t in ts:
         t.join()
     wall = time.perf_counter() - t0
-    model = filt + per_bin * bins_each
-    eff = min(1.0, model / max(wall, 1e-9))
-    return {"value": single_rate * threads * eff, "unit": "guide*target comparisons/s", "cores": threads, "kind": "port",
-            "sample": "oracle/ff_oracle.c, %d threads (the usable cores of this box) each running the single-thread sample of %d bins at the same "
-                      "time: %.2f s wall against %.2f s for one thread alone -> parallel efficiency %.2f; value = single-thread rate x threads x efficiency"
-                      % (threads, bins_each, wall, model, eff),
-            "seconds": wall, "parallel_efficiency": eff}
+    rate = len(g) * odb.sample_targets / wall
+    return {"value": rate, "unit": "guide*target comparisons/s", "cores": threads, "kind": "port",
+            "sample": "oracle/ff_oracle.c, a run split over the bins: %d threads (the usable cores of this box), each running the reference's linear traversal "
+                      "(prefix filter + block compare) over its contiguous share of the first %d of 16384 bins (%d targets), all %d guides: %.2f s wall "
+                      "(slowest thread %.2f s, fastest %.2f s)" % (threads, nb, odb.sample_targets, len(g), wall, max(times), min(times)),
+            "seconds": wall, "projected_full_run_seconds": wall * 16384.0 / nb}
 
 
 def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max_ot, budget_s):
@@ -237,7 +236,7 @@ def cpu_baseline(targets_dev, pos_off_dev, positions_dev, guides_np, max_mm, max
     except Exception as e:
         _CPU_JVM = {"value": None, "unit": "guide*target comparisons/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
     try:  # SURVEY.md section 8d also asks for the port on all host cores (bins are independent: one thread per bin range)
-        _CPU_MT = cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, single, filt, per_bin)
+        _CPU_MT = cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, nb, idx)
     except Exception as e:
         _CPU_MT = {"value": None, "unit": "guide*target comparisons/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     return {"value": G * (idx / nb) * n_bins / full_run, "unit": "guide*target comparisons/s", "cores": 1, "kind": "port",

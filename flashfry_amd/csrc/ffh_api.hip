@@ -1149,6 +1149,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             }
             ctx->tm.pairs_prefix += cnt[kStatPairs]; ctx->tm.pairs_suffix += cnt[kStatPairs + 1];
             float a = 0, b = 0;
+            FFH_HIP(hipEventSynchronize(ctx->ev[4]));   // (complete on the device -- the counters behind it have arrived -- but the event itself may not be marked yet)
             FFH_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
             FFH_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
             ms_prep += a; ms_cmp += b;
@@ -1192,7 +1193,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(hipGetLastError());
         uint32_t still = 0;
         FFH_HIP(hipMemcpyAsync(&still, ctx->g_pos.p + n_guides, 4, hipMemcpyDeviceToHost, st));
-        FFH_HIP(hipStreamSynchronize(st));
+        FFH_HIP(spin_wait(ctx, nullptr));
         ctx->tm.retired_guides = n_guides - still;
         act_guides = ctx->g_active.p; act_map = ctx->g_map.p; n_act = still;
     }
@@ -1404,6 +1405,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         if (e != hipSuccess) { ctx->err = std::string("finalize: ") + hipGetErrorString(e); delete r; return FFH_E_HIP; }
         r->offsets_pending = true;
         float ms = 0;
+        (void)hipEventSynchronize(ctx->ev[1]);
         (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
         ctx->tm.finalize_ms = ms;
         finish_scan_timings(ctx);

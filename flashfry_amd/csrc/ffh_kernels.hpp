@@ -16,6 +16,10 @@
 
 namespace ffh {
 
+// A value every lane of the wave holds equal, said so: the compiler cannot see that threadIdx.x >> 6 (or anything loaded through it) is
+// wave-uniform, and without this it predicates every loop over a wave's segment per lane
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 struct Geometry {      // how the compared bases sit inside the 48-bit string field
     int c0;            // plane bit of the LAST compared base (Cas9: 3, Cpf1: 0)
     int lc;            // number of compared bases (20, or 19 for the 19-mer enzymes)
@@ -116,7 +120,7 @@ __global__ void k_bucket_first(const uint64_t *__restrict__ targets, uint64_t n,
 __global__ __launch_bounds__(256) void k_group_build_direct(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ first,
                                                             const uint64_t *__restrict__ targets, Geometry geo, int width, uint32_t nb, uint32_t R, uint32_t GW,
                                                             uint32_t *__restrict__ gwords, uint32_t *__restrict__ ddelta) {
-    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6);
     if (b >= nb) return;
     const uint32_t nt = bstart[b + 1] - bstart[b], g0 = gstart[b], ngr = gstart[b + 1] - g0;
     const uint32_t k0 = nt ? first[b] : 0u;
@@ -151,7 +155,7 @@ __global__ void k_group_count(const uint32_t *__restrict__ bstart, uint32_t nb, 
 __global__ __launch_bounds__(256) void k_group_build(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ keys,
                                                      const uint32_t *__restrict__ tidx_in, uint32_t nb, uint32_t R, uint32_t GW, uint32_t *__restrict__ gwords,
                                                      uint32_t *__restrict__ tidx_out) {
-    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, b = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6);
     if (b >= nb) return;
     const uint32_t k0 = bstart[b], nt = bstart[b + 1] - k0, g0 = gstart[b], ngr = gstart[b + 1] - g0;
     for (uint32_t c = 0; 2 * c < ngr; ++c) {
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__rest
 // one wave per partition, the lanes stride over the patterns (a thread per partition left 4096 threads walking 529 patterns each: 36 us)
 __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig,
                                                     uint32_t *__restrict__ part_count) {
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= ig.n_part) return;
     uint32_t n = 0;
     for (uint32_t p = lane; p < ig.n_pat; p += 64) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
@@ -485,17 +489,18 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint3
     const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits, lowmask = nlow - 1u;
     const uint32_t part_lo = ig.range[0] >> ig.low_bits, part_hi = ig.range[1] >> ig.low_bits;
     const bool live = d >= part_lo && d <= part_hi;   // partitions without a target take no entries
-    // The patterns are in numeric order, so the ones that share their partition bits -- and with them the source run q ^ high(p) --
-    // are neighbours.  A wave walks a contiguous slice of the patterns; its lanes take the guides of the source run side by side
-    // (coalesced, and L1-hot for the next pattern of the same run).  fn(low bucket bits, guide).
+    // virtual threads = (pattern, slice of the source run): S slices per pattern keep the block busy when there are few patterns.
+    // (A wave per slice of the patterns with its lanes side by side on the source run -- coalesced reads -- was measured too: 318
+    // against 210 us for the hg38-scale prefix image; the runs are short (~24 guides) and a wave then walks ~33 patterns one after
+    // the other.)  fn(low bucket bits, guide).
+    const uint32_t S = max(1u, (2u * (uint32_t)kPartThreads) / max(ig.n_pat, 1u)), V = ig.n_pat * S;
     auto enumerate = [&](auto &&fn) {
         if (!live) return;
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kPartThreads / 64;
-        const uint32_t per_w = (ig.n_pat + nw - 1) / nw, pa = wave * per_w, pb = min(ig.n_pat, pa + per_w);
-        for (uint32_t p = pa; p < pb; ++p) {
+        for (uint32_t v = threadIdx.x; v < V; v += kPartThreads) {
+            const uint32_t p = v / S, sl = v - p * S;
             const uint32_t pat = patterns[p], src = d ^ (pat >> ig.low_bits), plo = pat & lowmask;
             const uint32_t k1 = gp_start[src + 1];
-            for (uint32_t k = gp_start[src] + lane; k < k1; k += 64) {
+            for (uint32_t k = gp_start[src] + sl; k < k1; k += S) {
                 const uint32_t rec = by_part[k], low = (rec >> kGidBits) ^ plo;
                 if (SLAB) {
                     const uint32_t r = bucket_rank((d << ig.low_bits) | low, ig.width);
@@ -618,9 +623,9 @@ __global__ __launch_bounds__(256) void k_cutoff(const uint32_t *__restrict__ seg
                                                 const uint32_t *__restrict__ prior, uint32_t n_guides, uint32_t overflow, uint32_t *__restrict__ n_ret,
                                                 uint32_t *__restrict__ ot_count, uint32_t *__restrict__ full, uint32_t *__restrict__ totals,
                                                 uint32_t *__restrict__ pre /* nullable: per kept hit, the guide's kept positions before it */) {
-    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6);
     if (g >= n_guides) return;
-    const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
+    const uint32_t b = wave_uniform(seg_begin[g]), e = wave_uniform(seg_end[g]), p0 = wave_uniform(prior ? prior[g] : 0u);
     uint32_t run = p0, kept = 0;
     for (uint32_t i = b; i < e && run < overflow; i += 64) {
         const bool in = i + lane < e;
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) void k_cutoff(const uint32_t *__restrict__ seg
         if (pre && keep) pre[i + lane] = run - p0 + (incl - c);
         const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
         kept += nk;
-        if (nk) run += __shfl(incl, nk - 1, 64);
+        if (nk) run += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(nk - 1u));   // (nk is a ballot's popcount: uniform)
     }
     if (lane == 0) {
         if (totals) totals[g] = min(run, overflow);
@@ -810,10 +815,10 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
                                                          const double *__restrict__ hsu, const double *__restrict__ jost /* may be null */,
                                                          uint32_t n_guides, GuideSummary *__restrict__ out) {
     __shared__ WalkLds wk;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
+    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
-    const uint32_t n = n_ret[g];
-    const uint64_t b = ret_off[g];
+    const uint32_t n = wave_uniform(n_ret[g]);
+    const uint64_t b = ((uint64_t)wave_uniform((uint32_t)(ret_off[g] >> 32)) << 32) | wave_uniform((uint32_t)ret_off[g]);
     uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, n_scored = 0;
     double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
     for (uint32_t i = 0; i < n; i += 64) {  // pass 1: histogram, closest level, ordered f64 sums
@@ -884,9 +889,9 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     }
     __shared__ WalkLds wk;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
+    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
-    const uint32_t b = seg_begin[g], e = seg_end[g], p0 = prior ? prior[g] : 0u;
+    const uint32_t b = wave_uniform(seg_begin[g]), e = wave_uniform(seg_end[g]), p0 = wave_uniform(prior ? prior[g] : 0u);
     // multi-GPU fix-up pass: a shard's own aggregates (computed with prior 0) stand unless the positions of the shards before it
     // push this guide's running total to the limit inside or before this shard
     if (fix_totals && !(p0 > 0u && p0 + fix_totals[g] >= overflow)) return;
@@ -902,7 +907,7 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         const bool keep = in && (run + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
         const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
         kept += nk;
-        if (nk) run += __shfl(incl, nk - 1, 64);
+        if (nk) run += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(nk - 1u));   // (nk is a ballot's popcount: uniform)
         int mmi = 0xFF;
         double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
         if (keep) {

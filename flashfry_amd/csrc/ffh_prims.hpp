@@ -346,9 +346,11 @@ constexpr int kSegRows = kSegWaveMax / 64;
 __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end,
                                                  uint32_t n_guides, int tbits, uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ n_heavy) {
     __shared__ __attribute__((aligned(16))) uint32_t low[4][kSegWaveMax];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.x * 4 + wave;
+    // (wave, segment bounds and everything derived from them are wave-uniform: said explicitly, or the compiler predicates every loop
+    // below per lane and turns v_readlane into a waterfall)
+    const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), g = blockIdx.x * 4 + wave;
     if (g >= n_guides) return;
-    const uint32_t b = seg_begin[g], n = seg_end[g] - b;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_begin[g]), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg_end[g]) - b;
     if (n <= 1u) return;
     if (n > kSegWaveMax) {
         if (lane == 0) heavy_list[atomicAdd(n_heavy, 1u)] = g;

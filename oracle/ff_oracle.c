@@ -588,6 +588,49 @@ ffo_result *ffo_discover(const ffo_db *db, const uint64_t *guides, int n_guides,
     return res;
 }
 
+/* The linear traversal (LinearTraversal.next :82-97 + LinearTraverser.scan :94-100) over the bins [bin_begin, bin_end) only: what one
+ * worker of a run split over the bins does (SURVEY.md section 8d asks for the CPU port on all host cores: bins are independent, a
+ * worker filters and scans its own range).  The cut-off applies within the range; a throughput baseline, not a result path. */
+ffo_result *ffo_discover_bin_range(const ffo_db *db, const uint64_t *guides, int n_guides, int max_mm, int max_ot, int bin_begin, int bin_end) {
+    const ffo_pack *p = db->pack;
+    int nb = db->n_bins, w = db->bin_width;
+    if (bin_begin < 0) bin_begin = 0;
+    if (bin_end > nb) bin_end = nb;
+    ffo_result *res = (ffo_result *)calloc(1, sizeof *res);
+    res->n = n_guides;
+    res->saturated = 1;
+    res->guides = (ffo_guide_ot *)calloc((size_t)(n_guides > 0 ? n_guides : 1), sizeof(ffo_guide_ot));
+    for (int i = 0; i < n_guides; i++) { res->guides[i].encoding = guides[i]; res->guides[i].overflow = max_ot; }
+    ffo_agg agg = {res->guides, n_guides, NULL, NULL};
+    block_manager bm;
+    block_manager_init(&bm, p, w, 4, n_guides);
+    linear_trav lt;
+    lt.guides_to_use = (int *)malloc(sizeof(int) * (size_t)(n_guides > 0 ? n_guides : 1));
+    lt.n_use = n_guides;
+    for (int i = 0; i < n_guides; i++) lt.guides_to_use[i] = i;
+    agg.overflow_cb = linear_overflow;
+    agg.cb_ctx = &lt;
+    int *run = (int *)malloc(sizeof(int) * (size_t)(n_guides > 0 ? n_guides : 1));
+    int rc = 0;
+    char name[16];
+    for (int b = bin_begin; b < bin_end && rc == 0; b++) {
+        ffo_bin_and_mask bam;
+        ffo_bin_name(w, (uint32_t)b, name);
+        ffo_bin_to_long_comparitor(p, name, w, 0, &bam);
+        int m = 0;
+        for (int i = 0; i < lt.n_use; i++)
+            if (ffo_mismatch_bin(p, &bam, guides[lt.guides_to_use[i]]) <= max_mm) run[m++] = lt.guides_to_use[i];
+        const ffo_bin *bin = &db->bins[b];
+        if (!bin->longs) { ffo_set_error("bin %d missing from database", b); rc = -20; break; }
+        rc = compare_block(&bm, bin->longs, bin->n_longs, run, m, &agg, max_mm, &bam);
+    }
+    free(run);
+    free(lt.guides_to_use);
+    block_manager_free(&bm);
+    if (rc) { ffo_result_free(res); return NULL; }
+    return res;
+}
+
 void ffo_result_free(ffo_result *r) {
     if (!r) return;
     for (int i = 0; i < r->n; i++) {

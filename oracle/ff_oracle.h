@@ -112,6 +112,9 @@ typedef struct ffo_result ffo_result;
  * sort by start, ResultsAggregator.scala:35, only changes output row order -- applied by ffo_discover_fasta) */
 ffo_result *ffo_discover(const ffo_db *db, const uint64_t *guides, int n_guides,
                          int max_mismatch, int max_offtargets, int force_linear);
+/* one worker of a run split over the bins: the linear traversal over [bin_begin, bin_end) only (CPU baseline on all host cores) */
+ffo_result *ffo_discover_bin_range(const ffo_db *db, const uint64_t *guides, int n_guides, int max_mismatch, int max_offtargets,
+                                   int bin_begin, int bin_end);
 void        ffo_result_free(ffo_result *r);
 int         ffo_result_n_guides(const ffo_result *r);
 int         ffo_result_saturated(const ffo_result *r);      /* traversal mode actually used: 1 linear, 0 seek */

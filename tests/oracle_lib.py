@@ -85,6 +85,8 @@ class Oracle:
         L.ffo_last_error.restype = C.c_char_p
         L.ffo_discover.restype = C.c_void_p
         L.ffo_discover.argtypes = [C.c_void_p, u64p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ffo_discover_bin_range.restype = C.c_void_p
+        L.ffo_discover_bin_range.argtypes = [C.c_void_p, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ffo_result_free.argtypes = [C.c_void_p]
         L.ffo_result_n_guides.argtypes = [C.c_void_p]
         L.ffo_result_saturated.argtypes = [C.c_void_p]
