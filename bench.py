@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: split one hg38-sized database (strong) or give every rank its own (weak)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-verification and the list-delivering discover after the timed loop")
     ap.add_argument("--no-skewed", action="store_true", help="skip the second workload (repeat-structured genome, guides sampled from it)")
+    ap.add_argument("--no-c2", action="store_true", help="skip the chr22-scale leg (configs[1]: 1000 guides, resident step + CLI wall time)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure the compare kernel's HBM traffic")
     ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"), help="where the PMC passes write their CSVs")
     return ap.parse_args()
@@ -531,7 +532,15 @@ def main():
         verify_db = None
         torch.cuda.empty_cache()
 
-    skewed, real_genome = None, None
+    skewed, real_genome, c2 = None, None, None
+    if rank == 0 and world == 1 and not args.no_c2:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_legs
+            from flashfry_amd import _build
+            c2 = bench_legs.c2_leg(torch, capi, synth, local, args.max_mismatch, args.max_offtargets, cli=_build.CLI)
+        except Exception as e:  # a reported extra, never a reason to lose the measurement
+            c2 = {"error": repr(e)}
     if rank == 0 and world == 1:
         if not args.no_skewed:
             try:
@@ -629,6 +638,8 @@ def main():
             "hits": {"raw": raw_hits, "raw_per_guide": raw_hits / max(G, 1), "kept_positions": kept_pos, "overflowed_guides": int(final["overflow"].sum())},
             "algorithmic_bytes_survey": b_survey,
             "skewed": skewed,
+            # BASELINE.json configs[1] / SURVEY.md section 8d: the chr22-scale step and the CLI's wall time from argv to the closed table
+            "c2": c2,
             "real_genome": real_genome,
         }
     else:

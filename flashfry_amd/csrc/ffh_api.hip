@@ -943,13 +943,16 @@ __global__ void k_slab_cuts(const uint64_t *__restrict__ targets, uint64_t n, in
 
 static void drop_slabs(ffh_ctx *ctx) { ctx->slab_img.clear(); ctx->slab_t.clear(); ctx->slabs_state = 0; }
 
+// (round 3: eight slabs whose ends double -- 1/64, 1/32, 1/16, 1/8, 1/4, 1/2, 3/4, 1 of sequence space -- now that a slab costs a
+// suffix candidate list and a work-list filter instead of a second enumeration of the prefix candidates: a guide leaves at most
+// ~2 x the hits its cut-off keeps; the figures below are round 2's, with the six slabs it had)
 // slab k = the targets whose first three bases rank in [kSlabRank[k], kSlabRank[k + 1]): 1/64, 3/64, 1/8, 3/16, 1/4 and 3/8 of
 // sequence space.  A guide with H hits spread like the genome is retired after the first slab boundary beyond 2000/H of it, so it
 // leaves at most ~1.6 x the hits its cut-off keeps plus one slab's worth; a guide of a million-copy family leaves 1/64 of them.
 // On the repeat-structured bench workload (2.5e8 raw hits unbounded): 3 slabs {1, 8} 1.43e8 raw hits / 16.5 ms per step,
 // 4 slabs {1, 8, 32} 7.0e7 / 15.2 ms, these 6 slabs 4.7e7 / 13.7 ms (19.1 ms unbounded); every slab costs ~0.8 ms of its own
 // (candidate binning with a counting pass, ordering and totals of its hits, two round trips).
-static const uint32_t kSlabRank[7] = {0u, 1u, 4u, 12u, 24u, 40u, 64u};
+static const uint32_t kSlabRank[9] = {0u, 1u, 2u, 4u, 8u, 16u, 32u, 48u, 64u};
 
 static int ensure_slabs(ffh_ctx *ctx) {
     if (ctx->slabs_state) return FFH_OK;   // 1 = built, -1 = this database cannot be bounded
@@ -1064,7 +1067,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // typical run fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); k_work_count / k_work_fill then list the
     // runs that have candidates, a bucket larger than the strip as several strip-sized group ranges.  Candidate lists larger than the
     // strip take the kernel's piecewise path.
-    auto side_plan = [&](int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S) -> int {
+    auto side_plan = [&](int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S,
+                         uint32_t rank_lo = 0u, uint32_t rank_hi = 63u, bool count_pairs = true) -> int {
         S = SideArgs{};
         S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.direct ? nullptr : im.tidx.p; S.dd_off = im.direct ? S_nb_plus_1(width) : 0u; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
         S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
@@ -1080,10 +1084,11 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_bat)));
         hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
-                           ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, ctx->n_part[which], ctx->d_counters + kStatPairs + which);
+                           ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u,
+                           ctx->d_counters + kStatPairs + which, rank_lo, rank_hi, (uint32_t)width);
         exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->scan_tmp32.p, st);
         hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
-                           ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which);
+                           ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which, rank_lo, rank_hi, (uint32_t)width);
         S.list = ctx->wl_list[which].p;
         S.n_list = ctx->wl_off[which].p + n_bat;
         return FFH_OK;
@@ -1101,6 +1106,18 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(ctx->g_active.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->g_map.reserve((size_t)n_guides + 1)); FFH_HIP(ctx->totals.reserve((size_t)n_guides + 1));
         FFH_HIP(hipMemsetAsync(ctx->g_total.p, 0, (size_t)n_guides * 4, st));
     }
+    // A bounded scan builds the prefix image's candidate list ONCE, for all guides and all slabs (a slab then is a filter on the
+    // work list; a retired guide is made unreachable in the guide table: k_bound_update) instead of enumerating it again, with a
+    // counting pass, for every slab.  Needs the whole guide set in one batch and maxMismatch + r1 < prefix width (true of every
+    // two-image plan the cost model picks); otherwise the prefix side is binned per slab on the packed active set.
+    const bool shared_prefix = bounded && n_guides <= batch && max_mm + plan.r1 < plan.a &&
+                               !(getenv("FFH_SLAB_PREFIX") && std::strcmp(getenv("FFH_SLAB_PREFIX"), "per-slab") == 0);
+    const uint64_t n_items_p_all = (uint64_t)n_guides * (uint64_t)np_p;
+    if (shared_prefix) {
+        FFH_HIP(ctx->item_gid.reserve(n_items_p_all + (uint64_t)n_guides * (uint64_t)np_s + 64));
+        const int rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, ctx->guides.p, -1, n_guides, 0u);
+        if (rc) return rc;
+    }
     for (size_t sl = 0; sl < slabs.size() && n_act; ++sl) {
         const Slab &SL = slabs[sl];
         const unsigned long long slab_start = cursor_before;
@@ -1112,20 +1129,26 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
             FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
             FFH_HIP(hipEventRecord(ctx->ev[2], st));
-            int rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
-            if (rc) return rc;
+            int rc = FFH_OK;
+            if (!shared_prefix) {
+                rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
+                if (rc) return rc;
+            }
             if (plan.r2 >= 0) {
-                rc = prepare_side(ctx, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)n_items_p);
+                rc = prepare_side(ctx, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
                 if (rc) return rc;
             }
             FFH_HIP(hipEventRecord(ctx->ev[3], st));
             CompareArgs ca{};
-            rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
+            if (shared_prefix) rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
+            else rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
             if (rc) return rc;
             if (plan.r2 >= 0) { rc = side_plan(1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]); if (rc) return rc; }   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
             else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
-            ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.guide_base = g0; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
-            ca.gmap = act_map ? act_map + g0 : nullptr;
+            ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
+            ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
+            ca.gmap[0] = shared_prefix ? nullptr : (act_map ? act_map + g0 : nullptr);
+            ca.gmap[1] = act_map ? act_map + g0 : nullptr;
             launch_compare(ca, ctx->d_counters, ctx->compare_grid, st);
             FFH_HIP(hipGetLastError());
             FFH_HIP(hipEventRecord(ctx->ev[4], st));
@@ -1185,7 +1208,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         }
         hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(n_guides, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, (const uint64_t *)ctx->hit_t.p, (const uint32_t *)nullptr,
                            n_guides, bound_ot, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ctx->totals.p, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_bound_update, dim3(blocks_for(n_guides, 256)), dim3(256), 0, st, ctx->g_total.p, (const uint32_t *)ctx->totals.p, n_guides, bound_ot, ctx->g_flag.p);
+        hipLaunchKernelGGL(k_bound_update, dim3(blocks_for(n_guides, 256)), dim3(256), 0, st, ctx->g_total.p, (const uint32_t *)ctx->totals.p, n_guides, bound_ot, ctx->g_flag.p,
+                           shared_prefix ? ctx->gtab[0].p : (uint2 *)nullptr, plan.a >= 16 ? 0xFFFFFFFFu : (1u << (2 * plan.a)) - 1u);
         FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_guides)));
         exclusive_scan<uint32_t, uint32_t>(ctx->g_flag.p, n_guides, ctx->g_pos.p, ctx->scan_tmp32.p, st);
         hipLaunchKernelGGL(k_bound_compact, dim3(blocks_for(n_guides, 256)), dim3(256), 0, st, (const uint64_t *)ctx->guides.p, (const uint32_t *)ctx->g_flag.p,

@@ -101,12 +101,12 @@ struct CompareArgs {
     const uint32_t *gids;     // candidate CSR of both sides
     uint64_t *hits;
     uint64_t cap;
-    uint32_t guide_base;      // first guide of this batch of guides
+    uint32_t guide_base[2];   // per side: first guide of this batch of guides in the caller's array
     int tbits;                // hit key = (global guide << tbits) | database index
     int max_mm;
-    uint32_t pad;
-    const uint32_t *gmap;     // nullable: number, in the caller's guide array, of every guide of this batch (a bounded scan's later
-                              // slabs run on the packed set of guides still active); null = guide_base + position in the batch
+    const uint32_t *gmap[2];  // per side, nullable: number, in the caller's guide array, of every guide of the side's candidate list (a
+                              // bounded scan's later slabs run the suffix image on the packed set of guides still active, the prefix
+                              // image on all guides with the retired ones made unreachable); null = guide_base + position
 };
 
 // before every compare launch: clears the per-launch statistics words (one launch in place of a memset)
@@ -185,8 +185,8 @@ struct HitStage {
         uint64_t *__restrict__ hits = A->hits;
         const uint64_t cap = A->cap;
         const uint32_t *__restrict__ tidx_p = A->side[0].tidx, *__restrict__ tidx_s = A->side[1].tidx;
-        const uint32_t guide_base = A->guide_base;
-        const uint32_t *__restrict__ gmap = A->gmap;
+        const uint32_t base_p = A->guide_base[0], base_s = A->guide_base[1];
+        const uint32_t *__restrict__ gmap_p = A->gmap[0], *__restrict__ gmap_s = A->gmap[1];
         const int tbits = A->tbits;
         const unsigned long long old_pos = chunk_pos;
         const uint32_t old_left = chunk_left;
@@ -217,7 +217,10 @@ struct HitStage {
                 uint32_t ti = slot;
                 if (sfx && tidx_s) ti = tidx_s[slot];
                 if (!sfx && tidx_p) ti = tidx_p[slot];
-                const uint32_t g = gmap ? gmap[(uint32_t)(h >> 32)] : (uint32_t)(h >> 32) + guide_base;
+                const uint32_t gl = (uint32_t)(h >> 32);
+                uint32_t g = gl + (sfx ? base_s : base_p);
+                if (sfx && gmap_s) g = gmap_s[gl];
+                if (!sfx && gmap_p) g = gmap_p[gl];
                 hits[dst] = ((uint64_t)g << tbits) | ti;
             }
         }
@@ -343,14 +346,25 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
 //   k_work_fill   the entries.  A call with a handful of guides lists a few hundred batches instead of making every wave walk all
 //                 4^11 buckets' boundaries; a bucket of 1e5 targets becomes ~100 entries dealt to ~100 waves.
 // ---------------------------------------------------------------------------------------------------------
+// One slab of a bounded scan on the prefix image, whose candidate CSR is built ONCE for all slabs: the batch's buckets that belong to
+// the slab (first three bases ranked lo .. hi in sequence order: bucket_rank).  The rank changes every 4^(width - 3) bucket ids, a
+// batch has at most kMaxNB of them, so the slab's part of a batch is one run [s0, s1).  lo = 0, hi = 63: the whole batch.
+__device__ __forceinline__ void slab_run(uint32_t b0, uint32_t b1, uint32_t lo, uint32_t hi, uint32_t width, uint32_t &s0, uint32_t &s1) {
+    s0 = b0; s1 = b1;
+    if (lo == 0u && hi >= 63u) return;
+    while (s0 < b1) { const uint32_t r = bucket_rank(s0, width); if (r >= lo && r <= hi) break; ++s0; }
+    s1 = s0;
+    while (s1 < b1) { const uint32_t r = bucket_rank(s1, width); if (r < lo || r > hi) break; ++s1; }
+}
 __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
                                                     uint32_t n_bat, uint32_t *__restrict__ counts, const unsigned long long *__restrict__ part_pairs,
-                                                    uint32_t n_part, unsigned long long *__restrict__ pairs_out) {
+                                                    uint32_t n_part, unsigned long long *__restrict__ pairs_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
     __shared__ unsigned long long red[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_bat) {
-        const uint32_t b0 = t * NB, b1 = min(nb, b0 + NB);
-        const uint32_t ngr = gstart[b1] - gstart[b0], nc = istart[b1] - istart[b0];
+        uint32_t s0, s1;
+        slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
+        const uint32_t ngr = gstart[s1] - gstart[s0], nc = istart[s1] - istart[s0];
         counts[t] = (ngr && nc) ? (ngr + split - 1u) / split : 0u;
     }
     if (blockIdx.x != 0) return;
@@ -364,15 +378,16 @@ __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__
     if (threadIdx.x == 0) atomicAdd(pairs_out, red[0] + red[1] + red[2] + red[3]);
 }
 __global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, const uint32_t *__restrict__ offs,
-                            uint4 *__restrict__ list, unsigned long long *__restrict__ n_out) {
+                            uint4 *__restrict__ list, unsigned long long *__restrict__ n_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_bat) return;
     const uint32_t o = offs[t], n = offs[t + 1] - o;
     if (t == n_bat - 1) *n_out = offs[n_bat];
     if (!n) return;
-    const uint32_t b0 = t * NB, b1 = min(nb, b0 + NB);
-    const uint32_t nbv = b1 - b0, gs = gstart[b0], ge = gstart[b1];
-    for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(b0, nbv, gs + k * split, min(ge, gs + (k + 1) * split));
+    uint32_t s0, s1;
+    slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
+    const uint32_t gs = gstart[s0], ge = gstart[s1];
+    for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(s0, s1 - s0, gs + k * split, min(ge, gs + (k + 1) * split));
 }
 
 // job -> bucket lookup of a parked piece: kMaxRows words of 64 marker bits, one bit per non-empty bucket at the job before its first

@@ -970,12 +970,18 @@ __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint
 // (crispr/ResultsAggregator.scala:61-69, LinearTraversal.scala:64-76).
 // ---------------------------------------------------------------------------------------------------------
 // total[g] += positions of the slab just scanned (both saturated at the limit); flag[g] = still below the limit
-__global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, uint32_t n, uint32_t limit, uint32_t *__restrict__ flag) {
+// gtab0 (nullable): the prefix image's guide table when its candidate list is shared by all slabs -- a guide that retires now gets
+// the COMPLEMENT of its bucket id there: against every bucket of its candidate list (its own id with <= r1 bases changed) the key
+// then differs in >= width - r1 bases, more than any maxMismatch a two-image plan runs with, so the compare kernel gives its jobs
+// no steps -- without a test of its own in the hot loop.
+__global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, uint32_t n, uint32_t limit, uint32_t *__restrict__ flag,
+                               uint2 *__restrict__ gtab0, uint32_t key_mask) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    const uint32_t t = min(limit, total[g] + min(limit, slab_total[g]));
+    const uint32_t before = total[g], t = min(limit, before + min(limit, slab_total[g]));
     total[g] = t;
     flag[g] = t < limit ? 1u : 0u;
+    if (gtab0 && before < limit && t >= limit) gtab0[g].y = ~gtab0[g].y & key_mask;
 }
 // the guides still active, packed: their longs and their numbers in the caller's guide array
 __global__ void k_bound_compact(const uint64_t *__restrict__ guides, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,

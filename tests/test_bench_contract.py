@@ -47,6 +47,8 @@ def test_single_gpu_line():
     assert d["executed_pair_tests_per_s"] > 0 and d["roofline"]["useful_valu_frac"] > 0
     assert d["skewed"] and "error" not in d["skewed"] and d["skewed"]["raw_hits"] > 0
     assert d["real_genome"] is None  # no FF_GENOME_FASTA on the box
+    c2 = d["c2"]                     # BASELINE.json configs[1]: the chr22-scale step and the CLI's wall time (BGZF database file -> table)
+    assert c2 and "error" not in c2 and "cli_error" not in c2 and c2["ms_per_step"] > 0 and c2["discover_wall_warm_s"] > 0 and c2["table_bytes"] > 1000, c2
 
 
 @pytest.mark.parametrize("scaling", ["strong", "weak"])

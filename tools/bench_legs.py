@@ -173,3 +173,63 @@ def fasta_leg(capi, n_guides, max_mm, max_ot, device=0, seed=12345):
                     "comparisons_per_s": n_guides * int(info.n_targets) / t_disc}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def c2_leg(torch, capi, synth, device, max_mm, max_ot, cli=None, steps=30):
+    """BASELINE.json configs[1] and SURVEY.md section 8d's chr22-scale line: 1 000 random NGG guides against a chr22-scale synthetic
+    database (4.5e6 unique targets), <= max_mm mismatches, one GPU.  (a) the resident step: aggregates only, and with the hit lists and
+    positions delivered; (b) `t_discover`: the drop-in CLI from argv to the closed output file on the same database WRITTEN TO DISK in
+    the reference's format (BGZF body + text header), first run (the file was just written: the kernel's page cache holds it, the
+    process pays header parse, BGZF member directory, device inflate, block decode, scan images) and median of three more."""
+    import subprocess
+    dev = torch.device("cuda", device)
+    G, T_req = 1000, int(4.5e6)
+    guides_dev = synth.make_guides(G, seed=synth.GUIDE_SEED + 2, device=dev)
+    db = synth.make_database(T_req, seed=synth.DB_SEED + 2, plant_guides=guides_dev, device=dev)
+    guides = guides_dev.cpu().numpy().view(np.uint64)
+    out = {"workload": "chr22-scale (BASELINE.json configs[1]): %d random NGG guides vs %d unique targets (%d positions), <=%d mismatches, maximumOffTargets %d, 1 GPU"
+                       % (G, db["T"], db["P"], max_mm, max_ot)}
+    with capi.Context(3, device=device) as ctx:
+        torch.cuda.synchronize()
+        ctx.load_soa_device(db["targets"].data_ptr(), db["T"], db["positions"].data_ptr(), db["P"])
+        out["db_prepare_ms"] = ctx.info().prepare_ms
+        for name, kw in (("ms_per_step", dict(summaries_only=True)), ("discover_with_lists_ms", dict(hit_scores=False))):
+            for _ in range(3):
+                ctx.discover(guides, max_mm, max_ot, **kw)
+            ts = []
+            for _ in range(steps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = ctx.discover(guides, max_mm, max_ot, **kw)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out[name] = float(np.median(ts))
+        tm = ctx.timings().as_dict()
+        out.update(value=G * db["T"] / (out["ms_per_step"] * 1e-3), unit="comparisons/s", raw_hits=int(tm["n_raw_hits"]), compare_ms=tm["compare_ms"],
+                   plan=[tm["prefix_bases"], tm["prefix_radius"], tm["suffix_radius"]], kept_positions=int(res.summaries["ot_count"].sum()))
+    if cli and os.path.exists(cli):
+        work = tempfile.mkdtemp(prefix="ffh_c2_")
+        try:
+            dbp = os.path.join(work, "db")
+            t0 = time.perf_counter()
+            capi.write_database(dbp, 3, db["targets"].cpu().numpy().view(np.uint64), db["positions"].cpu().numpy().view(np.uint64), synth.CONTIGS_24)
+            out["db_write_s"] = time.perf_counter() - t0
+            out["db_file_bytes"] = os.path.getsize(dbp)
+            fa = os.path.join(work, "guides.fasta")
+            write_guides_fasta(fa, guides)
+            walls = []
+            for k in range(4):
+                o = os.path.join(work, "out%d.tsv" % k)
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "discover", "--database", dbp, "--fasta", fa, "--output", o, "--maxMismatch", str(max_mm), "--maximumOffTargets", str(max_ot),
+                                    "--positionOutput"], capture_output=True, timeout=600)
+                walls.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    out["cli_error"] = r.stderr.decode()[-300:]
+                    break
+            if "cli_error" not in out:
+                out["discover_wall_first_s"] = walls[0]
+                out["discover_wall_warm_s"] = float(np.median(walls[1:]))
+                out["table_bytes"] = os.path.getsize(os.path.join(work, "out0.tsv"))
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return out
