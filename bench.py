@@ -114,7 +114,7 @@ VALU_CYCLES_HALF_RATE = 4.4
 def pair_step_valu(rest_bases, far):
     """VALU instructions of one bit-sliced step (64 lanes x 32 targets = 2048 pair tests) with `rest_bases` bases outside the bucket
     id: two per base for the mismatch words, the carry-save adder tree (one v_bitop3 per sum / per carry), four for count <= budget,
-    one for the valid word, four more for count > r1 on the suffix image"""
+    one for the valid word, two more for count > r1 on the suffix image (compile-time form of the per-plan kernel instances)"""
     n, ops = [rest_bases, 0, 0, 0], 0
     for lv in range(4):
         while n[lv] >= 3:
@@ -127,7 +127,7 @@ def pair_step_valu(rest_bases, far):
             ops += 2 if lv < 3 else 1
             if lv < 3:
                 n[lv + 1] += 1
-    return 2 * rest_bases + ops + 5 + (5 if far else 0)
+    return 2 * rest_bases + ops + 5 + (2 if far else 0)   # (the far condition is two v_bitop3 in the instances compiled for a plan: scan_row<R, FAR>)
 
 
 def cpu_baseline_all_cores(oracle, run, guides_np, max_mm, max_ot, nb_sample, sample_targets):

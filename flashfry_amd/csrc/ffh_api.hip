@@ -943,16 +943,16 @@ __global__ void k_slab_cuts(const uint64_t *__restrict__ targets, uint64_t n, in
 
 static void drop_slabs(ffh_ctx *ctx) { ctx->slab_img.clear(); ctx->slab_t.clear(); ctx->slabs_state = 0; }
 
-// (round 3: eight slabs whose ends double -- 1/64, 1/32, 1/16, 1/8, 1/4, 1/2, 3/4, 1 of sequence space -- now that a slab costs a
-// suffix candidate list and a work-list filter instead of a second enumeration of the prefix candidates: a guide leaves at most
-// ~2 x the hits its cut-off keeps; the figures below are round 2's, with the six slabs it had)
+// (round 3 tried eight slabs whose ends double -- 1/64, 1/32, ... 1/2, 3/4, 1 -- once a slab no longer re-enumerated the prefix
+// candidates: the same 4.8e7 raw hits on the repeat-structured workload -- the guides that overshoot do so inside the FIRST slab, a
+// 64th of a million-copy family is 15 000 hits -- and 1.1 ms more in two more compare launches; six slabs stay)
 // slab k = the targets whose first three bases rank in [kSlabRank[k], kSlabRank[k + 1]): 1/64, 3/64, 1/8, 3/16, 1/4 and 3/8 of
 // sequence space.  A guide with H hits spread like the genome is retired after the first slab boundary beyond 2000/H of it, so it
 // leaves at most ~1.6 x the hits its cut-off keeps plus one slab's worth; a guide of a million-copy family leaves 1/64 of them.
 // On the repeat-structured bench workload (2.5e8 raw hits unbounded): 3 slabs {1, 8} 1.43e8 raw hits / 16.5 ms per step,
 // 4 slabs {1, 8, 32} 7.0e7 / 15.2 ms, these 6 slabs 4.7e7 / 13.7 ms (19.1 ms unbounded); every slab costs ~0.8 ms of its own
 // (candidate binning with a counting pass, ordering and totals of its hits, two round trips).
-static const uint32_t kSlabRank[9] = {0u, 1u, 2u, 4u, 8u, 16u, 32u, 48u, 64u};
+static const uint32_t kSlabRank[7] = {0u, 1u, 4u, 12u, 24u, 40u, 64u};
 
 static int ensure_slabs(ffh_ctx *ctx) {
     if (ctx->slabs_state) return FFH_OK;   // 1 = built, -1 = this database cannot be bounded

@@ -13,7 +13,7 @@ timeline) timeout 300 bash tools/timeline.sh > $O/timeline_step.txt 2>&1; timeou
 shard)  for n in 2 4 8; do timeout 300 python tools/shard_step.py --shards $n --rank $((n/2)) 2>/dev/null | tail -1; done | tee $O/shard_step.txt ;;
 grid)   timeout 900 python tools/timing_grid.py --out $O/timing_grid.json > $O/timing_grid.md 2> $O/timing_grid.err; tail -22 $O/timing_grid.md ;;
 bulge)  timeout 600 python tools/bulge_scale.py --guides 10000 --brute-guides 300 --out $O/bulge_scale.json 2>&1 | tail -4 ;;
-cli)    timeout 900 python tools/cli_wall.py --out $O/cli_wall_chr22_scale.json 2>&1 | tail -3; timeout 1500 python tools/cli_wall.py --mbases 3100 --contigs 24 --guides 100000 --out $O/cli_wall_hg38_scale.json 2>&1 | tail -3 ;;
+cli)    timeout 900 python tools/cli_wall.py --out $O/cli_wall_chr22_scale.json 2>&1 | tail -3; timeout 1500 python tools/cli_wall.py --mbases 3100 --contigs 24 --big-guides 100000 --out $O/cli_wall_hg38_scale.json 2>&1 | tail -3 ;;
 ingest) timeout 900 python tools/ingest_scale.py --out $O/ingest_hg38_scale.json 2>&1 | tail -3 ;;
 c2)     timeout 300 python bench.py --targets 4.5e6 --guides 1000 --steps 50 --warmup 5 --cpu-seconds 10 --no-skewed --no-c2 > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 1500 $O/bench_c2.json ;;
 stress) timeout 1300 python tools/stress_parity.py 1200 > $O/stress_parity.txt 2>&1; tail -3 $O/stress_parity.txt ;;
