@@ -72,7 +72,7 @@ def measure_traffic(args):
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d, exist_ok=True)
         cmd = [prof, "--kernel-trace", "--pmc"] + counters + ["--kernel-include-regex", "k_compare<|k_image_hist", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic", "--no-verify", "--no-skewed",
+               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-traffic", "--no-verify", "--no-skewed", "--no-c2",
                "--targets", str(args.targets), "--guides", str(args.guides), "--max-mismatch", str(args.max_mismatch), "--max-offtargets", str(args.max_offtargets)]
         env = dict(os.environ, TMPDIR="/tmp")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=300)  # a pass takes ~40 s; a hung profiler must not hold the bench

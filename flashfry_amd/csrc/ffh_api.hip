@@ -132,6 +132,7 @@ struct ffh_result {
     uint64_t n_hits = 0, n_positions = 0;
     bool offsets_pending = false;      // aggregates-only result: guide_offsets / n_hits are folded from the summaries when first asked for
     bool pos_offsets_pending = false;  // pos_offsets are folded from the counts in the hit target longs when first asked for
+    std::once_flag offsets_once, pos_offsets_once;   // the accessors may be called from several host threads at once (the CLI formats rows in parallel)
     int scores_valid = 0;
     // the arrays live in two pinned blocks owned by the context's pool: everything per guide and per hit, and the positions
     // (whose number is known only after the per-hit arrays are on their way to the host)
@@ -1587,11 +1588,12 @@ uint32_t ffh_result_n_guides(const ffh_result *r) { return r->n_guides; }
 static void settle_offsets(const ffh_result *cr) {
     ffh_result *r = const_cast<ffh_result *>(cr);
     if (!r->offsets_pending) return;
-    r->offsets_pending = false;
-    uint64_t run = 0;
-    for (uint32_t g = 0; g < r->n_guides; ++g) { r->guide_offsets[g] = run; run += r->summaries[g].n_hits; }
-    r->guide_offsets[r->n_guides] = run;
-    r->n_hits = run;
+    std::call_once(r->offsets_once, [r] {
+        uint64_t run = 0;
+        for (uint32_t g = 0; g < r->n_guides; ++g) { r->guide_offsets[g] = run; run += r->summaries[g].n_hits; }
+        r->guide_offsets[r->n_guides] = run;
+        r->n_hits = run;
+    });
 }
 uint64_t ffh_result_n_hits(const ffh_result *r) { settle_offsets(r); return r->n_hits; }
 uint64_t ffh_result_n_positions(const ffh_result *r) { return r->n_positions; }
@@ -1605,22 +1607,25 @@ const double *ffh_result_hit_cfd(const ffh_result *r) { return r->hit_cfd; }
 static void settle_pos_offsets(const ffh_result *cr) {
     ffh_result *r = const_cast<ffh_result *>(cr);
     if (!r->pos_offsets_pending) return;
-    r->pos_offsets_pending = false;
-    const uint64_t H = r->n_hits;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = (unsigned)std::min<uint64_t>(std::min(8u, hw), H / 262144 + 1);
-    std::vector<uint64_t> part(nt + 1, 0);
-    auto slice = [&](unsigned t, uint64_t &a, uint64_t &b) { a = H * t / nt; b = H * (t + 1) / nt; };
-    auto run = [&](auto &&fn) {
-        if (nt == 1) { fn(0u); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
-        for (auto &x : th) x.join();
-    };
-    run([&](unsigned t) { uint64_t a, b, s = 0; slice(t, a, b); for (uint64_t h = a; h < b; ++h) s += r->hit_targets[h] >> 48; part[t + 1] = s; });
-    for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
-    run([&](unsigned t) { uint64_t a, b, s = part[t]; slice(t, a, b); for (uint64_t h = a; h < b; ++h) { r->pos_offsets[h] = s; s += r->hit_targets[h] >> 48; } });
-    r->pos_offsets[H] = part[nt];
+    // (once, whoever comes first; a second thread waits here until the offsets are complete -- a plain flag let it read them half
+    // written: "cannot create std::vector larger than max_size()" from the CLI's parallel row formatting)
+    std::call_once(r->pos_offsets_once, [r] {
+        const uint64_t H = r->n_hits;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::min(8u, hw), H / 262144 + 1);
+        std::vector<uint64_t> part(nt + 1, 0);
+        auto slice = [&](unsigned t, uint64_t &a, uint64_t &b) { a = H * t / nt; b = H * (t + 1) / nt; };
+        auto run = [&](auto &&fn) {
+            if (nt == 1) { fn(0u); return; }
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
+            for (auto &x : th) x.join();
+        };
+        run([&](unsigned t) { uint64_t a, b, s = 0; slice(t, a, b); for (uint64_t h = a; h < b; ++h) s += r->hit_targets[h] >> 48; part[t + 1] = s; });
+        for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
+        run([&](unsigned t) { uint64_t a, b, s = part[t]; slice(t, a, b); for (uint64_t h = a; h < b; ++h) { r->pos_offsets[h] = s; s += r->hit_targets[h] >> 48; } });
+        r->pos_offsets[H] = part[nt];
+    });
 }
 const uint64_t *ffh_result_pos_offsets(const ffh_result *r) { if (r->pos_offsets) settle_pos_offsets(r); return r->pos_offsets; }
 const uint64_t *ffh_result_positions(const ffh_result *r) { return r->positions; }

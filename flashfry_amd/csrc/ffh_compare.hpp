@@ -51,12 +51,6 @@ namespace ffh {
 #ifndef FFH_GPL
 #define FFH_GPL 6
 #endif
-#ifndef FFH_ODD_PER
-#define FFH_ODD_PER 1
-#endif
-#ifndef FFH_PICK_P
-#define FFH_PICK_P 1
-#endif
 #ifndef FFH_PIPE_TRIPS
 #define FFH_PIPE_TRIPS 2   // 16-byte pieces of a group's words requested one group ahead (0: none; more cost registers)
 #endif
@@ -518,15 +512,13 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             const uint32_t ncand = c1 - c0, pmax = ncand <= 64u ? 16u : ncand <= 128u ? 8u : 4u;
             auto ceil_div = [](uint32_t a, uint32_t b) { return (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b) + 0.99f); };   // a < 4096, 1 <= b <= 16
             uint32_t P, per;
-            if (FFH_PICK_P && e.nbv == 1u) {
+            if (e.nbv == 1u) {
                 // One bucket in the piece (the suffix image, a large prefix bucket): lanes 0..15 price P = lane + 1 -- rows of 64 jobs
                 // x groups per job -- and the cheapest wins.  (~ngr / 6 regardless of the candidates left every second piece of the
                 // suffix image with a second row of two jobs that ran as long as the full one.)
                 const uint32_t ngr0 = lane_of(ngr, 0), ng0 = lane_of(ng, 0);
                 uint32_t Pc = min((lane & 15u) + 1u, pmax), perc = ngr0 ? ceil_div(ngr0, Pc) : 0u;
-#if FFH_ODD_PER
                 if (Pc > 1u) perc |= 1u;     // (an odd number of groups per part keeps the parts out of each other's LDS banks: below)
-#endif
                 Pc = perc ? ceil_div(ngr0, perc) : 1u;
                 const uint32_t rows_c = (ng0 * Pc + 63u) >> 6;
                 uint32_t best = ((rows_c * perc) << 16) | (rows_c << 8) | Pc;    // fewest row-steps, then fewest rows, then fewest parts
@@ -536,19 +528,15 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                 best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x140, 0xf, 0xf, false));   // row_mirror
                 P = lane_of(best, 0) & 0xFFu;
                 per = ngr ? ceil_div(ngr, P) : 0u;
-#if FFH_ODD_PER
                 if (P > 1u) per |= 1u;
-#endif
             } else {
                 P = (ngr + (uint32_t)kGroupsPerLane / 2u) / (uint32_t)kGroupsPerLane;   // ~ ngr / 6, rounded
                 P = min(max(P, 1u), pmax);
                 per = ngr ? ceil_div(ngr, P) : 0u;
-#if FFH_ODD_PER
                 // The parts of one candidate are read by neighbouring lanes at the same time, `per` groups apart: with GW = 24 words per
                 // group and an even `per` the parts p and p + 4 (per = 6: 144 p words) start in the same LDS bank with different
                 // addresses -- a two-way conflict on every read of the row.  An odd number of groups per part spreads the parts.
                 if (P > 1u) { per |= 1u; P = ceil_div(ngr, per); }
-#endif
             }
             const uint32_t jobs = ng * P;
             uint32_t incl = jobs;   // inclusive scan over the row of 16 lanes

@@ -68,3 +68,20 @@ def test_two_rank_line_on_one_gpu(scaling):
     if scaling == "strong":  # ONE database split by bins: the ranks' shards add up to the single-GPU database (3e6 drawn, duplicates collapse)
         assert 2.9e6 < d["config"]["targets_total"] < 3.1e6
     assert d["hits"]["kept_positions"] > 0
+
+
+def test_sharded_step_with_one_rank_goes_through_the_library_exchange():
+    """FFH_BENCH_FORCE_EXCHANGE=1: the sharded step of `bench.py --gpus N` with a single rank -- ffh_comm_create_rank (ncclCommInitRank,
+    world 1) + ffh_discover_sharded, the unique id handed round by torch.distributed -- the code the driver's multi-GPU run executes"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FFH_BENCH_FORCE_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--cpu-seconds", "0", "--no-skewed", "--no-c2", "--no-verify"], env=env,
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = last_json(r.stdout)
+    check_contract(d, 1)
+    assert "RCCL collectives issued by libflashfry_hip (rccl-rank)" in d["config"]["exchange"], d["config"]
+    assert d["hits"]["kept_positions"] > 0

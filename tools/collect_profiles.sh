@@ -7,12 +7,12 @@ OUT=$R/gpurun_out/${1:-profiles}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel time summary of the default benchmark command (traffic passes and CPU baseline switched off: they are separate runs)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-seconds 0 --no-traffic --no-verify --no-skewed > "$OUT/stats_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-seconds 0 --no-traffic --no-verify --no-skewed --no-c2 > "$OUT/stats_bench.log" 2>&1
 grep -v '^[WEI]2026' "$OUT/stats_bench.log" | tail -1 > "$OUT/stats_bench.json"
 # 2. PMC passes on the compare kernel (one --pmc set per run, --kernel-trace only)
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   N=$(echo $P | cut -d" " -f1)
-  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "k_compare<|k_image_hist" --output-format csv -d "$OUT/pmc_$N" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed > "$OUT/pmc_$N.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "k_compare<|k_image_hist" --output-format csv -d "$OUT/pmc_$N" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed --no-c2 > "$OUT/pmc_$N.log" 2>&1
 done
 # 3. the default benchmark line itself (with its own traffic passes and CPU baseline)
 cd "$R" && python bench.py > "$OUT/bench_default.log" 2>&1

@@ -5,7 +5,7 @@ K=$1; shift
 i=0
 for P in "$@"; do
   i=$((i+1)); rm -rf /tmp/pmcs_$i
-  timeout 150 rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$K" --output-format csv -d /tmp/pmcs_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed > /tmp/pmcs_$i.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$K" --output-format csv -d /tmp/pmcs_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed --no-c2 > /tmp/pmcs_$i.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections

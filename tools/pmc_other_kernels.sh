@@ -5,7 +5,7 @@ RX="k_item_bin_direct|k_guide_by_part|k_sort_hist|k_sort_scatter|k_segments|k_se
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS"; do
   N=$(echo $P | cut -d" " -f1)
   rm -rf /tmp/pmco_$N
-  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$RX" --output-format csv -d /tmp/pmco_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed > /tmp/pmco_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --kernel-include-regex "$RX" --output-format csv -d /tmp/pmco_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed --no-c2 > /tmp/pmco_$N.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections

@@ -1,7 +1,7 @@
 # device timeline of the last benchmark step: every kernel and copy with its start offset, duration and the idle gap before it
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_tl
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_tl -o tl -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['breakdown_ms'])"
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_tl -o tl -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-traffic --no-verify --no-skewed --no-c2 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['breakdown_ms'])"
 k=$(find /tmp/prof_tl -name "*kernel_trace.csv" | head -1)
 m=$(find /tmp/prof_tl -name "*memory_copy_trace.csv" | head -1)
 python - "$k" "$m" <<'PY'
