@@ -1251,8 +1251,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         if (full_lsd || (many && !force_seg)) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
         else {
             FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
-            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);
-            FFH_HIP(hipMemsetAsync(n_heavy, 0, 4, st));
+            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup)
             uint64_t *by_guide = radix_sort_u64(ctx->hits.p, ctx->n_raw, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);
             uint64_t *other = by_guide == ctx->hits.p ? ctx->hits_alt.p : ctx->hits.p;
             hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, by_guide, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);

@@ -107,6 +107,7 @@ struct CompareArgs {
 __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int first_batch) {
     if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
+    if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
