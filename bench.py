@@ -339,6 +339,17 @@ def skewed_workload(torch, capi, synth, ctx_uniform, dev, local, args):
         # the scan as ffh_discover runs it (bounding switches itself on for a guide set like this one after the first call; forced on
         # here so that the first timed call already is a bounded one), then the same with bounding off
         res, ms, tms = run(1)
+        # ... and the complete product of the bounded call: hit lists and positions on the host (what the CLI asks for)
+        lists = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            full = ctx.discover(guides, args.max_mismatch, args.max_offtargets, hit_scores=False)
+            lists.append((time.perf_counter() - t0) * 1e3)
+        if full.summaries.tobytes() != res.summaries.tobytes():
+            raise SystemExit("bench: the list-delivering bounded call's aggregates differ from the aggregates-only call's")
+        kept_pos = int(full.n_positions)
+        del full
         res_u, ms_u, tms_u = run(0)
         if res.summaries.tobytes() != res_u.summaries.tobytes():
             raise SystemExit("bench: the bounded scan's aggregates differ from the unbounded scan's")
@@ -347,6 +358,7 @@ def skewed_workload(torch, capi, synth, ctx_uniform, dev, local, args):
         out = {"workload": "hg38-skewed: %d guides sampled by position from a repeat-structured genome of %d distinct targets (%d positions), <=%d mismatches, "
                            "maximumOffTargets %d" % (len(guides), T, P, args.max_mismatch, args.max_offtargets),
                "ms_per_step": ms, "value": len(guides) * T / (ms * 1e-3), "unit": "comparisons/s", "breakdown_ms": bd(tms),
+               "discover_with_lists_ms": float(np.median(lists[1:])), "kept_positions": kept_pos,
                "raw_hits": int(tms[-1]["n_raw_hits"]), "raw_hits_per_guide": tms[-1]["n_raw_hits"] / max(len(guides), 1),
                "bounded_slabs": int(tms[-1]["bounded_slabs"]), "retired_guides": int(tms[-1]["retired_guides"]),
                # ffh_set_bounding(0): every guide meets the whole database, every raw hit is kept and sorted (round 1's only mode)

@@ -199,6 +199,7 @@ struct ffh_ctx {
     std::vector<uint64_t> bin_bytes;
     uint32_t n_bins = 0, bin_begin = 0, bin_end = 0;
     double db_prepare_ms = 0;
+    double span = 1.0;   // fraction of prefix-key space the shard's targets lie in (plan_cost)
     ffh_load_stats load{};
     double load_device_inflate_ms = 0;
     int plan_a = -1, plan_r1 = -1;
@@ -230,7 +231,11 @@ struct ffh_ctx {
     DevBuf<unsigned long long> part_pairs[2];  // per candidate partition: targets x candidates of its buckets (k_item_bin)
     uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
-    DevBuf<uint32_t> icount, ifill, item_gid, part_fill, part_hist, part_start, part_items, scan_tmp32, gp_start, by_part;
+    DevBuf<uint32_t> icount, ifill, item_gid, part_items, scan_tmp32;
+    // candidate binning and work list of one image: per side, because the two sides are prepared on two streams at once (scan_impl)
+    struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
+    hipStream_t side_st = nullptr;             // the suffix image's preparation runs here, beside the prefix image's on `st`
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
     DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
@@ -298,21 +303,33 @@ static const std::vector<uint32_t> &patterns_for(ffh_ctx *ctx, int n, int r) {
 
 // cost of the best (r1, r2) for a prefix width a, in pair tests per guide: every candidate entry meets the slots of its bucket (the
 // targets rounded up to groups of 32: + 16 on average) and costs about as much as kEntryCost pair tests to generate and bin
-// (measured at hg38 scale: 10.4 ps per entry against 0.24 ps per pair test)
-static double plan_cost(double T, int lc, int a, int max_mm, Plan &best) {
+// (measured at hg38 scale: 10.4 ps per entry against 0.24 ps per pair test).
+// span: the fraction of prefix-key space the shard's targets lie in (a bin shard of a database in sequence order is one
+// contiguous range of it: 1/8 for one of eight shards).  Inside that range the prefix buckets are as full as the whole database's,
+// outside it they are empty -- a candidate pattern that lands there is generated and looked up (about a third of an entry's cost) but
+// neither binned nor compared; the suffix buckets thin out evenly.  Planning a shard by its target count alone took the 10 + 10
+// split for an eighth of hg38 where 11 + 9, the whole database's plan, runs 37 % fewer pair tests.
+static double plan_cost(double T, double span, int lc, int a, int max_mm, Plan &best) {
     constexpr double kEntryCost = 40.0;
     const int s = lc - a;
-    const double per_p = std::max(T / std::pow(4.0, a), 1.0) + 16.0, per_s = std::max(T / std::pow(4.0, s), 1.0) + 16.0;
+    const double per_p = span * (std::max(T / (span * std::pow(4.0, a)), 1.0) + 16.0) + kEntryCost * (1.0 + 2.0 * span) / 3.0;
+    const double per_s = std::max(T / std::pow(4.0, s), 1.0) + 16.0 + kEntryCost;
     best = Plan{a, std::min(max_mm, a), s, -1};
-    double best_cost = ball_size(a, best.r1) * (per_p + kEntryCost);
+    double best_cost = ball_size(a, best.r1) * per_p;
     if (max_mm >= 1)
         for (int r1 = 0; r1 <= std::min(max_mm - 1, a); ++r1) {
             const int r2 = max_mm - 1 - r1;
             if (r2 > s) continue;
-            const double cost = ball_size(a, r1) * (per_p + kEntryCost) + ball_size(s, r2) * (per_s + kEntryCost);
+            const double cost = ball_size(a, r1) * per_p + ball_size(s, r2) * per_s;
             if (cost < best_cost) { best_cost = cost; best = Plan{a, r1, s, r2}; }
         }
     return best_cost;
+}
+// the default prefix width: ~48 targets per (non-empty) prefix bucket, both keys <= 12 bases; a small database keeps the split near
+// the middle (an image with more than 4^10 buckets costs more in bucket-proportional passes than its short candidate lists save)
+static int default_prefix_width(double T, double span, int lc) {
+    const int a = (int)std::floor(std::log(std::max(T, 1.0) / span / 48.0) / std::log(4.0));
+    return std::max(lc - 12, std::min(12, std::max(a, lc - 10)));
 }
 
 static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
@@ -324,7 +341,7 @@ static Plan choose_plan(const ffh_ctx *ctx, int max_mm) {
         return p;
     }
     Plan best;
-    (void)plan_cost((double)std::max<uint64_t>(ctx->T, 1), lc, a, max_mm, best);
+    (void)plan_cost((double)std::max<uint64_t>(ctx->T, 1), ctx->span, lc, a, max_mm, best);
     if (a + s != lc) best = Plan{a, std::min(max_mm, a), s, -1};
     return best;
 }
@@ -418,14 +435,19 @@ static int prepare_database(ffh_ctx *ctx) {
     ctx->db_sorted = hbad2[1] == 0;
     if (hbad) { ctx->err = "Encoded position count should be greater than zero (and fit a signed short)"; return FFH_E_FORMAT; }
     if (total != ctx->P) { ctx->err = "positions array length does not equal the sum of the target counts"; return FFH_E_FORMAT; }
-    // bucket widths: ~48 targets per prefix bucket, both keys <= 12 bases
+    // the part of prefix-key space the shard covers (plan_cost): first and last target of a database in sequence order
+    ctx->span = 1.0;
     const int lc = ctx->geo.lc;
-    int a = (int)std::floor(std::log((double)std::max<uint64_t>(ctx->T, 1) / 48.0) / std::log(4.0));
-    if (ctx->plan_a >= 0) a = ctx->plan_a;
-    // small databases: an image with more than 4^10 buckets costs more in bucket-proportional passes (tile counting, table
-    // scans: 16.7 M buckets for a 12-base image) than its short candidate lists save, so the split stays near the middle
-    if (ctx->plan_a < 0) a = std::max(a, lc - 10);
-    a = std::max(lc - 12, std::min(12, a));
+    if (ctx->db_sorted && ctx->geo.c0 == 0 && ctx->T >= 2 && lc >= 12) {
+        uint64_t ends[2];
+        FFH_HIP(hipMemcpyAsync(&ends[0], ctx->targets.p, 8, hipMemcpyDeviceToHost, ctx->st));
+        FFH_HIP(hipMemcpyAsync(&ends[1], ctx->targets.p + (ctx->T - 1), 8, hipMemcpyDeviceToHost, ctx->st));
+        FFH_HIP(hipStreamSynchronize(ctx->st));
+        const int sh = 2 * (ctx->geo.scan_len - 12);
+        const uint64_t k0 = (ends[0] >> sh) & 0xFFFFFFull, k1 = (ends[1] >> sh) & 0xFFFFFFull;
+        if (k1 >= k0) ctx->span = std::min(1.0, std::max((double)(k1 - k0 + 1) / 16777216.0, 1.0 / 4096.0));
+    }
+    int a = ctx->plan_a >= 0 ? std::max(lc - 12, std::min(12, ctx->plan_a)) : default_prefix_width((double)ctx->T, ctx->span, lc);
     drop_slabs(ctx);   // (slab images of the database that was resident before)
     ctx->alt[0] = Image(); ctx->alt[1] = Image();
     int rc = build_image(ctx, 0, a);
@@ -446,13 +468,13 @@ static int prepare_database(ffh_ctx *ctx) {
 // im: the image the candidates are for (the shard's, or one slab's: ffh_scan_bounded); range: {first, last} bucket outside which
 // entries are dropped (device memory); gptr: the ng guides of this launch; seg_at >= 0: also clear the hit segments of guides
 // seg_at .. seg_at + ng - 1 (their numbers in the caller's array)
-static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t *range, int radius, const uint64_t *gptr, int64_t seg_at, uint32_t ng,
+static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im, const uint32_t *range, int radius, const uint64_t *gptr, int64_t seg_at, uint32_t ng,
                         uint32_t item_base, uint32_t rank_lo = 0u, uint32_t rank_hi = 63u) {
     const int width = im.width;
     const uint32_t nb = 1u << (2 * width);
     const std::vector<uint32_t> &pat = patterns_for(ctx, width, radius);
     const uint32_t np = (uint32_t)pat.size();
-    hipStream_t st = ctx->st;
+    ffh_ctx::SideScratch &sc = ctx->side_scr[which];
     DevBuf<uint32_t> &patterns = ctx->patterns[which], &gbucket = ctx->gbucket[which], &istart = ctx->istart[which];
     if (ctx->patterns_key[which] != std::make_pair(width, std::min(radius, width)) || patterns.cap < np) {  // uploaded once per (width, radius)
         FFH_HIP(patterns.reserve(np));
@@ -462,7 +484,7 @@ static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t
     FFH_HIP(gbucket.reserve(ng));
     FFH_HIP(ctx->gtab[which].reserve((size_t)ng + 64));
     FFH_HIP(istart.reserve((size_t)nb + 1));
-    FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(nb)));
+    FFH_HIP(sc.scan_tmp.reserve(scan_scratch_elems_safe(nb)));
     // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
     const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
@@ -483,48 +505,48 @@ static int prepare_side(ffh_ctx *ctx, int which, const Image &im, const uint32_t
     ig.range = range;
     ig.rank_lo = rank_lo; ig.rank_hi = rank_hi; ig.width = (uint32_t)width;
     const bool filtered = rank_lo > 0u || rank_hi < 63u;   // one slab of a bounded scan: the sizes are counted, not derived
-    FFH_HIP(ctx->part_hist.reserve((size_t)ig.n_part + 1));
+    FFH_HIP(sc.part_hist.reserve((size_t)ig.n_part + 1));
     FFH_HIP(ctx->part_pairs[which].reserve((size_t)ig.n_part + 1));
     // the launch also clears the partition histogram and, on the prefix side, the guides' hit segments (one thread per guide anyway:
     // saves the fill launches before k_guide_part_hist and k_segments)
     if (which == 0) hipLaunchKernelGGL(k_guide_keys<false>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[0].p, gbucket.p,
                                        seg_at >= 0 ? ctx->seg_begin.p + seg_at : (uint32_t *)nullptr, seg_at >= 0 ? ctx->seg_end.p + seg_at : (uint32_t *)nullptr,
-                                       ctx->part_hist.p, ig.n_part);
+                                       sc.part_hist.p, ig.n_part);
     else hipLaunchKernelGGL(k_guide_keys<true>, dim3(blocks_for(ng, 256)), dim3(256), 0, st, gptr, ng, ctx->geo, width, ctx->gtab[1].p, gbucket.p, (uint32_t *)nullptr,
-                            (uint32_t *)nullptr, ctx->part_hist.p, ig.n_part);
-    FFH_HIP(ctx->part_fill.reserve((size_t)2 * ig.n_part + 2));
-    FFH_HIP(ctx->part_start.reserve((size_t)ig.n_part + 2));
-    uint32_t *part_count = ctx->part_fill.p, *part_fill = ctx->part_fill.p + ig.n_part + 1;
-    hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, ctx->part_hist.p, ctx->part_fill.p, 2u * ig.n_part + 2u);
+                            (uint32_t *)nullptr, sc.part_hist.p, ig.n_part);
+    FFH_HIP(sc.part_fill.reserve((size_t)2 * ig.n_part + 2));
+    FFH_HIP(sc.part_start.reserve((size_t)ig.n_part + 2));
+    uint32_t *part_count = sc.part_fill.p, *part_fill = sc.part_fill.p + ig.n_part + 1;
+    hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, sc.part_hist.p, sc.part_fill.p, 2u * ig.n_part + 2u);
     static const bool old_binning = getenv("FFH_BINNING") && std::strcmp(getenv("FFH_BINNING"), "records") == 0;   // A/B: the round-2 form
     if (!old_binning) {
         // guides grouped by partition (counting sort on the histogram), then every partition's block enumerates its own entries from
         // those runs: no intermediate records (ffh_kernels.hpp: k_item_bin_direct)
-        FFH_HIP(ctx->gp_start.reserve((size_t)ig.n_part + 2));
-        FFH_HIP(ctx->by_part.reserve((size_t)ng + 1));
-        exclusive_scan<uint32_t, uint32_t>(ctx->part_hist.p, ig.n_part, ctx->gp_start.p, ctx->scan_tmp32.p, st);
+        FFH_HIP(sc.gp_start.reserve((size_t)ig.n_part + 2));
+        FFH_HIP(sc.by_part.reserve((size_t)ng + 1));
+        exclusive_scan<uint32_t, uint32_t>(sc.part_hist.p, ig.n_part, sc.gp_start.p, sc.scan_tmp.p, st);
         hipLaunchKernelGGL(k_guide_by_part, dim3(blocks_for(ng, 1024)), dim3(1024), 0, st, (const uint32_t *)gbucket.p, ng, ig.low_bits, ig.n_part,
-                           (const uint32_t *)ctx->gp_start.p, part_fill, ctx->by_part.p);
-        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
-        else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
+                           (const uint32_t *)sc.gp_start.p, part_fill, sc.by_part.p);
+        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_count);
+        else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
                                 (const uint32_t *)patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
                                 (unsigned long long *)nullptr);
-        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
-        if (!filtered) hipLaunchKernelGGL((k_item_bin_direct<false, false>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
-                                          (const uint32_t *)patterns.p, ig, (const uint32_t *)ctx->part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p,
+        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, sc.part_start.p, sc.scan_tmp.p, st);
+        if (!filtered) hipLaunchKernelGGL((k_item_bin_direct<false, false>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
+                                          (const uint32_t *)patterns.p, ig, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p,
                                           (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
-        else hipLaunchKernelGGL((k_item_bin_direct<false, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)ctx->gp_start.p, (const uint32_t *)ctx->by_part.p,
-                                (const uint32_t *)patterns.p, ig, (const uint32_t *)ctx->part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p, (const uint32_t *)im.bstart.p,
+        else hipLaunchKernelGGL((k_item_bin_direct<false, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
+                                (const uint32_t *)patterns.p, ig, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p, (const uint32_t *)im.bstart.p,
                                 ctx->part_pairs[which].p);
     } else {
         FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
         const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
-        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, ctx->part_hist.p, patterns.p, ig, part_count);
+        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_count);
         else hipLaunchKernelGGL((k_item_partition<false, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
-        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, ctx->part_start.p, ctx->scan_tmp32.p, st);
-        if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
-        else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, ctx->part_start.p, part_fill, ctx->part_items.p);
-        hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, ctx->part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
+        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, sc.part_start.p, sc.scan_tmp.p, st);
+        if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, sc.part_start.p, part_fill, ctx->part_items.p);
+        else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, sc.part_start.p, part_fill, ctx->part_items.p);
+        hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, sc.part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
                            (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
     }
     ctx->n_part[which] = ig.n_part;
@@ -619,6 +641,9 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     ctx->st = ctx->own_st;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_pub, 32 * sizeof(unsigned long long), hipHostMallocMapped);
@@ -652,6 +677,9 @@ void ffh_destroy(ffh_ctx *ctx) {
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
+    if (ctx->side_st) { (void)hipStreamSynchronize(ctx->side_st); (void)hipStreamDestroy(ctx->side_st); }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->own_st) (void)hipStreamDestroy(ctx->own_st);
     delete ctx;  // the device buffers free themselves
 }
@@ -997,13 +1025,13 @@ static int select_images(ffh_ctx *ctx, int max_mm) {
     const int lc = ctx->geo.lc, cur = ctx->img[0].width;
     const double T = (double)ctx->T;
     Plan p;
-    const double cost_cur = plan_cost(T, lc, cur, max_mm, p);
+    const double cost_cur = plan_cost(T, ctx->span, lc, cur, max_mm, p);
     // among equally cheap widths (the model is symmetric in prefix and suffix) the one nearest to the default split wins
-    const int a_def = std::max(lc - 12, std::min(12, std::max((int)std::floor(std::log(T / 48.0) / std::log(4.0)), lc - 10)));
+    const int a_def = default_prefix_width(T, ctx->span, lc);
     int best_a = cur;
     double best = cost_cur;
     for (int a = std::max(lc - 12, 8); a <= std::min(12, lc - 8); ++a) {
-        const double c = plan_cost(T, lc, a, max_mm, p);
+        const double c = plan_cost(T, ctx->span, lc, a, max_mm, p);
         if (c < best * (1.0 - 1e-9) || (c <= best * (1.0 + 1e-9) && std::abs(a - a_def) < std::abs(best_a - a_def))) { best = c; best_a = a; }
     }
     if (best_a == cur || best > 0.8 * cost_cur) return FFH_OK;
@@ -1068,7 +1096,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // typical run fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); k_work_count / k_work_fill then list the
     // runs that have candidates, a bucket larger than the strip as several strip-sized group ranges.  Candidate lists larger than the
     // strip take the kernel's piecewise path.
-    auto side_plan = [&](int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S,
+    auto side_plan = [&](hipStream_t st, int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S,
                          uint32_t rank_lo = 0u, uint32_t rank_hi = 63u, bool count_pairs = true) -> int {
         S = SideArgs{};
         S.gstart = im.gstart.p; S.gwords = im.gwords.p; S.tidx = im.direct ? nullptr : im.tidx.p; S.dd_off = im.direct ? S_nb_plus_1(width) : 0u; S.istart = ctx->istart[which].p; S.gtab = ctx->gtab[which].p;
@@ -1083,11 +1111,11 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
         FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
         FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
-        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe(n_bat)));
+        FFH_HIP(ctx->side_scr[which].scan_tmp.reserve(scan_scratch_elems_safe(n_bat)));
         hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
                            ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u,
                            ctx->d_counters + kStatPairs + which, rank_lo, rank_hi, (uint32_t)width);
-        exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->scan_tmp32.p, st);
+        exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->side_scr[which].scan_tmp.p, st);
         hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
                            ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which, rank_lo, rank_hi, (uint32_t)width);
         S.list = ctx->wl_list[which].p;
@@ -1116,7 +1144,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     const uint64_t n_items_p_all = (uint64_t)n_guides * (uint64_t)np_p;
     if (shared_prefix) {
         FFH_HIP(ctx->item_gid.reserve(n_items_p_all + (uint64_t)n_guides * (uint64_t)np_s + 64));
-        const int rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, ctx->guides.p, -1, n_guides, 0u);
+        const int rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, ctx->guides.p, -1, n_guides, 0u);
         if (rc) return rc;
     }
     for (size_t sl = 0; sl < slabs.size() && n_act; ++sl) {
@@ -1131,21 +1159,31 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
             FFH_HIP(hipEventRecord(ctx->ev[2], st));
             int rc = FFH_OK;
-            if (!shared_prefix) {
-                rc = prepare_side(ctx, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
-                if (rc) return rc;
-            }
-            if (plan.r2 >= 0) {
-                rc = prepare_side(ctx, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
-                if (rc) return rc;
-            }
-            FFH_HIP(hipEventRecord(ctx->ev[3], st));
+            // The two images' candidate lists and work lists do not depend on each other, and most of their kernels are small (a few
+            // microseconds of work under a launch floor of ~4.5): the suffix image's run on a second stream beside the prefix image's,
+            // forked and joined with events.  FFH_SIDE_STREAMS=0: one after the other on the context's stream.
+            static const bool one_stream = (getenv("FFH_SIDE_STREAMS") && atoi(getenv("FFH_SIDE_STREAMS")) == 0) ||
+                                           (getenv("FFH_BINNING") && std::strcmp(getenv("FFH_BINNING"), "records") == 0);   // (that path shares part_items)
+            const bool fork = plan.r2 >= 0 && ctx->side_st && !one_stream;
+            hipStream_t st1 = fork ? ctx->side_st : st;
             CompareArgs ca{};
-            if (shared_prefix) rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
-            else rc = side_plan(0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
+            if (fork) { FFH_HIP(hipEventRecord(ctx->fork_ev, st)); FFH_HIP(hipStreamWaitEvent(st1, ctx->fork_ev, 0)); }
+            if (plan.r2 >= 0) {
+                rc = prepare_side(ctx, st1, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
+                if (rc) return rc;
+                rc = side_plan(st1, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+                if (rc) return rc;
+                if (fork) FFH_HIP(hipEventRecord(ctx->join_ev, st1));
+            } else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
+            if (!shared_prefix) {
+                rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
+                if (rc) return rc;
+            }
+            if (shared_prefix) rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
+            else rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
             if (rc) return rc;
-            if (plan.r2 >= 0) { rc = side_plan(1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]); if (rc) return rc; }   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
-            else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
+            if (fork) FFH_HIP(hipStreamWaitEvent(st, ctx->join_ev, 0));
+            FFH_HIP(hipEventRecord(ctx->ev[3], st));   // (prepare_ms: candidate lists and work lists; compare_ms: the compare launch alone)
             ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
             ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
             ca.gmap[0] = shared_prefix ? nullptr : (act_map ? act_map + g0 : nullptr);
@@ -1415,7 +1453,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         // the kernel stores every summary into the result's page-locked block as well (hipHostMalloc memory is mapped into the
         // device's address space): the 88 bytes per guide cross the link under the kernel instead of in a copy after it
         static const bool zero_copy = !(getenv("FFH_SUMMARY_COPY") && atoi(getenv("FFH_SUMMARY_COPY")) == 1);
-        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(epilogue_grid(G)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
                                   ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr,
@@ -2025,7 +2063,7 @@ static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, cons
     const uint32_t G = ctx->n_guides;
     FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
     if (!d_fix_totals) FFH_HIP(hipEventRecord(ctx->ev[7], ctx->st));
-    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(epilogue_grid(G)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
                               (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                               d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p,
                               (GuideSummary *)d_summaries, d_totals, d_fix_totals, (GuideSummary *)nullptr);

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--targets", type=float, default=3.0e8)
     ap.add_argument("--guides", type=int, default=100000)
+    ap.add_argument("--plan-a", type=int, default=-1, help="force the prefix width (default: the library's choice)")
     args = ap.parse_args()
     import torch
     from flashfry_amd import capi, synth
@@ -25,6 +26,8 @@ def main():
     t, p = db["targets"][lo:hi].contiguous(), db["positions"][plo:phi].contiguous()
     with capi.Context(3) as ctx:
         torch.cuda.synchronize()
+        if args.plan_a >= 0:
+            ctx.set_plan(args.plan_a, -1)
         ctx.load_soa_device(t.data_ptr(), hi - lo, p.data_ptr(), phi - plo)
         for _ in range(3):
             ctx.scan_device(gd.data_ptr(), args.guides, 4)
@@ -38,7 +41,7 @@ def main():
             tms.append(ctx.timings().as_dict())
         print(json.dumps({"shards": args.shards, "rank": args.rank, "targets": hi - lo, "ms_per_step": float(np.median(ts)),
                           "breakdown_ms": {k: round(float(np.mean([x[k] for x in tms])), 3) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
-                          "tiles_prefix": int(tms[-1]["tiles_prefix"]), "pairs": int(tms[-1]["pairs_prefix"] + tms[-1]["pairs_suffix"]), "hits": int(res.summaries["n_hits"].sum())}))
+                          "plan": [int(tms[-1]["prefix_bases"]), int(tms[-1]["prefix_radius"]), int(tms[-1]["suffix_radius"])], "tiles_prefix": int(tms[-1]["tiles_prefix"]), "pairs": int(tms[-1]["pairs_prefix"] + tms[-1]["pairs_suffix"]), "hits": int(res.summaries["n_hits"].sum())}))
 
 
 if __name__ == "__main__":

@@ -1,4 +1,5 @@
 
+"""the repeat-structured workload of bench.py alone: unbounded, then bounded; every field of ffh_timings (dev tool, GPU box)"""
 import sys, time, json, numpy as np, torch
 sys.path.insert(0, ".")
 from flashfry_amd import capi, synth
@@ -18,4 +19,4 @@ with capi.Context(3) as ctx:
             res = ctx.discover(guides, 4, 2000, summaries_only=True)
             ts.append((time.perf_counter() - t0) * 1e3)
         tm = ctx.timings().as_dict()
-        print("bounding", mode, "ms", round(float(np.median(ts)), 2), {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items() if k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms", "n_raw_hits", "bounded_slabs", "retired_guides", "compare_launches")}, "digest", hash(res.summaries.tobytes()) & 0xffffff)
+        print("bounding", mode, "ms", round(float(np.median(ts)), 2), {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items() }, "digest", hash(res.summaries.tobytes()) & 0xffffff)
