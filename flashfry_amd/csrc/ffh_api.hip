@@ -232,10 +232,8 @@ struct ffh_ctx {
     uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
     DevBuf<uint32_t> icount, ifill, item_gid, part_items, scan_tmp32;
-    // candidate binning and work list of one image: per side, because the two sides are prepared on two streams at once (scan_impl)
+    // candidate binning and work list of one image
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
-    hipStream_t side_st = nullptr;             // the suffix image's preparation runs here, beside the prefix image's on `st`
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
     DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
@@ -438,7 +436,7 @@ static int prepare_database(ffh_ctx *ctx) {
     // the part of prefix-key space the shard covers (plan_cost): first and last target of a database in sequence order
     ctx->span = 1.0;
     const int lc = ctx->geo.lc;
-    if (ctx->db_sorted && ctx->geo.c0 == 0 && ctx->T >= 2 && lc >= 12) {
+    if (ctx->db_sorted && ctx->geo.c0 + lc == ctx->geo.scan_len && ctx->T >= 2 && lc >= 12) {   // (a 3' PAM: the compared bases lead the sequence)
         uint64_t ends[2];
         FFH_HIP(hipMemcpyAsync(&ends[0], ctx->targets.p, 8, hipMemcpyDeviceToHost, ctx->st));
         FFH_HIP(hipMemcpyAsync(&ends[1], ctx->targets.p + (ctx->T - 1), 8, hipMemcpyDeviceToHost, ctx->st));
@@ -641,9 +639,6 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     ctx->st = ctx->own_st;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_pub, 32 * sizeof(unsigned long long), hipHostMallocMapped);
@@ -677,9 +672,6 @@ void ffh_destroy(ffh_ctx *ctx) {
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     if (ctx->copy_st) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamDestroy(ctx->copy_st); }
-    if (ctx->side_st) { (void)hipStreamSynchronize(ctx->side_st); (void)hipStreamDestroy(ctx->side_st); }
-    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
-    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->own_st) (void)hipStreamDestroy(ctx->own_st);
     delete ctx;  // the device buffers free themselves
 }
@@ -1159,21 +1151,15 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
             FFH_HIP(hipEventRecord(ctx->ev[2], st));
             int rc = FFH_OK;
-            // The two images' candidate lists and work lists do not depend on each other, and most of their kernels are small (a few
-            // microseconds of work under a launch floor of ~4.5): the suffix image's run on a second stream beside the prefix image's,
-            // forked and joined with events.  FFH_SIDE_STREAMS=0: one after the other on the context's stream.
-            static const bool one_stream = (getenv("FFH_SIDE_STREAMS") && atoi(getenv("FFH_SIDE_STREAMS")) == 0) ||
-                                           (getenv("FFH_BINNING") && std::strcmp(getenv("FFH_BINNING"), "records") == 0);   // (that path shares part_items)
-            const bool fork = plan.r2 >= 0 && ctx->side_st && !one_stream;
-            hipStream_t st1 = fork ? ctx->side_st : st;
+            // (The two images' candidate lists do not depend on each other and most of their kernels sit on the launch floor, so round 3
+            // ran the suffix image's on a second stream, forked and joined with events: 2.14 against 2.13 ms per step -- the two
+            // streams' kernels did not overlap on this stack and every event wait added a few microseconds.  One stream.)
             CompareArgs ca{};
-            if (fork) { FFH_HIP(hipEventRecord(ctx->fork_ev, st)); FFH_HIP(hipStreamWaitEvent(st1, ctx->fork_ev, 0)); }
             if (plan.r2 >= 0) {
-                rc = prepare_side(ctx, st1, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
+                rc = prepare_side(ctx, st, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
                 if (rc) return rc;
-                rc = side_plan(st1, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+                rc = side_plan(st, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
                 if (rc) return rc;
-                if (fork) FFH_HIP(hipEventRecord(ctx->join_ev, st1));
             } else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
             if (!shared_prefix) {
                 rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
@@ -1182,7 +1168,6 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             if (shared_prefix) rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
             else rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
             if (rc) return rc;
-            if (fork) FFH_HIP(hipStreamWaitEvent(st, ctx->join_ev, 0));
             FFH_HIP(hipEventRecord(ctx->ev[3], st));   // (prepare_ms: candidate lists and work lists; compare_ms: the compare launch alone)
             ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
             ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
@@ -1194,6 +1179,15 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
             FFH_HIP(spin_wait(ctx, cnt));
             FFH_HIP(hipGetLastError());
+#ifdef FFH_WAVE_STATS
+            {
+                unsigned long long ws[8];
+                FFH_HIP(hipMemcpy(ws, ctx->d_counters + 20, sizeof ws, hipMemcpyDeviceToHost));
+                const double nw = (double)std::max<unsigned long long>(ws[5], 1);
+                fprintf(stderr, "[wave stats] slab %zu: %llu waves, cycles per wave mean %.0f max %llu (suffix side: mean %.0f max %llu), rows per wave mean %.0f max %llu, unfit pieces %llu\n",
+                        sl, ws[5], (double)ws[0] / nw, ws[1], (double)ws[2] / nw, ws[3], (double)ws[6] / nw, ws[7], ws[4]);
+            }
+#endif
             first_launch = false;
             const unsigned long long cursor = cnt[0];
             // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
@@ -1453,7 +1447,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         // the kernel stores every summary into the result's page-locked block as well (hipHostMalloc memory is mapped into the
         // device's address space): the 88 bytes per guide cross the link under the kernel instead of in a copy after it
         static const bool zero_copy = !(getenv("FFH_SUMMARY_COPY") && atoi(getenv("FFH_SUMMARY_COPY")) == 1);
-        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(epilogue_grid(G)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
                                   ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr,
@@ -2063,7 +2057,7 @@ static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, cons
     const uint32_t G = ctx->n_guides;
     FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
     if (!d_fix_totals) FFH_HIP(hipEventRecord(ctx->ev[7], ctx->st));
-    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(epilogue_grid(G)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
                               (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                               d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p,
                               (GuideSummary *)d_summaries, d_totals, d_fix_totals, (GuideSummary *)nullptr);

@@ -259,7 +259,7 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
     auto epilogue = [&](size_t i, const uint32_t *d_prior, const uint32_t *d_fix, uint32_t *d_totals) {
         ffh_ctx *ctx = cm->ctx[i];
         (void)hipSetDevice(ctx->device);
-        hipLaunchKernelGGL(k_guide_epilogue, dim3(epilogue_grid(G)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+        hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
                            (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                            d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_ot, jost ? 1 : 0, ctx->n_ret.p, cm->buf[i]->summ.p, d_totals, d_fix,
                            (GuideSummary *)nullptr);

@@ -108,6 +108,9 @@ __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int fir
     if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
     if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
+#ifdef FFH_WAVE_STATS   // (dev builds: tools/build_variant.sh WORK stats -DFFH_WAVE_STATS)
+    if (threadIdx.x >= 20 && threadIdx.x < 32) cursor[threadIdx.x] = 0ull;
+#endif
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -405,6 +408,11 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
     const uint32_t *__restrict__ gids = A.gids;
     HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor, 0ull, 0u, 0ull};
     RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
+#ifdef FFH_WAVE_STATS   // how evenly the launch's time is spread over its waves: cycles per wave (sum, max), per side; pieces that did not fit
+    const unsigned long long ws_begin = clock64();
+    unsigned long long ws_side1 = 0;
+    uint32_t ws_unfit = 0, ws_rows = 0;
+#endif
 
     // what a batch covers: nbv buckets from b0 on, groups [g0, g1), candidates [c0, c1)
     struct Extent { uint32_t nbv, b0, g0, g1, c0, c1; };
@@ -568,6 +576,9 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         auto rows = [&](uint32_t n_jobs) {
             uint32_t before = 0;   // buckets begun in the rows before this one
             for (uint32_t j0 = 0; j0 < n_jobs; j0 += 64) {
+#ifdef FFH_WAVE_STATS
+                ++ws_rows;
+#endif
                 const uint32_t J = j0 + lane;
                 const uint64_t M = mark_lds[wave][j0 >> 6];
                 const uint32_t mlo = (uint32_t)M, mhi = (uint32_t)(M >> 32);
@@ -642,6 +653,9 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                         load_gids(c0, c1, greg_a);
                         load_entries(c0, c1, greg_a, ereg);
                         const uint32_t nj = park(e, t0, t1, c0, c1, kreg, greg_a, ereg, dG0, dI0);
+#ifdef FFH_WAVE_STATS
+                        ++ws_unfit;
+#endif
                         rows(nj);
                     }
                 }
@@ -664,8 +678,20 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         }
     };
     run_side(std::integral_constant<int, 1>{});
+#ifdef FFH_WAVE_STATS
+    ws_side1 = clock64() - ws_begin;
+#endif
     run_side(std::integral_constant<int, 0>{});
     hs.finish();
+#ifdef FFH_WAVE_STATS
+    if (lane == 0) {
+        const unsigned long long dt = clock64() - ws_begin;
+        atomicAdd(&cursor[20], dt); atomicMax(&cursor[21], dt);
+        atomicAdd(&cursor[22], ws_side1); atomicMax(&cursor[23], ws_side1);
+        atomicAdd(&cursor[24], (unsigned long long)ws_unfit); atomicAdd(&cursor[25], 1ull); atomicAdd(&cursor[26], (unsigned long long)ws_rows);
+        atomicMax(&cursor[27], (unsigned long long)ws_rows);
+    }
+#endif
 }
 
 // The instances: one per plan the cost model picks at genome scale for a 20-base pack (choose_plan / select_images: 11 + 9 with radii

@@ -872,6 +872,10 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
 // bit-identical to the three-kernel path that also delivers the hit lists.
 // st == nullptr: the target longs of the hits have not been gathered (k_hit_targets); the kernel then reads them through the
 // sorted hit keys itself -- its waves are busy with the ordered walk, so the gather hides behind them instead of costing a pass.
+// (Round 3 tried persistent blocks -- tables filled once per block, every wave looping over guides with the bounds / keys / target
+// longs of the next three guides requested ahead: 95 registers instead of 64, five waves per SIMD instead of eight, and 0.345
+// against 0.31 ms at hg38 scale, 0.34 against 0.29 ms on an eighth of it.  The chain of dependent loads is hidden better by the
+// three extra waves than by the prefetch.)
 __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
                                                         const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
                                                         const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
@@ -890,124 +894,80 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     __shared__ WalkLds wk;
     __shared__ GuideSummary out_lds[4];
     __syncthreads();
-    // A block's four waves take guides blockIdx.x * 4 + wave, + 4 * gridDim.x, ...: the tables above are filled once per block
-    // instead of once per four guides, and the chain of dependent loads in front of a guide's arithmetic -- segment bounds -> sorted
-    // keys -> target longs, three memory round trips that a guide with a dozen hits cannot hide (a bin shard, a small database) --
-    // is requested while the guides before it are being worked on: bounds three guides ahead, keys two, targets one.
-    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), stride = gridDim.x * 4;
-    const uint64_t tmask = (1ull << tbits) - 1ull;
-    struct Seg { uint32_t b, e, p0; bool skip; uint64_t gd; };
-    auto bounds = [&](uint32_t g) -> Seg {
-        Seg s{0u, 0u, 0u, true, 0ull};
-        if (g < n_guides) {
-            s.b = wave_uniform(seg_begin[g]); s.e = wave_uniform(seg_end[g]); s.p0 = wave_uniform(prior ? prior[g] : 0u);
-            s.gd = guides[g];
-            // multi-GPU fix-up pass: a shard's own aggregates (computed with prior 0) stand unless the positions of the shards before
-            // it push this guide's running total to the limit inside or before this shard
-            s.skip = fix_totals && !(s.p0 > 0u && s.p0 + wave_uniform(fix_totals[g]) >= overflow);
+    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), g = blockIdx.x * 4 + wave;
+    if (g >= n_guides) return;
+    const uint32_t b = wave_uniform(seg_begin[g]), e = wave_uniform(seg_end[g]), p0 = wave_uniform(prior ? prior[g] : 0u);
+    // multi-GPU fix-up pass: a shard's own aggregates (computed with prior 0) stand unless the positions of the shards before it
+    // push this guide's running total to the limit inside or before this shard
+    if (fix_totals && !(p0 > 0u && p0 + fix_totals[g] >= overflow)) return;
+    const uint64_t gd = guides[g];
+    uint32_t run = p0, kept = 0;
+    uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, closest_count = 0, n_scored = 0;
+    double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
+    for (uint32_t i = b; i < e && run < overflow; i += 64) {
+        const bool in = i + lane < e;
+        const uint64_t t = !in ? 0ull : st ? st[i + lane] : targets[hit_keys[i + lane] & ((1ull << tbits) - 1ull)];
+        const uint32_t c = in ? (uint32_t)(t >> 48) : 0u;
+        const uint32_t incl = wave_inclusive_scan_u32(c, lane);
+        const bool keep = in && (run + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
+        const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
+        kept += nk;
+        if (nk) run += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(nk - 1u));   // (nk is a ballot's popcount: uniform)
+        int mmi = 0xFF;
+        double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
+        if (keep) {
+            score_pair(gd, t, geo, &lt, mmi, f, h);
+            if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair(gd, t, geo, &lt);
         }
-        return s;
-    };
-    auto first_keys = [&](const Seg &s) -> uint64_t { return (!st && !s.skip && s.b + lane < s.e) ? hit_keys[s.b + lane] : 0ull; };
-    auto first_targets = [&](const Seg &s, uint64_t key) -> uint64_t {
-        if (s.skip || s.b + lane >= s.e) return 0ull;
-        return st ? st[s.b + lane] : targets[key & tmask];
-    };
-    uint32_t g = blockIdx.x * 4 + wave;
-    Seg sa = bounds(g), sb = bounds(g + stride), sc = bounds(g + 2 * stride);
-    uint64_t kb = first_keys(sb);
-    uint64_t ta = first_targets(sa, first_keys(sa));
-    for (; g < n_guides; g += stride) {
-        const uint64_t tb = first_targets(sb, kb);
-        const uint64_t kc = first_keys(sc);
-        const Seg sd = bounds(g + 3 * stride);
-        if (!sa.skip) {
-            const uint32_t b = sa.b, e = sa.e, p0 = sa.p0;
-            const uint64_t gd = sa.gd;
-            uint32_t run = p0, kept = 0;
-            uint32_t hist[5] = {0, 0, 0, 0, 0}, closest = 0xFFFFFFFFu, closest_count = 0, n_scored = 0;
-            double cfd_sum = 0.0, hsu_sum = 0.0, cfd_max = 0.0, jost_sum = 0.0, jost_max = 0.0, lane_cfd_max = 0.0, lane_jost_max = 0.0;
-            for (uint32_t i = b; i < e && run < overflow; i += 64) {
-                const bool in = i + lane < e;
-                const uint64_t t = i == b ? ta : !in ? 0ull : st ? st[i + lane] : targets[hit_keys[i + lane] & tmask];
-                const uint32_t c = in ? (uint32_t)(t >> 48) : 0u;
-                const uint32_t incl = wave_inclusive_scan_u32(c, lane);
-                const bool keep = in && (run + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
-                const uint32_t nk = (uint32_t)__popcll(__ballot(keep));
-                kept += nk;
-                if (nk) run += (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(nk - 1u));   // (nk is a ballot's popcount: uniform)
-                int mmi = 0xFF;
-                double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
-                if (keep) {
-                    score_pair(gd, t, geo, &lt, mmi, f, h);
-                    if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair(gd, t, geo, &lt);
-                }
-                const uint32_t m = keep ? (uint32_t)mmi : 0xFFu, ck = keep ? c : 0u;
+        const uint32_t m = keep ? (uint32_t)mmi : 0xFFu, ck = keep ? c : 0u;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) hist[k] += (m == (uint32_t)k) ? ck : 0u;  // ClosestHit.scala:57-59
-                const uint32_t cm = wave_min_u32((keep && m > 0) ? m : 0xFFFFFFFFu);  // :62-67, folded chunk by chunk
-                if (cm < closest) { closest = cm; closest_count = 0; }
-                if (cm != 0xFFFFFFFFu && cm == closest) closest_count += wave_sum_u32((m == closest) ? ck : 0u);
-                // ordered f64 sums: the kept hits are lanes 0 .. nk-1, walked in that order.  Unscored hits (the on-target itself) add
-                // +0.0, which leaves a non-negative sum bit for bit as it is, so the walk needs no mask; maxima do not depend on the
-                // order and are kept per lane (one wave reduction at the end).
-                const bool sc2 = keep && f == f;
-                const double fz = sc2 ? f * (double)c : 0.0, hz = sc2 ? h : 0.0;
-                lane_cfd_max = fmax(lane_cfd_max, sc2 ? f : 0.0);
-                n_scored += (uint32_t)__popcll(__ballot(sc2));
-                walk_park(wk, wave, lane, fz, hz);
-                walk_fold(wk, wave, nk, cfd_sum, hsu_sum);
-                if (want_jost) {
-                    const bool sj = keep && j == j;
-                    const double jz = sj ? j * (double)c : 0.0;
-                    lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
-                    walk_fold_jost(wk, wave, lane, nk, jz, jost_sum);
-                }
-            }
-            cfd_max = wave_max_f64(lane_cfd_max);
-            jost_max = wave_max_f64(lane_jost_max);
-            GuideSummary s;
-            s.n_hits = kept; s.ot_count = run - p0; s.overflow = run >= overflow;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) s.hist[k] = wave_sum_u32(hist[k]);
-            s.closest = closest;
-            s.closest_count = closest == 0xFFFFFFFFu ? 0u : closest_count;
-            s.in_genome = s.hist[0]; s.n_scored = n_scored;
-            s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
-            s.jost_max = jost_max; s.jost_sum = jost_sum;
-            // The 88 bytes leave as ONE coalesced store of 22 lanes (through the wave's LDS slot) instead of six 16-byte stores of lane
-            // 0: the copy in page-locked host memory crosses PCIe, where a 16-byte write costs a packet of its own.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the previous guide's reads of the slot are done)
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                out_lds[wave] = s; n_ret[g] = kept;
-                if (totals_out) totals_out[g] = min(run - p0, overflow);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            static_assert(sizeof(GuideSummary) == 88, "22 words");
-            if (lane < 22) {
-                const uint32_t v = reinterpret_cast<const uint32_t *>(&out_lds[wave])[lane];
-                reinterpret_cast<uint32_t *>(out + g)[lane] = v;
-                if (host_out) reinterpret_cast<uint32_t *>(host_out + g)[lane] = v;
-            }
+        for (int k = 0; k < 5; ++k) hist[k] += (m == (uint32_t)k) ? ck : 0u;  // ClosestHit.scala:57-59
+        const uint32_t cm = wave_min_u32((keep && m > 0) ? m : 0xFFFFFFFFu);  // :62-67, folded chunk by chunk
+        if (cm < closest) { closest = cm; closest_count = 0; }
+        if (cm != 0xFFFFFFFFu && cm == closest) closest_count += wave_sum_u32((m == closest) ? ck : 0u);
+        // ordered f64 sums: the kept hits are lanes 0 .. nk-1, walked in that order.  Unscored hits (the on-target itself) add +0.0,
+        // which leaves a non-negative sum bit for bit as it is, so the walk needs no mask; maxima do not depend on the order and
+        // are kept per lane (one wave reduction at the end).
+        const bool sc = keep && f == f;
+        const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
+        lane_cfd_max = fmax(lane_cfd_max, sc ? f : 0.0);
+        n_scored += (uint32_t)__popcll(__ballot(sc));
+        walk_park(wk, wave, lane, fz, hz);
+        walk_fold(wk, wave, nk, cfd_sum, hsu_sum);
+        if (want_jost) {
+            const bool sj = keep && j == j;
+            const double jz = sj ? j * (double)c : 0.0;
+            lane_jost_max = fmax(lane_jost_max, sj ? j : 0.0);
+            walk_fold_jost(wk, wave, lane, nk, jz, jost_sum);
         }
-        sa = sb; sb = sc; sc = sd; ta = tb; kb = kc;
     }
-}
-
-// blocks of a k_guide_epilogue launch: every block slot of the chip once (what the occupancy query says fits a CU x the CUs), fewer
-// for few guides
-inline unsigned epilogue_grid(uint32_t n_guides) {
-    static const unsigned cap = [] {
-        if (getenv("FFH_EPILOGUE_BLOCKS")) return (unsigned)std::max(1, atoi(getenv("FFH_EPILOGUE_BLOCKS")));
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_guide_epilogue, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        return (unsigned)(per_cu * cus);
-    }();
-    return std::min((unsigned)((n_guides + 3u) / 4u), cap);
+    cfd_max = wave_max_f64(lane_cfd_max);
+    jost_max = wave_max_f64(lane_jost_max);
+    GuideSummary s;
+    s.n_hits = kept; s.ot_count = run - p0; s.overflow = run >= overflow;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s.hist[k] = wave_sum_u32(hist[k]);
+    s.closest = closest;
+    s.closest_count = closest == 0xFFFFFFFFu ? 0u : closest_count;
+    s.in_genome = s.hist[0]; s.n_scored = n_scored;
+    s.cfd_max = cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
+    s.jost_max = jost_max; s.jost_sum = jost_sum;
+    // The 88 bytes leave as ONE coalesced store of 22 lanes (through the wave's LDS slot) instead of six 16-byte stores of lane 0: the
+    // copy in page-locked host memory crosses PCIe, where a 16-byte write costs a packet of its own -- 100 000 summaries took the
+    // kernel ~0.3 ms whatever the number of hits (a shard with an eighth of them: 0.306 against 0.308 ms).
+    if (lane == 0) {
+        out_lds[wave] = s; n_ret[g] = kept;
+        if (totals_out) totals_out[g] = min(run - p0, overflow);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    static_assert(sizeof(GuideSummary) == 88, "22 words");
+    if (lane < 22) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(&out_lds[wave])[lane];
+        reinterpret_cast<uint32_t *>(out + g)[lane] = v;
+        if (host_out) reinterpret_cast<uint32_t *>(host_out + g)[lane] = v;
+    }
 }
 
 __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ out_off,

@@ -1,7 +1,8 @@
-# kernels of the repeat-structured workload's LAST bounded discover call: per-kernel totals and the compare launches in order
+# kernels of the LAST discover call of a script (default: the repeat-structured workload, tools/skewed_ab.py): per-kernel totals and the big launches in order
+# usage: tools/skewed_timeline.sh [script.py args...]
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_sk
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_sk -o sk -- python $GRAFT_REPO_ROOT/tools/skewed_ab.py 2>/dev/null | tail -3
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_sk -o sk -- python ${@:-$GRAFT_REPO_ROOT/tools/skewed_ab.py} 2>/dev/null | tail -3
 k=$(find /tmp/prof_sk -name "*kernel_trace.csv" | head -1)
 python - "$k" <<'PY'
 import csv, sys, collections
@@ -15,7 +16,7 @@ t0 = seq[0][0]
 tot = collections.defaultdict(lambda: [0, 0])
 for s, e, n in seq:
     tot[n][0] += 1; tot[n][1] += e - s
-    if "k_compare<" in n or "segsort" in n or "k_sort_scatter" in n or "k_item_bin" in n:
+    if e - s > 12000:
         print("%9.1f us  +%8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, n))
 print("span %.1f us" % ((seq[-1][1] - t0) / 1e3))
 for n, (c, d) in sorted(tot.items(), key=lambda x: -x[1][1])[:25]:
