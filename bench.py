@@ -622,8 +622,10 @@ def main():
             # the complete discover product: scan + cut-off + aggregates + the retained hits (target long incl. count, mismatches) and
             # their positions on the host -- what ResultsAggregator hands to the writer (CRISPRHit: sequence, count, coordinates)
             "discover_with_lists_ms": lists_ms["lists"] if lists_ms else None,
-            # ... without the position arrays (the reference's discover table prints them only with --positionOutput)
+            # ... without the position arrays: what `discover` asks for unless --positionOutput is given (the reference's default table
+            # prints sequence, count and mismatches of every off-target; modules/OffTargetDiscovery.scala:51-53,146): the DEFAULT product
             "discover_with_lists_no_positions_ms": lists_ms["no_positions"] if lists_ms else None,
+            "discover_product_ms": {"default_table": lists_ms["no_positions"], "with_positionOutput": lists_ms["lists"]} if lists_ms else None,
             # ... with this library's per-hit pam*cfd array on top (8 more bytes per hit across the link)
             "discover_with_lists_and_hit_scores_ms": lists_ms["lists_and_hit_scores"] if lists_ms else None,
             "roofline": {"bound": "valu-issue", "kernel": "ffh::k_compare",

@@ -1088,6 +1088,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // typical run fills ~3/4 of the wave's LDS strip (kKW words of groups, kKC candidates); k_work_count / k_work_fill then list the
     // runs that have candidates, a bucket larger than the strip as several strip-sized group ranges.  Candidate lists larger than the
     // strip take the kernel's piecewise path.
+    double expect[2] = {0.0, 0.0};   // work entries the two lists are expected to hold (the compare launch's way of dealing them depends on it)
     auto side_plan = [&](hipStream_t st, int which, const Image &im, uint64_t n_targets, int width, int r_far, double n_patterns, uint32_t ng, SideArgs &S,
                          uint32_t rank_lo = 0u, uint32_t rank_hi = 63u, bool count_pairs = true) -> int {
         S = SideArgs{};
@@ -1099,17 +1100,25 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
         S.split = (uint32_t)cap_g;
         const uint32_t n_bat = (S.nb + S.NB - 1) / S.NB;
-        const uint64_t max_entries = (uint64_t)n_bat + (n_targets / 32 + S.nb) / S.split + 2;
+        {   // batches that have a target and a candidate: the shard's part of prefix-key space (plan_cost), the slab's ranks
+            const double part = (which == 0 ? ctx->span : 1.0) * (double)(rank_hi - rank_lo + 1u) / 64.0;
+            expect[which] = std::min({(double)n_bat * part, (double)ng * n_patterns * part, (double)n_targets * part});
+        }
+        // (what a guide set without pile-ups needs; one that needs more is noticed after the launch, which then runs again: below)
+        const uint64_t max_entries = (uint64_t)n_bat + 2 * ((n_targets / 32 + S.nb) / S.split + 1) + (uint64_t)((double)ng * n_patterns) / kKC + 2;
         FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
         FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
-        FFH_HIP(ctx->wl_list[which].reserve((size_t)max_entries));
+        // (FFH_WORK_LIST_LIMIT: test aid -- a first list that small, so that the run-again path below is taken)
+        const char *lim = getenv("FFH_WORK_LIST_LIMIT");
+        FFH_HIP(ctx->wl_list[which].reserve(lim && atol(lim) > 0 ? std::min<size_t>((size_t)max_entries, (size_t)atol(lim)) : (size_t)max_entries));
         FFH_HIP(ctx->side_scr[which].scan_tmp.reserve(scan_scratch_elems_safe(n_bat)));
         hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
                            ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u,
                            ctx->d_counters + kStatPairs + which, rank_lo, rank_hi, (uint32_t)width);
         exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->side_scr[which].scan_tmp.p, st);
-        hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
-                           ctx->wl_list[which].p, ctx->d_counters + kStatEntries + which, rank_lo, rank_hi, (uint32_t)width);
+        S.list_cap = (uint32_t)std::min<size_t>(ctx->wl_list[which].cap, 0xFFFFFFF0u);
+        hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
+                           ctx->wl_list[which].p, S.list_cap, ctx->d_counters + kStatEntries + which, rank_lo, rank_hi, (uint32_t)width);
         S.list = ctx->wl_list[which].p;
         S.n_list = ctx->wl_off[which].p + n_bat;
         return FFH_OK;
@@ -1134,6 +1143,11 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     const bool shared_prefix = bounded && n_guides <= batch && max_mm + plan.r1 < plan.a &&
                                !(getenv("FFH_SLAB_PREFIX") && std::strcmp(getenv("FFH_SLAB_PREFIX"), "per-slab") == 0);
     const uint64_t n_items_p_all = (uint64_t)n_guides * (uint64_t)np_p;
+    // (Who is retired after a slab is decided on exact position totals: the slab's hits ordered by guide, their target longs
+    // gathered, the counts added up, ~0.35 ms per slab.  Round 3 tried a cheaper lower bound -- the compare kernel adding up, per
+    // guide, the hits of every (job, group) step that finds two or more: the hits of a repeat family's guides are dense enough to be
+    // caught, but positions are what reaches the limit, and a repeat's targets carry counts in the hundreds: 1.3e8 raw hits
+    // instead of 4.7e7, 15.4 against 9.6 ms per step on the repeat-structured workload.  Dropped.)
     if (shared_prefix) {
         FFH_HIP(ctx->item_gid.reserve(n_items_p_all + (uint64_t)n_guides * (uint64_t)np_s + 64));
         const int rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, ctx->guides.p, -1, n_guides, 0u);
@@ -1173,7 +1187,8 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
             ca.gmap[0] = shared_prefix ? nullptr : (act_map ? act_map + g0 : nullptr);
             ca.gmap[1] = act_map ? act_map + g0 : nullptr;
-            launch_compare(ca, ctx->d_counters, ctx->compare_grid, st);
+            launch_compare(ca, ctx->d_counters, ctx->compare_grid, st,
+                           work_list_is_long(expect[0], ctx->compare_grid) && (plan.r2 < 0 || work_list_is_long(expect[1], ctx->compare_grid)));
             FFH_HIP(hipGetLastError());
             FFH_HIP(hipEventRecord(ctx->ev[4], st));
             unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
@@ -1193,12 +1208,22 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
             // silently wrong result (the bulge path has the same guard)
             if (cursor >= (1ull << 32) - 64) { ctx->err = "more than 2^32 raw hits in one scan: lower maxMismatch, split the guide set, or shard the bins over more GPUs"; return FFH_E_ARG; }
+            bool redo = false;
             if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept, copied device to device)
                 DevBuf<uint64_t> bigger;
                 FFH_HIP(bigger.reserve((size_t)(cursor + cursor / 2)));
                 if (cursor_before) FFH_HIP(hipMemcpyAsync(bigger.p, ctx->hits.p, (size_t)cursor_before * 8, hipMemcpyDeviceToDevice, st));
                 FFH_HIP(hipStreamSynchronize(st));
                 ctx->hits = std::move(bigger);
+                redo = true;
+            }
+            for (int w = 0; w < 2; ++w)   // a work list that did not hold all entries (candidates piled on a few buckets): the same
+                if (cnt[kStatEntries + w] > ctx->wl_list[w].cap) {
+                    FFH_HIP(hipStreamSynchronize(st));
+                    FFH_HIP(ctx->wl_list[w].reserve((size_t)(cnt[kStatEntries + w] + cnt[kStatEntries + w] / 4 + 64)));
+                    redo = true;
+                }
+            if (redo) {
                 const unsigned long long back[2] = {cursor_before, n_real_hits};
                 FFH_HIP(hipMemcpy(ctx->d_counters, back, 16, hipMemcpyHostToDevice));  // the hit cursor and the hit count go back to where this batch began
                 continue;

@@ -48,6 +48,9 @@ namespace ffh {
 #ifndef FFH_WAVES_PER_SIMD
 #define FFH_WAVES_PER_SIMD 4
 #endif
+#ifndef FFH_QUEUE_CHUNK
+#define FFH_QUEUE_CHUNK 16    // work entries a wave draws from its queue at a time (0: fixed stride, no queue); 8: 1.07, 16 / 32: 1.06 ms per launch
+#endif
 #ifndef FFH_GPL
 #define FFH_GPL 6
 #endif
@@ -66,7 +69,8 @@ constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is s
 constexpr int kMaxParts = 16;             // jobs per candidate at most (park: fewer when a piece has many candidates)
 constexpr int kMinRest = 7, kMaxRest = 12;   // rest-key widths k_compare has a row form for (19-mers with a 12-base bucket key: 7)
 
-constexpr uint32_t kStatPairs = 4, kStatEntries = 6;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
+constexpr uint32_t kStatPairs = 4, kStatEntries = 6, kQueue = 32, kQueues = 16;   // cursor[32 + 16 side + k]: the side's k-th work queue (chunks drawn so far)
+constexpr uint32_t kQueueChunk = FFH_QUEUE_CHUNK;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
 
 __host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 + 3) & ~3; }   // words per group of 32 targets (16-byte multiple)
 
@@ -87,6 +91,8 @@ struct SideArgs {
                               // bucket larger than the strip (a repeat family) -- one strip-sized range of its groups, so that such a
                               // bucket is spread over many waves instead of pinning one
     const uint32_t *n_list;   // their number (device memory: built on the stream, no host round trip)
+    uint32_t list_cap;        // entries the list holds (a guide set that needs more is noticed by the host after the launch, which
+                              // then runs again with a larger list: scan_impl)
     int r_far;                // suffix side: r1 -- a pair is reported here only with MORE than r1 mismatches in its rest key (the
                               // prefix image reports the others); prefix side: -1
 };
@@ -108,6 +114,7 @@ __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int fir
     if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
     if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
+    if (threadIdx.x >= kQueue && threadIdx.x < kQueue + 2 * kQueues) cursor[threadIdx.x] = 0ull;  // the two images' work queues (k_compare)
 #ifdef FFH_WAVE_STATS   // (dev builds: tools/build_variant.sh WORK stats -DFFH_WAVE_STATS)
     if (threadIdx.x >= 20 && threadIdx.x < 32) cursor[threadIdx.x] = 0ull;
 #endif
@@ -204,7 +211,9 @@ struct HitStage {
             chunk_left = old_left - fill;
         }
         // a record leaves as the sort key (global guide << tbits) | database index -- the index lookup rides on the flush instead of
-        // a pass of its own over all hits
+        // a pass of its own over all hits.  (Requesting the look-ups of all staged records -- four per lane -- before the first key
+        // is stored, for the rows of a repeat family where a wave flushes after every third step: nothing gained there, 1.12
+        // against 1.04 ms per launch at hg38 scale, where a flush holds a handful of records; dropped.)
         for (uint32_t i = lane; i < fill; i += 64) {
             const unsigned long long dst = i < old_left ? old_pos + i : new_pos + (i - old_left);
             if (dst < cap) {
@@ -337,7 +346,10 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
 
 // ---------------------------------------------------------------------------------------------------------
 // The work list of one image for one compare launch, built from the bucket boundaries and the candidate CSR offsets:
-//   k_work_count  per batch of NB consecutive buckets: 0 entries if it has no candidate or no target, else ceil(groups / split);
+//   k_work_count  per batch of NB consecutive buckets: 0 entries if it has no candidate or no target, else ceil(groups / split) x
+//                 ceil(candidates / kKC) -- an entry never holds more than the wave's strip and candidate table take (a repeat family's
+//                 bucket with thousands of candidate guides used to be ONE entry per 51 groups, worked off piece by piece by one wave
+//                 while the launch waited for it);
 //                 the launch also adds up the executed-pair statistic (targets x candidates of every bucket) from the partial
 //                 sums k_item_bin left per partition
 //   (scan)
@@ -354,6 +366,28 @@ __device__ __forceinline__ void slab_run(uint32_t b0, uint32_t b1, uint32_t lo, 
     s1 = s0;
     while (s1 < b1) { const uint32_t r = bucket_rank(s1, width); if (r < lo || r > hi) break; ++s1; }
 }
+// How a batch is cut into work entries: n_g pieces of at most `split` groups x n_c chunks of at most kKC >> cs candidates.  A batch
+// of ordinary buckets is one piece and -- unless a skewed guide set piles candidates on it -- one chunk.  A bucket larger than the
+// strip (n_g > 1) or a batch of one bucket (the suffix image at genome scale) is a repeat family's when it also has many candidates,
+// and its rows are then full of hits, each costing more than the test that found it: one entry of 42 groups x 256 candidates kept a
+// wave busy for a millisecond while the launch waited for it.  Such a batch takes smaller candidate chunks, so that an entry stays
+// within kMaxEntryWork group tests.
+#ifndef FFH_MAX_ENTRY_WORK
+#define FFH_MAX_ENTRY_WORK 2048
+#endif
+constexpr uint32_t kMaxEntryWork = FFH_MAX_ENTRY_WORK, kMaxCandShift = 4;
+struct WorkSplit { uint32_t n_g, n_c, cs; };
+__device__ __forceinline__ WorkSplit work_split(uint32_t ngr, uint32_t nc, uint32_t split, bool one_bucket) {
+    WorkSplit w;
+    w.n_g = (ngr + split - 1u) / split;
+    w.cs = 0;
+    const uint32_t piece = min(ngr, split);
+    if (w.n_g > 1u || one_bucket)
+        while (w.cs < kMaxCandShift && ((uint32_t)kKC >> w.cs) * piece > kMaxEntryWork) ++w.cs;
+    const uint32_t cs_n = (uint32_t)kKC >> w.cs;
+    w.n_c = (nc + cs_n - 1u) / cs_n;
+    return w;
+}
 __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
                                                     uint32_t n_bat, uint32_t *__restrict__ counts, const unsigned long long *__restrict__ part_pairs,
                                                     uint32_t n_part, unsigned long long *__restrict__ pairs_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
@@ -363,7 +397,8 @@ __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__
         uint32_t s0, s1;
         slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
         const uint32_t ngr = gstart[s1] - gstart[s0], nc = istart[s1] - istart[s0];
-        counts[t] = (ngr && nc) ? (ngr + split - 1u) / split : 0u;
+        const WorkSplit w = work_split(ngr, nc, split, s1 - s0 == 1u);
+        counts[t] = (ngr && nc) ? w.n_g * w.n_c : 0u;
     }
     if (blockIdx.x != 0) return;
     // the executed-pair statistic (targets x candidates of every bucket): k_item_bin left one partial sum per partition
@@ -375,17 +410,36 @@ __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(pairs_out, red[0] + red[1] + red[2] + red[3]);
 }
-__global__ void k_work_fill(const uint32_t *__restrict__ gstart, uint32_t nb, uint32_t NB, uint32_t split, uint32_t n_bat, const uint32_t *__restrict__ offs,
-                            uint4 *__restrict__ list, unsigned long long *__restrict__ n_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_bat) return;
-    const uint32_t o = offs[t], n = offs[t + 1] - o;
-    if (t == n_bat - 1) *n_out = offs[n_bat];
-    if (!n) return;
-    uint32_t s0, s1;
-    slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
-    const uint32_t gs = gstart[s0], ge = gstart[s1];
-    for (uint32_t k = 0; k < n; ++k) list[o + k] = make_uint4(s0, s1 - s0, gs + k * split, min(ge, gs + (k + 1) * split));
+// entry = {first bucket, buckets | cs << 4 | candidate chunk << 7, first group, end group}: candidates [chunk * (kKC >> cs), + kKC >> cs)
+// of the batch's list.  A thread per batch; a batch with many entries (a repeat family's bucket: hundreds) is written by its whole wave.
+__global__ __launch_bounds__(256) void k_work_fill(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
+                                                   uint32_t n_bat, const uint32_t *__restrict__ offs, uint4 *__restrict__ list, uint32_t list_cap,
+                                                   unsigned long long *__restrict__ n_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    uint32_t o = 0, n = 0, s0 = 0, s1 = 0, gs = 0, ge = 0;
+    WorkSplit w{1u, 1u, 0u};
+    if (t < n_bat) {
+        o = offs[t]; n = offs[t + 1] - o;
+        if (t == n_bat - 1) *n_out = offs[n_bat];
+    }
+    if (n) {
+        slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
+        gs = gstart[s0]; ge = gstart[s1];
+        w = work_split(ge - gs, istart[s1] - istart[s0], split, s1 - s0 == 1u);
+    }
+    auto entry = [&](uint32_t k, uint32_t o_, uint32_t s0_, uint32_t nbv_, uint32_t gs_, uint32_t ge_, uint32_t n_g_, uint32_t cs_) {
+        const uint32_t kc = k / n_g_, kg = k - kc * n_g_;   // (the pieces of one candidate chunk are neighbours; the queue deals neighbours to different waves)
+        if (o_ + k < list_cap) list[o_ + k] = make_uint4(s0_, nbv_ | (cs_ << 4) | (kc << 7), gs_ + kg * split, min(ge_, gs_ + (kg + 1u) * split));
+    };
+    constexpr uint32_t kSerial = 4;
+    if (n && n <= kSerial)
+        for (uint32_t k = 0; k < n; ++k) entry(k, o, s0, s1 - s0, gs, ge, w.n_g, w.cs);
+    for (uint64_t big = __ballot(n > kSerial); big; big &= big - 1ull) {
+        const int src = __ffsll((long long)big) - 1;
+        const uint32_t n_b = __shfl(n, src, 64), o_b = __shfl(o, src, 64), s0_b = __shfl(s0, src, 64), nbv_b = __shfl(s1 - s0, src, 64);
+        const uint32_t gs_b = __shfl(gs, src, 64), ge_b = __shfl(ge, src, 64), ng_b = __shfl(w.n_g, src, 64), cs_b = __shfl(w.cs, src, 64);
+        for (uint32_t k = lane; k < n_b; k += 64) entry(k, o_b, s0_b, nbv_b, gs_b, ge_b, ng_b, cs_b);
+    }
 }
 
 // job -> bucket lookup of a parked piece: kMaxRows words of 64 marker bits, one bit per non-empty bucket at the job before its first
@@ -394,7 +448,8 @@ constexpr int kMaxRows = 16;               // rows (of 64 jobs) of one parked pi
 // R0 / R1: the rest widths of the prefix / suffix image this instance is compiled for (the row form is then fixed and the kernel's
 // registers are those of max(R0, R1) instead of the widest form); 0 = any width, chosen per row.  FAR1: r1 + 1 of the suffix image
 // when the instance is compiled for it (scan_row), -1 = read from the arguments.  The host picks the instance (launch_compare).
-template <int R0, int R1, int FAR1>
+// QUEUE: the work entries are dealt through queues (long lists); else a fixed stride (the host decides: launch_compare)
+template <int R0, int R1, int FAR1, bool QUEUE>
 __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(const CompareArgs A, unsigned long long *__restrict__ cursor) {
     __shared__ __attribute__((aligned(16))) uint32_t strip_lds[kCmpWaves][kKW + 64];
     __shared__ __attribute__((aligned(16))) uint2 cand_lds[kCmpWaves][kKC];
@@ -426,9 +481,44 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         constexpr int FARC = side ? FAR1 : 0;          // the prefix image has no far condition
         const SideArgs S = A.side[side];
         if (!S.n_list) return;
-        const uint32_t n_total = *S.n_list;
-        uint32_t q = blockIdx.x * kCmpWaves + wave;
-        if (q >= n_total) return;
+        const uint32_t n_total = min(*S.n_list, S.list_cap);
+        // The order in which a wave takes work entries.  Entries differ in weight (buckets differ in size, a repeat family's rows are
+        // full of hits), and with a fixed stride the launch ended when its unluckiest wave did: 22 % after the mean wave at hg38 scale,
+        // 2 .. 6 x the mean on the repeat-structured workload.  So the entries are dealt in chunks of kQueueChunk: chunk t stands for
+        // the entries t, t + C, t + 2 C, ... (C = number of chunks: the pieces of one heavy bucket, neighbours in the list, go to
+        // different waves), a wave's first chunk is its own number, every further one the next ticket of its queue -- one atomic with
+        // its round trip per kQueueChunk entries, drawn where the wave has nothing in flight that it could not wait for.  kQueues
+        // queues per side, each with its share of the waves and of the chunks: same-address atomics complete at ~90 per microsecond
+        // on this part, and one queue for 4096 waves made the draws themselves the bottleneck (chunks of 4: 1.98 ms per launch
+        // against 1.14 with the fixed stride).
+        // kEnd: no chunk left (tickets only grow, so it stays that way); kNone: a chunk's entry past the end of the list.
+        constexpr uint32_t kEnd = 0xFFFFFFFFu, kNone = 0xFFFFFFFEu;
+        // (a list with fewer than two chunks per wave -- a small database, a bin shard, the slabs of a bounded scan -- keeps the fixed
+        // stride: chunks of 16 would leave most waves without work, and smaller chunks mean a draw, with its exposed round trip,
+        // per entry or two: measured 0.46 against 0.29 ms per step at chr22 scale, 0.39 against 0.25 ms per launch on an eighth
+        // of hg38.  The host picks the instance from the list lengths it expects; decided in here, per side at run time, the
+        // queue's gain at hg38 scale was gone -- 1.13 against 1.05 ms per launch.)
+        constexpr uint32_t chunk_len = kQueueChunk ? kQueueChunk : 1u;
+        const uint32_t n_chunks = (n_total + chunk_len - 1u) / chunk_len;
+        uint32_t chunk = blockIdx.x * kCmpWaves + wave, chunk_j = 0, stride_q = chunk;
+        const uint32_t n_queues = min(kQueues, gridDim.x), my_queue = blockIdx.x % n_queues;   // (every queue has a block that draws from it)
+        unsigned long long *queue = cursor + kQueue + side * kQueues + my_queue;
+        auto next_q = [&]() -> uint32_t {   // uniform
+            if constexpr (!QUEUE || kQueueChunk == 0) { const uint32_t r = stride_q < n_total ? stride_q : kEnd; stride_q += n_waves; return r; }
+            if (chunk_j == chunk_len) {
+                uint32_t t = 0;
+                if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(queue, 1ull);
+                chunk = chunk < n_chunks ? n_waves + my_queue + n_queues * uni(t) : chunk;
+                chunk_j = 0;
+            }
+            if (chunk >= n_chunks) return kEnd;
+            const uint32_t r = chunk + chunk_j * n_chunks;
+            ++chunk_j;
+            return r < n_total ? r : kNone;
+        };
+        uint32_t q = next_q();
+        if (q == kEnd) return;
+        uint32_t q1 = next_q(), q2 = next_q(), q3 = next_q(), q4 = next_q();
         const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ gwords = S.gwords;
         const uint32_t *__restrict__ list = reinterpret_cast<const uint32_t *>(S.list);
         const uint2 *__restrict__ gtab = S.gtab;
@@ -449,7 +539,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         auto load_desc = [&](uint32_t qq, uint32_t dE, uint32_t &dG, uint32_t &dI) {
             dG = 0; dI = 0;
             if (qq < n_total) {
-                const uint32_t idx = lane_of(dE, 0) + min(lane & 15u, lane_of(dE, 1));
+                const uint32_t idx = lane_of(dE, 0) + min(lane & 15u, lane_of(dE, 1) & 15u);
                 dG = gstart[idx + ((lane & 48u) == 16u ? dd_off : 0u)];
                 dI = istart[idx];
             }
@@ -458,10 +548,13 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             Extent e{0, 0, 0, 0, 0, 0};
             if (qq < n_total) {
                 e.b0 = lane_of(dE, 0);
-                e.nbv = lane_of(dE, 1);
+                const uint32_t y = lane_of(dE, 1);
+                e.nbv = y & 15u;
                 e.g0 = max(lane_of(dG, 0), lane_of(dE, 2));
                 e.g1 = min(lane_of(dG, e.nbv), lane_of(dE, 3));
-                e.c0 = lane_of(dI, 0); e.c1 = lane_of(dI, e.nbv);
+                const uint32_t cs_n = (uint32_t)kKC >> ((y >> 4) & 7u);
+                e.c0 = lane_of(dI, 0) + (y >> 7) * cs_n;
+                e.c1 = min(lane_of(dI, e.nbv), e.c0 + cs_n);
                 if (e.g1 <= e.g0) { e.g1 = e.g0; e.c1 = e.c0; }   // nothing to compare the candidates with
             }
             return e;
@@ -614,12 +707,12 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         // ---- prologue: work entries of four batches, boundaries of three, candidate ids of two, groups and guide entries of the first ----
         uint32_t dE0, dE1, dE2, dE3, dG0, dI0, dG1, dI1, dG2, dI2;
         load_entry(q, dE0);
-        load_entry(q + n_waves, dE1);
-        load_entry(q + 2 * n_waves, dE2);
-        load_entry(q + 3 * n_waves, dE3);
+        load_entry(q1, dE1);
+        load_entry(q2, dE2);
+        load_entry(q3, dE3);
         load_desc(q, dE0, dG0, dI0);
-        load_desc(q + n_waves, dE1, dG1, dI1);
-        load_desc(q + 2 * n_waves, dE2, dG2, dI2);
+        load_desc(q1, dE1, dG1, dI1);
+        load_desc(q2, dE2, dG2, dI2);
         uint4 kreg[kKeyRegs];
         uint32_t greg_a[kGidRegs], greg_b[kGidRegs];
         uint2 ereg[kGidRegs];
@@ -629,13 +722,13 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         for (int j = 0; j < kGidRegs; ++j) { ereg[j] = make_uint2(0, 0); greg_a[j] = 0; greg_b[j] = 0; }
         const uint32_t cap_g = (uint32_t)kKW / GW;   // groups the strip holds
         {
-            const Extent e0 = extent_of(q, dE0, dG0, dI0), e1 = extent_of(q + n_waves, dE1, dG1, dI1);
+            const Extent e0 = extent_of(q, dE0, dG0, dI0), e1 = extent_of(q1, dE1, dG1, dI1);
             load_gids(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a);
             load_gids(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_b);
             load_groups(e0.g0, min(e0.g1, e0.g0 + cap_g), kreg);
             load_entries(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a, ereg);
         }
-        for (; q < n_total; q += n_waves) {
+        while (q != kEnd) {
             const Extent e = extent_of(q, dE0, dG0, dI0);
             const bool fits = e.g1 - e.g0 <= cap_g && e.c1 - e.c0 <= (uint32_t)kKC, work = e.c1 > e.c0;
             uint32_t n_jobs = 0;
@@ -663,9 +756,9 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             // ---- request what the next batches need: the work entry of batch +4, boundaries of +3, candidate ids of +2, guide entries
             //      and groups of +1 ----
             uint32_t dE4, dG3, dI3;
-            load_entry(q + 4 * n_waves, dE4);
-            load_desc(q + 3 * n_waves, dE3, dG3, dI3);
-            const Extent e1 = extent_of(q + n_waves, dE1, dG1, dI1), e2 = extent_of(q + 2 * n_waves, dE2, dG2, dI2);
+            load_entry(q4, dE4);
+            load_desc(q3, dE3, dG3, dI3);
+            const Extent e1 = extent_of(q1, dE1, dG1, dI1), e2 = extent_of(q2, dE2, dG2, dI2);
 #pragma unroll
             for (int j = 0; j < kGidRegs; ++j) greg_a[j] = greg_b[j];
             load_gids(e2.c0, min(e2.c1, e2.c0 + (uint32_t)kKC), greg_b);
@@ -675,6 +768,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             if (n_jobs) rows(n_jobs);
             dE0 = dE1; dE1 = dE2; dE2 = dE3; dE3 = dE4;
             dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
+            q = q1; q1 = q2; q2 = q3; q3 = q4; q4 = next_q();
         }
     };
     run_side(std::integral_constant<int, 1>{});
@@ -697,19 +791,24 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
 // The instances: one per plan the cost model picks at genome scale for a 20-base pack (choose_plan / select_images: 11 + 9 with radii
 // 2 + 1 for <= 4 mismatches, 10 + 10 with 1 + 1 and 2 + 2 for <= 3 and <= 5), and the any-width one for everything else.
 template <int R0, int R1, int FAR1>
-inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_compare<R0, R1, FAR1>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool queue) {
+    if (queue) hipLaunchKernelGGL((k_compare<R0, R1, FAR1, true>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+    else hipLaunchKernelGGL((k_compare<R0, R1, FAR1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
-inline void launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
+// long_lists: both images' work lists are expected to hold at least two queue chunks per wave (work_list_is_long)
+inline void launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool long_lists) {
     static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;
+    static const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (A/B, tests)
+    const bool queue = queue_env < 0 ? long_lists : queue_env != 0;
     const bool two = ca.side[1].n_list != nullptr;
     const int r0 = (int)ca.side[0].rest, r1 = two ? (int)ca.side[1].rest : 0, far = two ? ca.side[1].r_far + 1 : 0;
     if (!generic_only && two) {
-        if (r0 == 9 && r1 == 11 && far == 3) return launch_compare_as<9, 11, 3>(ca, cursor, grid, st);
-        if (r0 == 10 && r1 == 10 && far == 2) return launch_compare_as<10, 10, 2>(ca, cursor, grid, st);
-        if (r0 == 10 && r1 == 10 && far == 3) return launch_compare_as<10, 10, 3>(ca, cursor, grid, st);
+        if (r0 == 9 && r1 == 11 && far == 3) return launch_compare_as<9, 11, 3>(ca, cursor, grid, st, queue);
+        if (r0 == 10 && r1 == 10 && far == 2) return launch_compare_as<10, 10, 2>(ca, cursor, grid, st, queue);
+        if (r0 == 10 && r1 == 10 && far == 3) return launch_compare_as<10, 10, 3>(ca, cursor, grid, st, queue);
     }
-    launch_compare_as<0, 0, -1>(ca, cursor, grid, st);
+    hipLaunchKernelGGL((k_compare<0, 0, -1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
+inline bool work_list_is_long(double expected_entries, unsigned grid) { return kQueueChunk != 0 && expected_entries >= 2.0 * kQueueChunk * grid * kCmpWaves; }
 
 }  // namespace ffh

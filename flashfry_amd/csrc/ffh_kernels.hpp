@@ -875,7 +875,8 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
 // (Round 3 tried persistent blocks -- tables filled once per block, every wave looping over guides with the bounds / keys / target
 // longs of the next three guides requested ahead: 95 registers instead of 64, five waves per SIMD instead of eight, and 0.345
 // against 0.31 ms at hg38 scale, 0.34 against 0.29 ms on an eighth of it.  The chain of dependent loads is hidden better by the
-// three extra waves than by the prefetch.)
+// three extra waves than by the prefetch.  Two or four guides per wave one after the other, the tables filled once per 8 or 16 guides:
+// 0.335 against 0.313 ms.)
 __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
                                                         const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
                                                         const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,

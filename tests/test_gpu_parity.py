@@ -863,3 +863,47 @@ def test_error_paths_added_since_round_1(capi, oracle, monkeypatch):
         ctx.load_soa(t2, p2)
         assert ctx.info().prefix_bases == 8 and ctx.info().suffix_bases == 12
         assert_same_hits(ctx.discover(g2, 4, 2000), odb.discover(g2, 4, 2000))
+
+
+def test_work_list_that_outgrows_its_first_allocation_and_piled_up_candidates(capi, oracle, monkeypatch):
+    """(1) the compare launch's work list starts at a size that suits a guide set without pile-ups and is cut off there; the host
+    notices the cut after the launch, grows the list and runs the batch again (FFH_WORK_LIST_LIMIT forces a tiny first list);
+    (2) many guides of one family on one huge bucket: the bucket's entries are split by candidate chunks as well as by groups
+    (work_split) and every chunk of every piece reports its hits exactly once"""
+    odb, t, p, g = dense_case(oracle, n_random=90_000, n_guides=700, n_dense=40, variants=150, seed=31)
+    want = odb.discover(g, 4, 300)
+    monkeypatch.setenv("FFH_WORK_LIST_LIMIT", "64")
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for bounding in (0, 1):
+            ctx.set_bounding(bounding)
+            got = ctx.discover(g, 4, 300)
+            assert_same_hits(got, want)
+            assert_same_scores(oracle, 3, g, got, want)
+    monkeypatch.delenv("FFH_WORK_LIST_LIMIT")
+    # one family: 3000 near-copies of one 20-mer among random targets, 600 guides that are near-copies as well -> one prefix bucket
+    # and one suffix bucket with hundreds of candidates and ~100 groups
+    rng = np.random.default_rng(5)
+    base = int(rng.integers(0, 1 << 40))
+    def near(n, k):
+        out = np.full(n, base, dtype=np.uint64)
+        for i in range(n):
+            for _ in range(int(rng.integers(0, k + 1))):
+                out[i] ^= np.uint64(int(rng.integers(1, 4)) << (2 * int(rng.integers(4, 16))))   # (bases 2..7 and 12..19 stay: shared buckets)
+        return out
+    fam = np.unique(near(6000, 3))
+    rest = rng.integers(0, 1 << 40, size=60_000, dtype=np.uint64)
+    raw = np.unique(np.concatenate([fam, rest]))
+    counts = rng.integers(1, 3, size=len(raw)).astype(np.uint64)
+    t = (raw << np.uint64(6)) | np.uint64(0b101010) | (counts << np.uint64(48))
+    n_pos = int(counts.sum())
+    p = rng.integers(0, 1 << 27, size=n_pos, dtype=np.uint64) | (np.uint64(23) << np.uint64(52)) | (np.uint64(1) << np.uint64(32))
+    g = (np.unique(near(900, 2)) << np.uint64(6)) | np.uint64(0b101010) | (np.uint64(1) << np.uint64(48))
+    odb = oracle.db_from_sorted(3, t, p, contigs=["c1"])
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for max_ot in (2 ** 31 - 1, 500):
+            got, want = ctx.discover(g, 4, max_ot), odb.discover(g, 4, max_ot)
+            assert_same_hits(got, want)
+            assert_same_scores(oracle, 3, g, got, want)
+        assert int(got.summaries["overflow"].sum()) > 0

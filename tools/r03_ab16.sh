@@ -1,0 +1,24 @@
+#!/bin/bash
+# entries of heavy buckets split by candidate chunks (kMaxEntryWork), run-again path of the work list
+mkdir -p gpurun_out/r03p
+O=gpurun_out/r03p
+S=$PWD/flashfry_amd/lib/ab
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x > $O/pytest1.log 2>&1; echo "pytest rc=$?" >> $O/pytest1.log; tail -4 $O/pytest1.log
+for lib in "" $S/work1k.so $S/work4k.so $S/static_queue.so; do
+  echo "== skewed ${lib:-work2k}" | tee -a $O/ab.txt
+  FFH_LIBRARY=$lib timeout 600 python tools/skewed_ab.py 2>&1 | grep "bounding" | cut -c1-420 | tee -a $O/ab.txt
+done
+echo "== skewed, wave stats" | tee -a $O/ab.txt
+FFH_LIBRARY=$S/stats_q.so timeout 600 python tools/skewed_ab.py 2>&1 | grep "wave stats" | tail -6 | tee -a $O/ab.txt
+run() { # name, env...
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --no-traffic --cpu-seconds 0 --no-verify --no-skewed --no-c2 --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$name', round(d['ms_per_step'], 3), {k: round(v, 3) for k, v in d['breakdown_ms'].items()}, 'raw', d['hits']['raw'], 'tiles', d['plan']['tiles'])" | tee -a $O/ab.txt
+}
+for rep in 1 2; do
+  run work2k X=1
+  run static FFH_LIBRARY=$S/static_queue.so
+done
+timeout 1200 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--targets", type=float, default=3.0e8)
     ap.add_argument("--guides", type=int, default=100000)
     ap.add_argument("--plan-a", type=int, default=-1, help="force the prefix width (default: the library's choice)")
+    ap.add_argument("--plan-r1", type=int, default=-1, help="force the prefix radius")
     args = ap.parse_args()
     import torch
     from flashfry_amd import capi, synth
@@ -26,8 +27,8 @@ def main():
     t, p = db["targets"][lo:hi].contiguous(), db["positions"][plo:phi].contiguous()
     with capi.Context(3) as ctx:
         torch.cuda.synchronize()
-        if args.plan_a >= 0:
-            ctx.set_plan(args.plan_a, -1)
+        if args.plan_a >= 0 or args.plan_r1 >= 0:
+            ctx.set_plan(args.plan_a, args.plan_r1)
         ctx.load_soa_device(t.data_ptr(), hi - lo, p.data_ptr(), phi - plo)
         for _ in range(3):
             ctx.scan_device(gd.data_ptr(), args.guides, 4)
