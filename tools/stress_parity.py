@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep against the oracle (dev tool, GPU box): many seeds x sizes x mismatch budgets x cut-offs through the
 same helpers as tests/test_gpu_parity.py.  Prints one line per case and stops at the first difference.
-  python tools/stress_parity.py [seconds]"""
+  python tools/stress_parity.py [seconds [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ from test_gpu_parity import dense_case
 
 oracle = oracle_lib.load()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     seed = int(rng.integers(0, 1 << 30))
