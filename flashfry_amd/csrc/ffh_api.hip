@@ -559,22 +559,28 @@ static hipError_t fence_in(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : h
 static hipError_t fence_out(ffh_ctx *ctx) { return ctx->borrowed ? hipSuccess : hipStreamSynchronize(ctx->st); }
 
 // copies the counter block to page-locked memory and, after it, the sequence number the host is polling for
-__global__ void k_publish(const unsigned long long *__restrict__ counters, volatile unsigned long long *__restrict__ host, unsigned long long seq) {
+__global__ void k_publish(const unsigned long long *__restrict__ counters, volatile unsigned long long *__restrict__ host, unsigned long long seq,
+                          const uint32_t *__restrict__ word /* nullable: one more device word the host wants -> host[17] */) {
     if (counters && threadIdx.x < 16) host[threadIdx.x] = counters[threadIdx.x];
+    if (word && threadIdx.x == 17) host[17] = *word;
     __threadfence_system();
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) host[16] = seq;
 }
-// everything issued on the stream so far has completed (and `out`, if given, holds the device counters)
-static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, nullable */) {
+// everything issued on the stream so far has completed (and `out`, if given, holds the device counters; `word_out` the device word
+// `word`).  Whatever the host wants to read after the wait has to come through the page-locked block: an asynchronous copy into
+// pageable host memory -- a stack variable -- is only known to have landed after a stream synchronisation, not when a later kernel's
+// store is seen (the number of guides still active after a slab was read that way; once in ~60 000 randomised cases it was stale).
+static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, nullable */, const uint32_t *word = nullptr, uint32_t *word_out = nullptr) {
     static const bool no_spin = getenv("FFH_NO_SPIN") && atoi(getenv("FFH_NO_SPIN")) == 1;
     if (no_spin || !ctx->h_pub) {
         if (out) { hipError_t e = hipMemcpyAsync(out, ctx->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st); if (e != hipSuccess) return e; }
+        if (word) { hipError_t e = hipMemcpyAsync(word_out, word, 4, hipMemcpyDeviceToHost, ctx->st); if (e != hipSuccess) return e; }
         return hipStreamSynchronize(ctx->st);
     }
     const unsigned long long seq = ++ctx->pub_seq;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->st, out ? (const unsigned long long *)ctx->d_counters : (const unsigned long long *)nullptr,
-                       (volatile unsigned long long *)ctx->d_pub, seq);
+                       (volatile unsigned long long *)ctx->d_pub, seq, word);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     volatile unsigned long long *h = ctx->h_pub;
@@ -589,6 +595,7 @@ static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, n
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     if (out) for (int i = 0; i < 16; ++i) out[i] = h[i];
+    if (word) *word_out = (uint32_t)h[17];
     return hipSuccess;
 }
 
@@ -1274,8 +1281,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                            (const uint32_t *)ctx->g_pos.p, n_guides, ctx->g_active.p, ctx->g_map.p);
         FFH_HIP(hipGetLastError());
         uint32_t still = 0;
-        FFH_HIP(hipMemcpyAsync(&still, ctx->g_pos.p + n_guides, 4, hipMemcpyDeviceToHost, st));
-        FFH_HIP(spin_wait(ctx, nullptr));
+        FFH_HIP(spin_wait(ctx, nullptr, ctx->g_pos.p + n_guides, &still));
         ctx->tm.retired_guides = n_guides - still;
         act_guides = ctx->g_active.p; act_map = ctx->g_map.p; n_act = still;
     }
