@@ -798,7 +798,7 @@ inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor,
 // long_lists: both images' work lists are expected to hold at least two queue chunks per wave (work_list_is_long)
 inline void launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool long_lists) {
     static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;
-    static const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (A/B, tests)
+    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (A/B, tests; read per launch)
     const bool queue = queue_env < 0 ? long_lists : queue_env != 0;
     const bool two = ca.side[1].n_list != nullptr;
     const int r0 = (int)ca.side[0].rest, r1 = two ? (int)ca.side[1].rest : 0, far = two ? ca.side[1].r_far + 1 : 0;

@@ -907,3 +907,24 @@ def test_work_list_that_outgrows_its_first_allocation_and_piled_up_candidates(ca
             assert_same_hits(got, want)
             assert_same_scores(oracle, 3, g, got, want)
         assert int(got.summaries["overflow"].sum()) > 0
+
+
+def test_work_queues_of_the_compare_launch_on_short_lists(capi, oracle, monkeypatch):
+    """the queue instance of k_compare is picked for long work lists only (hg38 scale: the full-scale tests and the bench's own
+    verification run it); FFH_WORK_QUEUE=1 forces it here, where most waves find their queue empty after their first chunk and
+    the lists end inside a chunk -- every entry must still be taken exactly once"""
+    monkeypatch.setenv("FFH_WORK_QUEUE", "1")
+    for seed, n_t, n_g, mm in ((3, 250_000, 400, 4), (4, 70_000, 150, 3), (5, 300, 7, 5)):
+        odb, t, p, g = make_case(oracle, n_t, n_g, enzyme=3, seed=seed)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            for bounding in (0, 1):
+                ctx.set_bounding(bounding)
+                got, want = ctx.discover(g, mm, 2000), odb.discover(g, mm, 2000)
+                assert_same_hits(got, want)
+    odb, t, p, g = dense_case(oracle, n_random=90_000, n_guides=500, n_dense=40, variants=150, seed=41)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        got, want = ctx.discover(g, 4, 300), odb.discover(g, 4, 300)
+        assert_same_hits(got, want)
+        assert_same_scores(oracle, 3, g, got, want)
