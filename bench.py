@@ -616,6 +616,10 @@ def main():
             # executed full-length comparisons (the pigeonhole candidate generation visits ~1/4300 of the nominal G x T pairs): the figure
             # comparable with the reference's BitEncoding.allComparisons counter
             "executed_pair_tests_per_step": pairs, "executed_pair_tests_per_s": pairs * args.steps / dt,
+            # what `value` times, said plainly: the aggregates-only discover (scan + ordered cut-off + CFD / Hsu2013 / closest-hit
+            # aggregates of every guide on the host) with the guide set already in HBM; the hit lists themselves are NOT delivered in
+            # the timed step -- that call is timed beside it as discover_product_ms (default table / with --positionOutput)
+            "step_delivers": "per-guide aggregates only (guides resident in HBM); hit lists: see discover_product_ms",
             # the same step with the guide set handed over as a (pageable) host buffer: PCIe-inclusive, never `value`
             "ms_per_step_host_guides": host_ms,
             "verified": verified, "verification": verify_note,
