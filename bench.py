@@ -468,12 +468,36 @@ def main():
     # devices).
     exchange_kind = os.environ.get("FFH_BENCH_EXCHANGE", "torch" if os.environ.get("FFH_BENCH_SAME_GPU") == "1" else "native") if sharded else None
     exch, comm, reduced = None, None, None
+    exchange_note = None
+
+    def all_ranks_ok(ok):   # every rank must take the same path: one that failed takes the others with it
+        if world <= 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     if sharded and exchange_kind == "native":
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = capi.Comm.rank(ctx, rank, world if world > 1 else 1, uid[0])
-        reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
-    elif sharded:
+        # the library's own communicator; should it not come up on this node (it has never run on more than one GPU), or fail in its
+        # first step, all ranks fall back to the torch.distributed form of the same exchange -- and the line says so
+        err = None
+        try:
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = capi.Comm.rank(ctx, rank, world if world > 1 else 1, uid[0])
+            reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
+            comm.discover_device(guides_dev.data_ptr(), int(guides_dev.shape[0]), args.max_mismatch, args.max_offtargets, want_summaries=(rank == 0), out=reduced)
+        except Exception as e:   # noqa: BLE001 -- whatever it is, the run goes on with the other exchange
+            err = repr(e)
+        if not all_ranks_ok(err is None):
+            exchange_note = "ffh_comm failed on a rank (%s); torch.distributed exchange used instead" % (err or "another rank")
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:   # noqa: BLE001
+                    pass
+            comm, exchange_kind = None, "torch"
+    if sharded and comm is None:
         exch = ffdist.DeviceExchange(G, dev)
 
     class _Reduced:  # the sharded step's result: the reduced per-guide aggregates, on rank 0
@@ -612,7 +636,8 @@ def main():
                        "guides": G, "targets_per_gpu": T, "targets_total": T_total, "positions_per_gpu": P,
                        "max_mismatch": args.max_mismatch, "max_offtargets": args.max_offtargets, "parallelism": "bin-shard x%d" % world,
                        "exchange": ({"native": "ffh_discover_sharded: RCCL collectives issued by libflashfry_hip (%s)" % (comm.transport if comm else "?"),
-                                     "torch": "library kernels + torch.distributed collectives"}[exchange_kind] if sharded else None)},
+                                     "torch": "library kernels + torch.distributed collectives"}[exchange_kind] if sharded else None),
+                       "exchange_note": exchange_note},
             # executed full-length comparisons (the pigeonhole candidate generation visits ~1/4300 of the nominal G x T pairs): the figure
             # comparable with the reference's BitEncoding.allComparisons counter
             "executed_pair_tests_per_step": pairs, "executed_pair_tests_per_s": pairs * args.steps / dt,
