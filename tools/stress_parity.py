@@ -76,6 +76,10 @@ while time.time() - t0 < budget:
             a, b = set(int(x) for x in gpu.hits(k)), set(int(x) for x in ora.hits(k))
             print("  guide %d: gpu %d hits, oracle %d, missing %s extra %s (database indices), overflow gpu %d oracle %d, gpu ot_count %d" % (
                 k, len(a), len(b), sorted(idx[v] for v in b - a)[:8], sorted(idx[v] for v in a - b)[:8], int(gpu.summaries["overflow"][k]), int(ora.full[k]), int(gpu.summaries["ot_count"][k])), flush=True)
+        ora_again = odb.discover(g, max_mm, max_ot)
+        print("  the oracle asked again: %s; the guide array holds %d distinct guides of %d" % (
+            "same answer" if np.array_equal(ora_again.guide_offsets, ora.guide_offsets) and np.array_equal(ora_again.hit_targets, ora.hit_targets) else "ANOTHER answer",
+            len(np.unique(g)), len(g)), flush=True)
         for tag, bnd in (("again, same context settings", bounding), ("unbounded", 0)):
             with capi.Context(enz) as ctx2:
                 ctx2.load_soa(t, p)
