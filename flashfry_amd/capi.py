@@ -21,7 +21,7 @@ FINALIZE_NO_HIT_SCORES = 16
 
 # every symbol include/flashfry_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "ffh_version", "ffh_device_count", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
+    "ffh_version", "ffh_device_count", "ffh_debug_pool_errors", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
     "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
     "ffh_scan_bounded", "ffh_set_bounding", "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
@@ -116,6 +116,8 @@ def load_library(build=True):
     L = C.CDLL(path)
     L.ffh_version.restype = C.c_int
     L.ffh_device_count.restype = C.c_int
+    if hasattr(L, "ffh_debug_pool_errors"):   # (absent from A/B builds of earlier revisions: FFH_LIBRARY)
+        L.ffh_debug_pool_errors.restype = C.c_uint64
     L.ffh_create.restype = C.c_void_p
     L.ffh_create.argtypes = [C.c_int, C.c_int]
     L.ffh_destroy.argtypes = [C.c_void_p]

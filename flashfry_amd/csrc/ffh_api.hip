@@ -94,7 +94,22 @@ struct Evt {
 
 // page-locked host blocks for results, recycled across calls (hipHostMalloc of several MB costs ~1 ms; pageable
 // destinations make every device-to-host copy go through a bounce buffer)
+// FFH_POOL_DEBUG=1 (tools/stress_parity.py): every block the pool hands out carries a canary over its slack [used, cap), checked when the
+// block comes back (a write past a result's end); a block that comes back is filled with a poison pattern, checked when it is
+// handed out again and when the pool dies (a device or host write into a block nobody owns: a late DMA, a stale pointer).
+// ffh_debug_pool_errors() counts what the checks found.
+static std::atomic<unsigned long long> g_pool_errors{0};
+static bool pool_debug() {
+    static const bool on = std::getenv("FFH_POOL_DEBUG") && std::atoi(std::getenv("FFH_POOL_DEBUG")) == 1;
+    return on;
+}
+static bool all_bytes(const void *p, size_t n, unsigned char v) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) if (b[i] != v) return false;
+    return true;
+}
 struct PinnedPool {
+    static constexpr unsigned char kCanary = 0xA5, kPoison = 0xDB;
     std::mutex m;
     std::vector<std::pair<void *, size_t>> free_blocks;
     void *get(size_t bytes, size_t &cap) {
@@ -104,27 +119,47 @@ struct PinnedPool {
             const long long mb = std::atoll(lim);
             if (mb > 0 && bytes > (size_t)mb << 20) return nullptr;
         }
+        void *p = nullptr;
         {
             std::lock_guard<std::mutex> g(m);
             for (size_t i = 0; i < free_blocks.size(); ++i)
                 if (free_blocks[i].second >= bytes && free_blocks[i].second <= 4 * bytes + (1u << 20)) {
-                    void *p = free_blocks[i].first;
+                    p = free_blocks[i].first;
                     cap = free_blocks[i].second;
                     free_blocks.erase(free_blocks.begin() + (long)i);
-                    return p;
+                    break;
                 }
         }
-        void *p = nullptr;
-        cap = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (p && pool_debug() && !all_bytes(p, cap, kPoison)) {
+            g_pool_errors.fetch_add(1);
+            fprintf(stderr, "[ffh pool debug] a released page-locked block (%zu bytes) was written to before it was handed out again\n", cap);
+        }
+        if (!p) {
+            cap = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        if (pool_debug()) std::memset((char *)p + bytes, kCanary, cap - bytes);
         return p;
     }
-    void put(void *p, size_t cap) {
+    void put(void *p, size_t cap, size_t used) {
+        if (pool_debug()) {
+            if (used <= cap && !all_bytes((const char *)p + used, cap - used, kCanary)) {
+                g_pool_errors.fetch_add(1);
+                fprintf(stderr, "[ffh pool debug] the slack behind a result block (%zu of %zu bytes used) was written to\n", used, cap);
+            }
+            std::memset(p, kPoison, cap);
+        }
         std::lock_guard<std::mutex> g(m);
-        if (free_blocks.size() >= 6) { (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
+        if (free_blocks.size() >= 6) { check_poison(free_blocks.front()); (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
         free_blocks.emplace_back(p, cap);
     }
-    ~PinnedPool() { for (auto &b : free_blocks) (void)hipHostFree(b.first); }
+    static void check_poison(const std::pair<void *, size_t> &b) {
+        if (pool_debug() && !all_bytes(b.first, b.second, kPoison)) {
+            g_pool_errors.fetch_add(1);
+            fprintf(stderr, "[ffh pool debug] a released page-locked block (%zu bytes) was written to before it was freed\n", b.second);
+        }
+    }
+    ~PinnedPool() { for (auto &b : free_blocks) { check_poison(b); (void)hipHostFree(b.first); } }
 };
 
 struct ffh_result {
@@ -138,7 +173,7 @@ struct ffh_result {
     // (whose number is known only after the per-hit arrays are on their way to the host)
     std::shared_ptr<PinnedPool> pool;
     void *block = nullptr, *block2 = nullptr;
-    size_t block_cap = 0, block2_cap = 0;
+    size_t block_cap = 0, block2_cap = 0, block_used = 0, block2_used = 0;
     ffh_guide_summary *summaries = nullptr;
     uint64_t *guide_offsets = nullptr, *hit_targets = nullptr, *pos_offsets = nullptr, *positions = nullptr;
     double *hit_cfd = nullptr;
@@ -155,7 +190,8 @@ struct ffh_result {
             o_cfd = o_ht + up((size_t)H * 8); o_poff = o_cfd + (with_cfd ? up((size_t)H * 8) : 0);
             o_mm = o_poff + (with_pos_offsets ? up(((size_t)H + 1) * 8) : 0); total = o_mm + up((size_t)H);
         }
-        block = pool->get(total + 64, block_cap);
+        block_used = total + 64;
+        block = pool->get(block_used, block_cap);
         if (!block) return false;
         char *b = (char *)block;
         summaries = (ffh_guide_summary *)(b + o_sum); guide_offsets = (uint64_t *)(b + o_goff);
@@ -168,13 +204,14 @@ struct ffh_result {
     }
     bool allocate_positions(uint64_t P) {
         n_positions = P;
-        block2 = pool->get((size_t)P * 8 + 64, block2_cap);
+        block2_used = (size_t)P * 8 + 64;
+        block2 = pool->get(block2_used, block2_cap);
         positions = (uint64_t *)block2;
         return block2 != nullptr;
     }
     ~ffh_result() {
-        if (block && pool) pool->put(block, block_cap);
-        if (block2 && pool) pool->put(block2, block2_cap);
+        if (block && pool) pool->put(block, block_cap, block_used);
+        if (block2 && pool) pool->put(block2, block2_cap, block2_used);
     }
 };
 
@@ -236,7 +273,7 @@ struct ffh_ctx {
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
-    DevBuf<uint4> wl_list[2];                               // the compare kernel's work list, per image
+    DevBuf<WorkEntry> wl_list[2];                             // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint32_t> sort_table, sort_offs, heavy_list;
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
@@ -605,6 +642,7 @@ static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, n
 extern "C" {
 
 int ffh_version(void) { return FFH_VERSION; }
+unsigned long long ffh_debug_pool_errors(void) { return g_pool_errors.load(); }
 
 int ffh_device_count(void) {
     int n = 0;
@@ -1194,22 +1232,16 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
             ca.gmap[0] = shared_prefix ? nullptr : (act_map ? act_map + g0 : nullptr);
             ca.gmap[1] = act_map ? act_map + g0 : nullptr;
-            launch_compare(ca, ctx->d_counters, ctx->compare_grid, st,
-                           work_list_is_long(expect[0], ctx->compare_grid) && (plan.r2 < 0 || work_list_is_long(expect[1], ctx->compare_grid)));
+            if (!launch_compare(ca, ctx->d_counters, ctx->compare_grid, st,
+                                work_list_is_long(expect[0], ctx->compare_grid) && (plan.r2 < 0 || work_list_is_long(expect[1], ctx->compare_grid)))) {
+                ctx->err = "no compare kernel for rest keys of " + std::to_string(ca.side[0].rest) + " + " + std::to_string(ca.side[1].rest) + " bases";
+                return FFH_E_STATE;
+            }
             FFH_HIP(hipGetLastError());
             FFH_HIP(hipEventRecord(ctx->ev[4], st));
             unsigned long long cnt[16];  // one read-back: hit cursor, hit count, executed pairs and work entries of the two images
             FFH_HIP(spin_wait(ctx, cnt));
             FFH_HIP(hipGetLastError());
-#ifdef FFH_WAVE_STATS
-            {
-                unsigned long long ws[8];
-                FFH_HIP(hipMemcpy(ws, ctx->d_counters + 20, sizeof ws, hipMemcpyDeviceToHost));
-                const double nw = (double)std::max<unsigned long long>(ws[5], 1);
-                fprintf(stderr, "[wave stats] slab %zu: %llu waves, cycles per wave mean %.0f max %llu (suffix side: mean %.0f max %llu), rows per wave mean %.0f max %llu, unfit pieces %llu\n",
-                        sl, ws[5], (double)ws[0] / nw, ws[1], (double)ws[2] / nw, ws[3], (double)ws[6] / nw, ws[7], ws[4]);
-            }
-#endif
             first_launch = false;
             const unsigned long long cursor = cnt[0];
             // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a

@@ -35,28 +35,16 @@
 
 namespace ffh {
 
-// (the FFH_* macros exist for same-box A/B builds with tools/build_variant.sh; the defaults are the product)
-#ifndef FFH_KW
-#define FFH_KW 1024
-#endif
-#ifndef FFH_KC
-#define FFH_KC 256
-#endif
-#ifndef FFH_STAGE
-#define FFH_STAGE 256
-#endif
-#ifndef FFH_WAVES_PER_SIMD
-#define FFH_WAVES_PER_SIMD 4
-#endif
-#ifndef FFH_QUEUE_CHUNK
-#define FFH_QUEUE_CHUNK 16    // work entries a wave draws from its queue at a time (0: fixed stride, no queue); 8: 1.07, 16 / 32: 1.06 ms per launch
-#endif
-#ifndef FFH_GPL
-#define FFH_GPL 6
-#endif
-#ifndef FFH_PIPE_TRIPS
-#define FFH_PIPE_TRIPS 2   // 16-byte pieces of a group's words requested one group ahead (0: none; more cost registers)
-#endif
+// The kernel's geometry.  (Same-box A/B builds of other values: tools/build_variant.sh rewrites its private copy of this block with
+// `KW=768 STAGE=192 ...` arguments; the product has no build-time switches.)
+constexpr int FFH_KW = 1024;            // group words parked per wave
+constexpr int FFH_KC = 256;             // candidates parked per wave
+constexpr int FFH_STAGE = 256;          // staged hits per wave
+constexpr int FFH_WAVES_PER_SIMD = 4;   // launch bound (four blocks of four waves per CU: LDS-limited)
+constexpr int FFH_QUEUE_CHUNK = 16;     // work entries a wave draws from its queue at a time (8: 1.07, 16 / 32: 1.06 ms per launch)
+constexpr int FFH_GPL = 6;              // groups per job of a large bucket, about
+constexpr int FFH_PIPE_TRIPS = 2;       // 16-byte pieces of a group's words requested one group ahead (more cost registers)
+constexpr int FFH_MAX_ENTRY_WORK = 2048;   // group tests per work entry of a heavy bucket, at most
 constexpr int kCmpThreads = 256;           // four waves, each with its own LDS strip: no block-level synchronisation in the kernel
 constexpr int kCmpWaves = kCmpThreads / 64;
 constexpr int kKW = FFH_KW;                // group words parked per wave (4 KB: 51 groups of 20 words, 42 of 24)
@@ -74,6 +62,7 @@ constexpr uint32_t kQueueChunk = FFH_QUEUE_CHUNK;   // cursor[4 + side]: execute
 
 __host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 + 3) & ~3; }   // words per group of 32 targets (16-byte multiple)
 
+struct WorkEntry;
 struct SideArgs {
     const uint32_t *gstart;   // [nb + 1] first group of every bucket
     const uint32_t *gwords;   // [groups * GW + kKW + 64] bit-sliced groups (padded: a batch is fetched in whole 16-byte pieces)
@@ -87,9 +76,9 @@ struct SideArgs {
     uint32_t rest;            // R: bases in the rest key
     uint32_t NB;              // buckets per batch
     uint32_t split;           // groups per work entry at most (= what the LDS strip holds)
-    const uint4 *list;        // work entries {first bucket, buckets, first group, end group}: a batch that has candidates, or -- for a
-                              // bucket larger than the strip (a repeat family) -- one strip-sized range of its groups, so that such a
-                              // bucket is spread over many waves instead of pinning one
+    const WorkEntry *list;         // work entries: a batch that has candidates, or -- for a bucket larger than the strip (a repeat
+                              // family) -- one strip-sized range of its groups, so that such a bucket is spread over many waves instead
+                              // of pinning one
     const uint32_t *n_list;   // their number (device memory: built on the stream, no host round trip)
     uint32_t list_cap;        // entries the list holds (a guide set that needs more is noticed by the host after the launch, which
                               // then runs again with a larger list: scan_impl)
@@ -115,9 +104,6 @@ __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int fir
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
     if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
     if (threadIdx.x >= kQueue && threadIdx.x < kQueue + 2 * kQueues) cursor[threadIdx.x] = 0ull;  // the two images' work queues (k_compare)
-#ifdef FFH_WAVE_STATS   // (dev builds: tools/build_variant.sh WORK stats -DFFH_WAVE_STATS)
-    if (threadIdx.x >= 20 && threadIdx.x < 32) cursor[threadIdx.x] = 0ull;
-#endif
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -169,10 +155,24 @@ __device__ __forceinline__ void count_planes(const uint32_t (&m)[N], uint32_t &c
     c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
 }
 
+// job -> bucket lookup of a parked piece: kMaxRows words of 64 marker bits, one bit per non-empty bucket at the job before its first
+constexpr int kMaxRows = 16;               // rows (of 64 jobs) of one parked piece at most: park() caps the jobs of a piece at 1024
+
+// what a wave keeps in LDS: one struct per wave, so that everything is an immediate offset from ONE base address (six separately
+// declared arrays cost six scalar registers of bases, in a kernel that was spilling them)
+struct alignas(16) WaveLds {
+    uint32_t strip[kKW + 64];              // the batch's group words
+    uint2 cand[kKC];                       // {rest key, bucket id} of the batch's candidates
+    uint32_t gid[kKC];                     // their guide numbers
+    uint4 tab[2][16];                      // per non-empty bucket of the piece: {first job, first candidate, bucket id, P | 65536 / P} / {strip word, groups, groups per job, first slot}
+    uint64_t stage[kStage];                // staged hits
+    uint64_t mark[kMaxRows];               // bucket markers
+};
+
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 constexpr uint32_t kChunkMax = 8192;   // hit-buffer slots a wave reserves at a time, at most
 struct HitStage {
-    lds_u64 *my;             // this wave's staged hits: guide of this batch << 32 | side << 31 | slot in the side's image
+    WaveLds *W;              // W->stage: this wave's staged hits, guide of this batch << 32 | side << 31 | slot in the side's image
     uint32_t fill;
     uint32_t lane;
     const CompareArgs *A;    // the kernel's argument block (scalar loads from the kernarg segment at flush time)
@@ -183,10 +183,11 @@ struct HitStage {
     // with many asks rarely; what is left of the last chunk is filled with all-ones keys, which sort behind every hit.
     unsigned long long chunk_pos;
     uint32_t chunk_left;
-    unsigned long long n_real;
+    uint32_t n_real;         // (a scan of 2^32 raw hits or more is refused by the host)
 
     __device__ __forceinline__ void flush() {
         wave_lds_fence();
+        lds_u64 *my = (lds_u64 *)W->stage;
         uint64_t *__restrict__ hits = A->hits;
         const uint64_t cap = A->cap;
         const uint32_t *__restrict__ tidx_p = A->side[0].tidx, *__restrict__ tidx_s = A->side[1].tidx;
@@ -242,11 +243,11 @@ struct HitStage {
         const uint64_t cap = A->cap;
         for (uint32_t i = lane; i < chunk_left; i += 64)
             if (chunk_pos + i < cap) hits[chunk_pos + i] = ~0ull;
-        if (lane == 0 && n_real) atomicAdd(cursor + 1, n_real);
+        if (lane == 0 && n_real) atomicAdd(cursor + 1, (unsigned long long)n_real);
     }
     // wave-uniform call: `lanes` = ballot of `hit`
     __device__ __forceinline__ void push(uint64_t lanes, bool hit, uint32_t gid, uint32_t slot) {
-        if (hit) my[fill + mbcnt(lanes)] = ((uint64_t)gid << 32) | slot;
+        if (hit) ((lds_u64 *)W->stage)[fill + mbcnt(lanes)] = ((uint64_t)gid << 32) | slot;
         fill += (uint32_t)__popcll(lanes);
         if (fill > kStage - 64) flush();  // always leave room for one more wave-wide batch
     }
@@ -256,7 +257,7 @@ struct HitStage {
 struct RowCtx {
     HitStage *hs;
     int max_mm, r_far;
-    uint32_t side_bit, width;
+    uint32_t width;
 };
 
 // One row: 64 jobs, one per lane -- one candidate guide against `trips` consecutive groups of its bucket.
@@ -266,7 +267,7 @@ struct RowCtx {
 //   FAR: what is known at compile time about the suffix image's extra condition "more than r1 mismatches in the rest key":
 //   0 none (prefix image), 1 .. 4 count >= FAR as one or two v_bitop3 on the count's bit planes, -1 taken from c.r_far at run time
 //   EARLY: 16-byte pieces of a group's words requested one group ahead (registers: the any-width instance cannot afford them)
-template <int R, int FAR, int EARLY>
+template <int R, int FAR, int EARLY, int SIDE>
 __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t sbase,
                                          const uint32_t *strip) {
     constexpr int GW = group_words(R);
@@ -298,7 +299,12 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
     const uint32_t t0 = 0u - (tcl & 1u), t1 = 0u - ((tcl >> 1) & 1u), t2 = 0u - ((tcl >> 2) & 1u), t3 = 0u - ((tcl >> 3) & 1u);
     const uint32_t far = (uint32_t)(c.r_far + 1);      // suffix image: at least this many rest mismatches (0: no condition)
     const uint32_t f0 = 0u - (far & 1u), f1 = 0u - ((far >> 1) & 1u), f2 = 0u - ((far >> 2) & 1u), f3 = 0u - ((far >> 3) & 1u);
-    for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < trips); ++t) {
+    // The loop is wave-uniform (the hit stage is the wave's): `live` = the lanes whose job still has a group at step t.  It is both the
+    // loop condition and -- as the mask operand of one v_cndmask -- what silences a lane that is done (its reads run into a neighbour's
+    // groups): one compare per step for both.  (Written as `for (; ballot(t < trips);) ... if (t >= trips) hit = 0` the compiler
+    // materialised the condition in a register and compared twice: five vector instructions per step instead of two.)
+    uint64_t live = __builtin_amdgcn_ballot_w64(trips != 0u);
+    for (uint32_t t = 0; live; ++t) {
         fetch(IE{}, IN{});
         uint32_t m[R];
 #pragma unroll
@@ -330,10 +336,11 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
                 hit &= g;
             }
         }
-        if (t >= trips) hit = 0;                        // a lane that is done (its reads ran into a neighbour's groups)
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hit) : "v"(hit), "s"(live));   // a lane that is done
+        live = __builtin_amdgcn_ballot_w64(t + 1u < trips);
         const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit != 0u);
-        if (lanes) {   // rare: the lanes with a non-zero mask stage one record per set bit (almost always one)
-            const uint32_t slot0 = (sbase + (t << 5)) | c.side_bit;
+        if (lanes) {   // rare per lane, usual per wave: the lanes with a non-zero mask stage one record per set bit (almost always one)
+            const uint32_t slot0 = (sbase + (t << 5)) | ((uint32_t)SIDE << 31);
             uint64_t more = lanes;
             do {
                 c.hs->push(more, hit != 0u, gid, slot0 + (uint32_t)__ffs((int)hit) - 1u);
@@ -372,9 +379,6 @@ __device__ __forceinline__ void slab_run(uint32_t b0, uint32_t b1, uint32_t lo, 
 // and its rows are then full of hits, each costing more than the test that found it: one entry of 42 groups x 256 candidates kept a
 // wave busy for a millisecond while the launch waited for it.  Such a batch takes smaller candidate chunks, so that an entry stays
 // within kMaxEntryWork group tests.
-#ifndef FFH_MAX_ENTRY_WORK
-#define FFH_MAX_ENTRY_WORK 2048
-#endif
 constexpr uint32_t kMaxEntryWork = FFH_MAX_ENTRY_WORK, kMaxCandShift = 4;
 struct WorkSplit { uint32_t n_g, n_c, cs; };
 __device__ __forceinline__ WorkSplit work_split(uint32_t ngr, uint32_t nc, uint32_t split, bool one_bucket) {
@@ -410,13 +414,18 @@ __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(pairs_out, red[0] + red[1] + red[2] + red[3]);
 }
-// entry = {first bucket, buckets | cs << 4 | candidate chunk << 7, first group, end group}: candidates [chunk * (kKC >> cs), + kKC >> cs)
-// of the batch's list.  A thread per batch; a batch with many entries (a repeat family's bucket: hundreds) is written by its whole wave.
+// A work entry, 32 bytes: what a wave needs to fetch the batch -- first bucket, buckets, groups [g0, g1), candidates [c0, c1) (absolute
+// indices into gwords / gids) -- worked out HERE, once, from the bucket boundaries.  (Round 3's 16-byte entries held {first bucket,
+// buckets | chunk, first group, end group} and every wave derived the extents from the boundaries with a dozen v_readlane + scalar
+// min / max per batch and pipeline stage; the boundaries had to be in flight three batches ahead for it.)
+struct WorkEntry { uint32_t b0, nbv, g0, g1, c0, c1, pad0, pad1; };
+static_assert(sizeof(WorkEntry) == 32, "two 16-byte stores");
+// A thread per batch; a batch with many entries (a repeat family's bucket: hundreds) is written by its whole wave.
 __global__ __launch_bounds__(256) void k_work_fill(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
-                                                   uint32_t n_bat, const uint32_t *__restrict__ offs, uint4 *__restrict__ list, uint32_t list_cap,
+                                                   uint32_t n_bat, const uint32_t *__restrict__ offs, WorkEntry *__restrict__ list, uint32_t list_cap,
                                                    unsigned long long *__restrict__ n_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    uint32_t o = 0, n = 0, s0 = 0, s1 = 0, gs = 0, ge = 0;
+    uint32_t o = 0, n = 0, s0 = 0, s1 = 0, gs = 0, ge = 0, is0 = 0, is1 = 0;
     WorkSplit w{1u, 1u, 0u};
     if (t < n_bat) {
         o = offs[t]; n = offs[t + 1] - o;
@@ -425,61 +434,53 @@ __global__ __launch_bounds__(256) void k_work_fill(const uint32_t *__restrict__ 
     if (n) {
         slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
         gs = gstart[s0]; ge = gstart[s1];
-        w = work_split(ge - gs, istart[s1] - istart[s0], split, s1 - s0 == 1u);
+        is0 = istart[s0]; is1 = istart[s1];
+        w = work_split(ge - gs, is1 - is0, split, s1 - s0 == 1u);
     }
-    auto entry = [&](uint32_t k, uint32_t o_, uint32_t s0_, uint32_t nbv_, uint32_t gs_, uint32_t ge_, uint32_t n_g_, uint32_t cs_) {
+    // entry k of the batch: piece kg of its groups x chunk kc of its candidates (kKC >> cs each)
+    auto entry = [&](uint32_t k, uint32_t o_, uint32_t s0_, uint32_t nbv_, uint32_t gs_, uint32_t ge_, uint32_t is0_, uint32_t is1_, uint32_t n_g_, uint32_t cs_) {
         const uint32_t kc = k / n_g_, kg = k - kc * n_g_;   // (the pieces of one candidate chunk are neighbours; the queue deals neighbours to different waves)
-        if (o_ + k < list_cap) list[o_ + k] = make_uint4(s0_, nbv_ | (cs_ << 4) | (kc << 7), gs_ + kg * split, min(ge_, gs_ + (kg + 1u) * split));
+        if (o_ + k >= list_cap) return;
+        const uint32_t cs_n = (uint32_t)kKC >> cs_;
+        uint32_t g0 = gs_ + kg * split, g1 = min(ge_, gs_ + (kg + 1u) * split), c0 = is0_ + kc * cs_n, c1 = min(is1_, c0 + cs_n);
+        if (g1 <= g0) { g1 = g0; c1 = c0; }   // nothing to compare the candidates with
+        uint4 *dst = reinterpret_cast<uint4 *>(list + (o_ + k));
+        dst[0] = make_uint4(s0_, nbv_, g0, g1);
+        dst[1] = make_uint4(c0, c1, 0u, 0u);
     };
     constexpr uint32_t kSerial = 4;
     if (n && n <= kSerial)
-        for (uint32_t k = 0; k < n; ++k) entry(k, o, s0, s1 - s0, gs, ge, w.n_g, w.cs);
+        for (uint32_t k = 0; k < n; ++k) entry(k, o, s0, s1 - s0, gs, ge, is0, is1, w.n_g, w.cs);
     for (uint64_t big = __ballot(n > kSerial); big; big &= big - 1ull) {
         const int src = __ffsll((long long)big) - 1;
         const uint32_t n_b = __shfl(n, src, 64), o_b = __shfl(o, src, 64), s0_b = __shfl(s0, src, 64), nbv_b = __shfl(s1 - s0, src, 64);
         const uint32_t gs_b = __shfl(gs, src, 64), ge_b = __shfl(ge, src, 64), ng_b = __shfl(w.n_g, src, 64), cs_b = __shfl(w.cs, src, 64);
-        for (uint32_t k = lane; k < n_b; k += 64) entry(k, o_b, s0_b, nbv_b, gs_b, ge_b, ng_b, cs_b);
+        const uint32_t is0_b = __shfl(is0, src, 64), is1_b = __shfl(is1, src, 64);
+        for (uint32_t k = lane; k < n_b; k += 64) entry(k, o_b, s0_b, nbv_b, gs_b, ge_b, is0_b, is1_b, ng_b, cs_b);
     }
 }
 
-// job -> bucket lookup of a parked piece: kMaxRows words of 64 marker bits, one bit per non-empty bucket at the job before its first
-constexpr int kMaxRows = 16;               // rows (of 64 jobs) of one parked piece at most: park() caps the jobs of a piece at 1024
-
-// R0 / R1: the rest widths of the prefix / suffix image this instance is compiled for (the row form is then fixed and the kernel's
-// registers are those of max(R0, R1) instead of the widest form); 0 = any width, chosen per row.  FAR1: r1 + 1 of the suffix image
-// when the instance is compiled for it (scan_row), -1 = read from the arguments.  The host picks the instance (launch_compare).
+// R0 / R1: the rest widths of the prefix / suffix image this instance is compiled for (the row forms are fixed and the kernel's
+// registers are those of max(R0, R1)).  FAR1: r1 + 1 of the suffix image when the instance is compiled for it (scan_row), -1 = read
+// from the arguments.  The host picks the instance (launch_compare).
 // QUEUE: the work entries are dealt through queues (long lists); else a fixed stride (the host decides: launch_compare)
 template <int R0, int R1, int FAR1, bool QUEUE>
 __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(const CompareArgs A, unsigned long long *__restrict__ cursor) {
-    __shared__ __attribute__((aligned(16))) uint32_t strip_lds[kCmpWaves][kKW + 64];
-    __shared__ __attribute__((aligned(16))) uint2 cand_lds[kCmpWaves][kKC];
-    __shared__ uint32_t gid_lds[kCmpWaves][kKC];
-    __shared__ __attribute__((aligned(16))) uint4 tab_lds[kCmpWaves][2][16];
-    __shared__ uint64_t stage[kCmpWaves][kStage];
-    __shared__ uint64_t mark_lds[kCmpWaves][kMaxRows];
+    __shared__ WaveLds lds_all[kCmpWaves];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * kCmpWaves;
-    const uint32_t *__restrict__ gids = A.gids;
-    HitStage hs{(lds_u64 *)stage[wave], 0u, lane, &A, cursor, 0ull, 0u, 0ull};
-    RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u, 0u};
-#ifdef FFH_WAVE_STATS   // how evenly the launch's time is spread over its waves: cycles per wave (sum, max), per side; pieces that did not fit
-    const unsigned long long ws_begin = clock64();
-    unsigned long long ws_side1 = 0;
-    uint32_t ws_unfit = 0, ws_rows = 0;
-#endif
+    WaveLds &W = lds_all[wave];
+    HitStage hs{&W, 0u, lane, &A, cursor, 0ull, 0u, 0u};
+    RowCtx rc{&hs, min(max(A.max_mm, 0), 30), -1, 0u};
 
-    // what a batch covers: nbv buckets from b0 on, groups [g0, g1), candidates [c0, c1)
-    struct Extent { uint32_t nbv, b0, g0, g1, c0, c1; };
-
-    // The suffix image's work entries come first (they are the heavier ones), then the prefix image's; inside a side the wave takes the
-    // entries q, q + n_waves, ... and runs a software pipeline over them.  The side is invariant in the pipeline, so everything that
-    // describes it stays in scalar registers.
+    // The suffix image's work entries come first (they are the heavier ones), then the prefix image's; inside a side the wave runs a
+    // software pipeline over the entries it takes.  The side is invariant in the pipeline, so everything that describes it stays in
+    // scalar registers -- and only what describes THIS side: the other side's pointers are not read before its turn.
     auto run_side = [&](auto side_tag) {
         constexpr int side = decltype(side_tag)::value;
         constexpr int RC = side ? R1 : R0;             // compiled rest width of this side (0: any)
         constexpr int FARC = side ? FAR1 : 0;          // the prefix image has no far condition
-        const SideArgs S = A.side[side];
+        const SideArgs &S = A.side[side];
         if (!S.n_list) return;
         const uint32_t n_total = min(*S.n_list, S.list_cap);
         // The order in which a wave takes work entries.  Entries differ in weight (buckets differ in size, a repeat family's rows are
@@ -499,15 +500,15 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         // of hg38.  The host picks the instance from the list lengths it expects; decided in here, per side at run time, the
         // queue's gain at hg38 scale was gone -- 1.13 against 1.05 ms per launch.)
         constexpr uint32_t chunk_len = kQueueChunk ? kQueueChunk : 1u;
+        const uint32_t n_waves = gridDim.x * kCmpWaves;
         const uint32_t n_chunks = (n_total + chunk_len - 1u) / chunk_len;
         uint32_t chunk = blockIdx.x * kCmpWaves + wave, chunk_j = 0, stride_q = chunk;
         const uint32_t n_queues = min(kQueues, gridDim.x), my_queue = blockIdx.x % n_queues;   // (every queue has a block that draws from it)
-        unsigned long long *queue = cursor + kQueue + side * kQueues + my_queue;
         auto next_q = [&]() -> uint32_t {   // uniform
             if constexpr (!QUEUE || kQueueChunk == 0) { const uint32_t r = stride_q < n_total ? stride_q : kEnd; stride_q += n_waves; return r; }
             if (chunk_j == chunk_len) {
                 uint32_t t = 0;
-                if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(queue, 1ull);
+                if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(cursor + kQueue + side * kQueues + my_queue, 1ull);
                 chunk = chunk < n_chunks ? n_waves + my_queue + n_queues * uni(t) : chunk;
                 chunk_j = 0;
             }
@@ -516,48 +517,33 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             ++chunk_j;
             return r < n_total ? r : kNone;
         };
-        uint32_t q = next_q();
-        if (q == kEnd) return;
-        uint32_t q1 = next_q(), q2 = next_q(), q3 = next_q(), q4 = next_q();
         const uint32_t *__restrict__ gstart = S.gstart, *__restrict__ istart = S.istart, *__restrict__ gwords = S.gwords;
         const uint32_t *__restrict__ list = reinterpret_cast<const uint32_t *>(S.list);
+        const uint32_t *__restrict__ gids = A.gids;
         const uint2 *__restrict__ gtab = S.gtab;
         const uint32_t dd_off = S.dd_off;
-        const uint32_t GW = RC ? (uint32_t)group_words(RC) : (uint32_t)group_words((int)S.rest);
+        constexpr uint32_t GW = (uint32_t)group_words(RC);
         rc.r_far = S.r_far;
-        rc.side_bit = (uint32_t)side << 31;
         rc.width = S.width;
 
-        // ---- the loads of the pipeline.  An entry past the end is an empty one (its loads are skipped). ----
-        // work entry qq: lanes 0..3 = {first bucket, buckets, first group, end group}
-        auto load_entry = [&](uint32_t qq, uint32_t &dE) {
-            dE = 0;
-            if (qq < n_total && lane < 4) dE = list[(size_t)qq * 4 + lane];
+        // ---- the pipeline.  A work entry lives in lanes 0..5 of ONE vector register ({first bucket, buckets, g0, g1, c0, c1}: scalar
+        //      registers are the scarce resource here) and is read out with v_readlane where a stage needs it.  An entry past the end
+        //      of the list, or of a chunk, is all zero: no groups, no candidates, its loads are skipped. ----
+        auto load_entry = [&](uint32_t qq) -> uint32_t {
+            uint32_t v = 0;
+            if (qq < n_total && lane < 6) v = list[(size_t)qq * 8 + lane];
+            return v;
         };
         // bucket boundaries of the entry: lane l <= nbv holds gstart / istart of bucket b0 + l; on a direct image lane 16 + l holds
         // ddelta of that bucket in dG (the second DPP row of the same register: no register of its own in the pipeline)
-        auto load_desc = [&](uint32_t qq, uint32_t dE, uint32_t &dG, uint32_t &dI) {
+        auto load_desc = [&](uint32_t E, uint32_t &dG, uint32_t &dI) {
             dG = 0; dI = 0;
-            if (qq < n_total) {
-                const uint32_t idx = lane_of(dE, 0) + min(lane & 15u, lane_of(dE, 1) & 15u);
+            const uint32_t nbv = lane_of(E, 1);
+            if (nbv) {
+                const uint32_t idx = lane_of(E, 0) + min(lane & 15u, nbv);
                 dG = gstart[idx + ((lane & 48u) == 16u ? dd_off : 0u)];
                 dI = istart[idx];
             }
-        };
-        auto extent_of = [&](uint32_t qq, uint32_t dE, uint32_t dG, uint32_t dI) -> Extent {
-            Extent e{0, 0, 0, 0, 0, 0};
-            if (qq < n_total) {
-                e.b0 = lane_of(dE, 0);
-                const uint32_t y = lane_of(dE, 1);
-                e.nbv = y & 15u;
-                e.g0 = max(lane_of(dG, 0), lane_of(dE, 2));
-                e.g1 = min(lane_of(dG, e.nbv), lane_of(dE, 3));
-                const uint32_t cs_n = (uint32_t)kKC >> ((y >> 4) & 7u);
-                e.c0 = lane_of(dI, 0) + (y >> 7) * cs_n;
-                e.c1 = min(lane_of(dI, e.nbv), e.c0 + cs_n);
-                if (e.g1 <= e.g0) { e.g1 = e.g0; e.c1 = e.c0; }   // nothing to compare the candidates with
-            }
-            return e;
         };
         // groups [g0, g1) of the image: g * GW words each, contiguous, fetched in 16-byte pieces (the array is padded by kKW + 64 words)
         auto load_groups = [&](uint32_t g0, uint32_t g1, uint4 (&kreg)[kKeyRegs]) {
@@ -585,27 +571,27 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
 
         // parks a piece of the batch -- groups [g0, g1), candidates [c0, c1) -- in the wave's LDS strip and deals its jobs; returns the
         // number of jobs.  Lane i < nbv: bucket i of the batch (dG / dI: its first group / first candidate, all buckets of the batch)
-        auto park = [&](const Extent &e, uint32_t g0, uint32_t g1, uint32_t c0, uint32_t c1, const uint4 (&kreg)[kKeyRegs], const uint32_t (&greg)[kGidRegs],
+        auto park = [&](uint32_t b0, uint32_t nbv, uint32_t g0, uint32_t g1, uint32_t c0, uint32_t c1, const uint4 (&kreg)[kKeyRegs], const uint32_t (&greg)[kGidRegs],
                         const uint2 (&ereg)[kGidRegs], uint32_t dG, uint32_t dI) -> uint32_t {
             wave_lds_fence();  // the previous piece's reads are done
             const uint32_t nw = (g1 - g0) * GW;
 #pragma unroll
             for (int j = 0; j < kKeyRegs; ++j)
-                if ((uint32_t)j * 256u < nw) reinterpret_cast<uint4 *>(strip_lds[wave])[j * 64 + lane] = kreg[j];
+                if ((uint32_t)j * 256u < nw) reinterpret_cast<uint4 *>(W.strip)[j * 64 + lane] = kreg[j];
 #pragma unroll
             for (int j = 0; j < kGidRegs; ++j) {
                 const uint32_t c = c0 + (uint32_t)j * 64u + lane;
                 if (c < c1) {
-                    cand_lds[wave][(uint32_t)j * 64u + lane] = ereg[j];
-                    gid_lds[wave][(uint32_t)j * 64u + lane] = greg[j];
+                    W.cand[(uint32_t)j * 64u + lane] = ereg[j];
+                    W.gid[(uint32_t)j * 64u + lane] = greg[j];
                 }
             }
-            if (lane < (uint32_t)kMaxRows) mark_lds[wave][lane] = 0ull;
+            if (lane < (uint32_t)kMaxRows) W.mark[lane] = 0ull;
             // bucket i: its groups and candidates clipped to the piece; P jobs per candidate
             const uint32_t nG = row_next(dG), nI = row_next(dI);
             const uint32_t lo_g = min(max(dG, g0), g1), hi_g = min(max(nG, g0), g1);
             const uint32_t lo_c = min(max(dI, c0), c1), hi_c = min(max(nI, c0), c1);
-            const bool act = lane < e.nbv;
+            const bool act = lane < nbv;
             const uint32_t ngr = act ? hi_g - lo_g : 0u, ng = (act && ngr) ? hi_c - lo_c : 0u;
             // Jobs per candidate: P parts of `per` groups each.  At most kMaxParts, and few enough that the piece stays within kMaxRows
             // rows of jobs.  (Divisions by a per-lane P <= 16 of numbers < 4096 go through v_rcp_f32: the quotients' fractional parts
@@ -614,7 +600,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             const uint32_t ncand = c1 - c0, pmax = ncand <= 64u ? 16u : ncand <= 128u ? 8u : 4u;
             auto ceil_div = [](uint32_t a, uint32_t b) { return (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b) + 0.99f); };   // a < 4096, 1 <= b <= 16
             uint32_t P, per;
-            if (e.nbv == 1u) {
+            if (nbv == 1u) {
                 // One bucket in the piece (the suffix image, a large prefix bucket): lanes 0..15 price P = lane + 1 -- rows of 64 jobs
                 // x groups per job -- and the cheapest wins.  (~ngr / 6 regardless of the candidates left every second piece of the
                 // suffix image with a second row of two jobs that ran as long as the full one.)
@@ -657,9 +643,9 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             wave_lds_fence();   // (the markers are cleared)
             if (ne) {
                 const uint32_t inv = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)P) + 0.999f);                 // ceil(65536 / P)
-                tab_lds[wave][0][slot] = make_uint4(js, lo_c - c0, e.b0 + lane, P | (inv << 8));   // x / P == (x * inv) >> 16 for x < 4096, P <= 16
-                tab_lds[wave][1][slot] = make_uint4((lo_g - g0) * GW, ngr, per, (lo_g << 5) + dd);
-                if (js) atomicOr((unsigned long long *)&mark_lds[wave][(js - 1u) >> 6], 1ull << ((js - 1u) & 63u));
+                W.tab[0][slot] = make_uint4(js, lo_c - c0, b0 + lane, P | (inv << 8));   // x / P == (x * inv) >> 16 for x < 4096, P <= 16
+                W.tab[1][slot] = make_uint4((lo_g - g0) * GW, ngr, per, (lo_g << 5) + dd);
+                if (js) atomicOr((unsigned long long *)&W.mark[(js - 1u) >> 6], 1ull << ((js - 1u) & 63u));
             }
             wave_lds_fence();
             return lane_of(incl, 15);
@@ -669,52 +655,37 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         auto rows = [&](uint32_t n_jobs) {
             uint32_t before = 0;   // buckets begun in the rows before this one
             for (uint32_t j0 = 0; j0 < n_jobs; j0 += 64) {
-#ifdef FFH_WAVE_STATS
-                ++ws_rows;
-#endif
                 const uint32_t J = j0 + lane;
-                const uint64_t M = mark_lds[wave][j0 >> 6];
+                const uint64_t M = W.mark[j0 >> 6];
                 const uint32_t mlo = (uint32_t)M, mhi = (uint32_t)(M >> 32);
                 const uint32_t i = before + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // the bucket of job J
                 before += (uint32_t)__popc(uni(mlo)) + (uint32_t)__popc(uni(mhi));
-                const uint4 ta = tab_lds[wave][0][i], tb = tab_lds[wave][1][i];
+                const uint4 ta = W.tab[0][i], tb = W.tab[1][i];
                 const uint32_t jj = J - ta.x, P = ta.w & 31u;
                 const uint32_t k = (jj * (ta.w >> 8)) >> 16, p = jj - k * P;                   // candidate k of the bucket, part p of it
                 const bool valid = J < n_jobs;
                 const uint32_t slot = min(ta.y + k, (uint32_t)kKC - 1u);
-                const uint2 cand = cand_lds[wave][slot];
-                const uint32_t gid = gid_lds[wave][slot];
+                const uint2 cand = W.cand[slot];
+                const uint32_t gid = W.gid[slot];
                 const uint32_t g_lo = p * tb.z;
                 uint32_t trips = 0;
                 if (valid && g_lo < tb.y) trips = min(tb.z, tb.y - g_lo);
                 const uint32_t x = cand.y ^ ta.z;
                 const uint32_t d = (uint32_t)__popc(((x >> rc.width) | x) & ((1u << rc.width) - 1u));   // mismatches inside the bucket key
                 const uint32_t gword = tb.x + g_lo * GW, sbase = tb.w + (g_lo << 5);
-                if constexpr (RC != 0) scan_row<RC, FARC, FFH_PIPE_TRIPS>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]);
-                else
-                    switch (S.rest) {   // uniform; kMinRest .. kMaxRest, checked by the host when the images are built
-                        case 7: scan_row<7, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        case 8: scan_row<8, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        case 9: scan_row<9, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        case 10: scan_row<10, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        case 11: scan_row<11, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        case 12: scan_row<12, FARC, 0>(rc, cand.x, d, gid, trips, gword, sbase, strip_lds[wave]); break;
-                        default: __builtin_trap();   // an image this kernel has no row form for: never a silently wrong hit set
-                    }
+                scan_row<RC, FARC, FFH_PIPE_TRIPS, side>(rc, cand.x, d, gid, trips, gword, sbase, W.strip);
             }
         };
 
-        // ---- prologue: work entries of four batches, boundaries of three, candidate ids of two, groups and guide entries of the first ----
-        uint32_t dE0, dE1, dE2, dE3, dG0, dI0, dG1, dI1, dG2, dI2;
-        load_entry(q, dE0);
-        load_entry(q1, dE1);
-        load_entry(q2, dE2);
-        load_entry(q3, dE3);
-        load_desc(q, dE0, dG0, dI0);
-        load_desc(q1, dE1, dG1, dI1);
-        load_desc(q2, dE2, dG2, dI2);
+        // ---- prologue: the work entries of four batches, candidate ids of two, groups / boundaries / guide entries of the first ----
+        uint32_t q = next_q();
+        if (q == kEnd) return;
+        uint32_t E0 = load_entry(q), E1, E2, E3, E4 = 0, ends = 0;   // ends bit k: the entry k batches ahead is past the wave's last
+        q = next_q(); E1 = load_entry(q); ends |= q == kEnd ? 2u : 0u;
+        q = next_q(); E2 = load_entry(q); ends |= q == kEnd ? 4u : 0u;
+        q = next_q(); E3 = load_entry(q); ends |= q == kEnd ? 8u : 0u;
         uint4 kreg[kKeyRegs];
-        uint32_t greg_a[kGidRegs], greg_b[kGidRegs];
+        uint32_t greg_a[kGidRegs], greg_b[kGidRegs], dG0, dI0;
         uint2 ereg[kGidRegs];
 #pragma unroll
         for (int j = 0; j < kKeyRegs; ++j) kreg[j] = make_uint4(0, 0, 0, 0);
@@ -722,92 +693,105 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         for (int j = 0; j < kGidRegs; ++j) { ereg[j] = make_uint2(0, 0); greg_a[j] = 0; greg_b[j] = 0; }
         const uint32_t cap_g = (uint32_t)kKW / GW;   // groups the strip holds
         {
-            const Extent e0 = extent_of(q, dE0, dG0, dI0), e1 = extent_of(q1, dE1, dG1, dI1);
-            load_gids(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a);
-            load_gids(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_b);
-            load_groups(e0.g0, min(e0.g1, e0.g0 + cap_g), kreg);
-            load_entries(e0.c0, min(e0.c1, e0.c0 + (uint32_t)kKC), greg_a, ereg);
+            const uint32_t c0 = lane_of(E0, 4), c1 = lane_of(E0, 5), d0 = lane_of(E1, 4), d1 = lane_of(E1, 5), g0 = lane_of(E0, 2), g1 = lane_of(E0, 3);
+            load_gids(c0, min(c1, c0 + (uint32_t)kKC), greg_a);
+            load_gids(d0, min(d1, d0 + (uint32_t)kKC), greg_b);
+            load_groups(g0, min(g1, g0 + cap_g), kreg);
+            load_desc(E0, dG0, dI0);
+            load_entries(c0, min(c1, c0 + (uint32_t)kKC), greg_a, ereg);
         }
-        while (q != kEnd) {
-            const Extent e = extent_of(q, dE0, dG0, dI0);
-            const bool fits = e.g1 - e.g0 <= cap_g && e.c1 - e.c0 <= (uint32_t)kKC, work = e.c1 > e.c0;
-            uint32_t n_jobs = 0;
-            // everything requested a batch ago has arrived (the compiler's waits cover it): park it
-            if (fits && work) n_jobs = park(e, e.g0, e.g1, e.c0, e.c1, kreg, greg_a, ereg, dG0, dI0);
-            if (!fits && work) {
-                // An entry that does not fit the strip (more candidates than it holds: a skewed guide set) is done in pieces of cap_g
-                // groups x kKC candidates fetched on the spot, through the same registers: correct for any input, the common case
-                // never does it.
-                for (uint32_t t0 = e.g0; t0 < e.g1; t0 += cap_g) {
-                    const uint32_t t1 = min(e.g1, t0 + cap_g);
-                    load_groups(t0, t1, kreg);
-                    for (uint32_t c0 = e.c0; c0 < e.c1; c0 += kKC) {
-                        const uint32_t c1 = min(e.c1, c0 + (uint32_t)kKC);
-                        load_gids(c0, c1, greg_a);
-                        load_entries(c0, c1, greg_a, ereg);
-                        const uint32_t nj = park(e, t0, t1, c0, c1, kreg, greg_a, ereg, dG0, dI0);
-#ifdef FFH_WAVE_STATS
-                        ++ws_unfit;
-#endif
-                        rows(nj);
-                    }
+        for (;;) {
+            // The batch is worked off in PIECES of at most cap_g groups x kKC candidates: one piece, unless the entry does not fit the
+            // strip (more candidates than it holds: a skewed guide set; correct for any input, the common case never takes a second
+            // piece).  The first piece is what was requested a batch ago; further ones are fetched on the spot through the same
+            // registers.  One copy of park() and rows() serves both (two inlined copies cost registers the kernel does not have).
+            uint32_t t0 = lane_of(E0, 2), k0 = lane_of(E0, 4);   // the piece: groups from t0, candidates from k0
+            for (bool first = true;; first = false) {
+                const uint32_t b0 = lane_of(E0, 0), nbv = lane_of(E0, 1), g1 = lane_of(E0, 3), c0 = lane_of(E0, 4), c1 = lane_of(E0, 5);
+                const uint32_t t1 = min(g1, t0 + cap_g), k1 = min(c1, k0 + (uint32_t)kKC);
+                if (!first) {
+                    if (k0 == c0) load_groups(t0, t1, kreg);
+                    load_gids(k0, k1, greg_a);
+                    load_entries(k0, k1, greg_a, ereg);
                 }
-            }
-            // ---- request what the next batches need: the work entry of batch +4, boundaries of +3, candidate ids of +2, guide entries
-            //      and groups of +1 ----
-            uint32_t dE4, dG3, dI3;
-            load_entry(q4, dE4);
-            load_desc(q3, dE3, dG3, dI3);
-            const Extent e1 = extent_of(q1, dE1, dG1, dI1), e2 = extent_of(q2, dE2, dG2, dI2);
+                // everything requested a batch ago has arrived (the compiler's waits cover it): park it
+                const uint32_t n_jobs = k1 > k0 ? park(b0, nbv, t0, t1, k0, k1, kreg, greg_a, ereg, dG0, dI0) : 0u;
+                uint32_t nk = k0 + (uint32_t)kKC, nt = t0;
+                if (nk >= c1) { nk = c0; nt = t0 + cap_g; }
+                const bool last = nt >= g1;
+                if (last) {
+                    // ---- request what the next batches need: the work entry of batch +4, candidate ids of +2, boundaries, guide entries
+                    //      and groups of +1 ----
+                    q = next_q();
+                    E4 = load_entry(q);
+                    ends |= q == kEnd ? 16u : 0u;
+                    const uint32_t d0 = lane_of(E2, 4), d1 = lane_of(E2, 5), n0 = lane_of(E1, 4), n1 = lane_of(E1, 5), h0 = lane_of(E1, 2), h1 = lane_of(E1, 3);
 #pragma unroll
-            for (int j = 0; j < kGidRegs; ++j) greg_a[j] = greg_b[j];
-            load_gids(e2.c0, min(e2.c1, e2.c0 + (uint32_t)kKC), greg_b);
-            load_entries(e1.c0, min(e1.c1, e1.c0 + (uint32_t)kKC), greg_a, ereg);
-            load_groups(e1.g0, min(e1.g1, e1.g0 + cap_g), kreg);
-            // ---- compute this batch out of LDS ----
-            if (n_jobs) rows(n_jobs);
-            dE0 = dE1; dE1 = dE2; dE2 = dE3; dE3 = dE4;
-            dG0 = dG1; dI0 = dI1; dG1 = dG2; dI1 = dI2; dG2 = dG3; dI2 = dI3;
-            q = q1; q1 = q2; q2 = q3; q3 = q4; q4 = next_q();
+                    for (int j = 0; j < kGidRegs; ++j) greg_a[j] = greg_b[j];
+                    load_gids(d0, min(d1, d0 + (uint32_t)kKC), greg_b);
+                    load_entries(n0, min(n1, n0 + (uint32_t)kKC), greg_a, ereg);
+                    load_groups(h0, min(h1, h0 + cap_g), kreg);
+                    load_desc(E1, dG0, dI0);
+                }
+                // ---- compute this piece out of LDS ----
+                if (n_jobs) rows(n_jobs);
+                if (last) break;
+                t0 = nt; k0 = nk;
+            }
+            if (ends & 2u) break;
+            E0 = E1; E1 = E2; E2 = E3; E3 = E4;
+            ends >>= 1;
         }
     };
     run_side(std::integral_constant<int, 1>{});
-#ifdef FFH_WAVE_STATS
-    ws_side1 = clock64() - ws_begin;
-#endif
     run_side(std::integral_constant<int, 0>{});
     hs.finish();
-#ifdef FFH_WAVE_STATS
-    if (lane == 0) {
-        const unsigned long long dt = clock64() - ws_begin;
-        atomicAdd(&cursor[20], dt); atomicMax(&cursor[21], dt);
-        atomicAdd(&cursor[22], ws_side1); atomicMax(&cursor[23], ws_side1);
-        atomicAdd(&cursor[24], (unsigned long long)ws_unfit); atomicAdd(&cursor[25], 1ull); atomicAdd(&cursor[26], (unsigned long long)ws_rows);
-        atomicMax(&cursor[27], (unsigned long long)ws_rows);
-    }
-#endif
 }
 
-// The instances: one per plan the cost model picks at genome scale for a 20-base pack (choose_plan / select_images: 11 + 9 with radii
-// 2 + 1 for <= 4 mismatches, 10 + 10 with 1 + 1 and 2 + 2 for <= 3 and <= 5), and the any-width one for everything else.
+// The instances.  Tuned ones -- far condition compiled in, queue and fixed-stride forms -- for the plans the cost model picks at genome
+// scale for a 20-base pack (choose_plan / select_images: 11 + 9 with radii 2 + 1 for <= 4 mismatches, 10 + 10 with 1 + 1 and 2 + 2 for
+// <= 3 and <= 5); for everything else one instance per PAIR of rest widths that can occur (prefix + suffix width = 20 or 19 compared
+// bases, both rest keys 7 .. 12 bases), far condition read at run time, fixed stride.  (Round 3 had ONE any-width instance that chose
+// the row form per row with a switch: its registers were the widest form's plus the switch's, 107 scalar and 8 vector registers
+// spilled -- every small database, every 19-mer and Cpf1 scan ran on it.)
 template <int R0, int R1, int FAR1>
 inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool queue) {
     if (queue) hipLaunchKernelGGL((k_compare<R0, R1, FAR1, true>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
     else hipLaunchKernelGGL((k_compare<R0, R1, FAR1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
-// long_lists: both images' work lists are expected to hold at least two queue chunks per wave (work_list_is_long)
-inline void launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool long_lists) {
-    static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;
-    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (A/B, tests; read per launch)
+template <int R0, int R1>
+inline void launch_compare_pair(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_compare<R0, R1, -1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+}
+// long_lists: both images' work lists are expected to hold at least two queue chunks per wave (work_list_is_long).
+// Returns false for a pair of rest widths no instance exists for (the host refuses such images when they are built).
+inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool long_lists) {
+    static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;   // tests: the per-pair instances for every plan
+    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (tests; read per launch)
     const bool queue = queue_env < 0 ? long_lists : queue_env != 0;
     const bool two = ca.side[1].n_list != nullptr;
-    const int r0 = (int)ca.side[0].rest, r1 = two ? (int)ca.side[1].rest : 0, far = two ? ca.side[1].r_far + 1 : 0;
+    const int r0 = (int)ca.side[0].rest, far = two ? ca.side[1].r_far + 1 : 0;
+    int r1 = two ? (int)ca.side[1].rest : 0;
     if (!generic_only && two) {
-        if (r0 == 9 && r1 == 11 && far == 3) return launch_compare_as<9, 11, 3>(ca, cursor, grid, st, queue);
-        if (r0 == 10 && r1 == 10 && far == 2) return launch_compare_as<10, 10, 2>(ca, cursor, grid, st, queue);
-        if (r0 == 10 && r1 == 10 && far == 3) return launch_compare_as<10, 10, 3>(ca, cursor, grid, st, queue);
+        if (r0 == 9 && r1 == 11 && far == 3) return launch_compare_as<9, 11, 3>(ca, cursor, grid, st, queue), true;
+        if (r0 == 10 && r1 == 10 && far == 2) return launch_compare_as<10, 10, 2>(ca, cursor, grid, st, queue), true;
+        if (r0 == 10 && r1 == 10 && far == 3) return launch_compare_as<10, 10, 3>(ca, cursor, grid, st, queue), true;
     }
-    hipLaunchKernelGGL((k_compare<0, 0, -1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+    if (!two) r1 = r0 <= 8 ? 12 : 20 - r0;   // a one-image plan never runs the suffix side: any instance with this prefix form
+    switch (r0 * 16 + r1) {
+        case 7 * 16 + 12: return launch_compare_pair<7, 12>(ca, cursor, grid, st), true;
+        case 8 * 16 + 12: return launch_compare_pair<8, 12>(ca, cursor, grid, st), true;
+        case 8 * 16 + 11: return launch_compare_pair<8, 11>(ca, cursor, grid, st), true;
+        case 9 * 16 + 11: return launch_compare_pair<9, 11>(ca, cursor, grid, st), true;
+        case 9 * 16 + 10: return launch_compare_pair<9, 10>(ca, cursor, grid, st), true;
+        case 10 * 16 + 10: return launch_compare_pair<10, 10>(ca, cursor, grid, st), true;
+        case 10 * 16 + 9: return launch_compare_pair<10, 9>(ca, cursor, grid, st), true;
+        case 11 * 16 + 9: return launch_compare_pair<11, 9>(ca, cursor, grid, st), true;
+        case 11 * 16 + 8: return launch_compare_pair<11, 8>(ca, cursor, grid, st), true;
+        case 12 * 16 + 8: return launch_compare_pair<12, 8>(ca, cursor, grid, st), true;
+        case 12 * 16 + 7: return launch_compare_pair<12, 7>(ca, cursor, grid, st), true;
+        default: return false;
+    }
 }
 inline bool work_list_is_long(double expected_entries, unsigned grid) { return kQueueChunk != 0 && expected_entries >= 2.0 * kQueueChunk * grid * kCmpWaves; }
 

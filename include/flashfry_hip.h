@@ -55,6 +55,9 @@ typedef struct ffh_result ffh_result;
 
 int ffh_version(void);
 int ffh_device_count(void);
+/* Diagnostics, no reference counterpart: with FFH_POOL_DEBUG=1 in the environment the page-locked result blocks carry canaries and
+ * released blocks a poison pattern; this is the number of violations seen so far in the process (0 when the checks are off). */
+unsigned long long ffh_debug_pool_errors(void);
 
 /* enzyme_index as stored in the database header: 1 Cpf1, 2 spCas9, 3 spCas9-NGG, 4 spCas9-NAG, 5 spCas9 19-mer,
  * 6 spCas9-NGG 19-mer (ParameterPack.indexToParameterPack, standards/StandardScanParameters.scala:61-69).

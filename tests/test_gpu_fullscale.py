@@ -76,6 +76,45 @@ def test_every_hit_of_sampled_guides_matches_a_brute_force_torch_scan(world):
                 assert np.array_equal(res.positions[int(po[k]):int(po[k + 1])], db["positions"][int(src[k]):int(src[k]) + n].cpu().numpy().view(np.uint64))
 
 
+def test_aggregates_of_sampled_guides_are_exact_at_full_size(world, oracle):
+    """CFD / Hsu2013 / CRISPRi / closest-hit aggregates at config C3's size, EXACT for 240 sampled guides (they were only
+    range-checked here): the brute-force torch scan gives a guide's complete hit list in database order, the ordered cut-off of
+    CRISPRSiteOT.addOT / full (crispr/CRISPRSiteOT.scala:39-46) is applied to it in numpy, and the oracle's string-level score_guide
+    (Doench2016CFDScore.scala:53-88, CrisprMitEduOffTarget.scala:98-148, ClosestHit.scala:57-67) folds the retained list; the library's
+    per-guide summaries -- from the aggregates-only step bench.py times -- must equal that bit for bit, with the cut-off far away
+    (2000) and biting (60)."""
+    from tests.helpers import assert_same_scores
+    torch, ctx, db = world["torch"], world["ctx"], world["db"]
+    sample = sorted(set(list(range(0, G, 100))[::8] + list(range(7, G, 863))))[:240]
+    assert len(sample) >= 200
+    lists = {}
+    for g in sample:
+        mm = torch_mismatches(torch, int(world["guides"][g].astype(np.int64)), db["targets"])
+        idx = torch.nonzero(mm <= 4).flatten()
+        lists[g] = db["targets"][idx].cpu().numpy().view(np.uint64)
+    sub = world["guides"][sample]
+    for max_ot in (MAX_OT, 60):
+        ctx.scan(world["guides"], 4)
+        only = ctx.finalize(max_ot, summaries_only=True, jost=True)          # the step the bench times: all 100 000 guides, aggregates only
+        full = ctx.discover(sub, 4, max_ot, jost=True)                       # the sampled guides with their lists and per-hit scores
+        assert only.summaries[sample].tobytes() == full.summaries.tobytes()
+
+        class Ora:   # what assert_same_scores reads of an oracle result
+            n_guides = len(sample)
+
+            def hits(self, k):
+                h = lists[sample[k]]
+                before = np.concatenate([[0], np.cumsum((h >> np.uint64(48)).astype(np.int64))[:-1]])
+                return h[before < max_ot]
+
+        ora = Ora()
+        for k in range(len(sample)):
+            assert np.array_equal(full.hits(k), ora.hits(k)), (max_ot, sample[k])
+        assert_same_scores(oracle, 3, sub, full, ora, exact=True, jost=True)
+        if max_ot == 60:
+            assert int(full.summaries["overflow"].sum()) >= 20               # (the cut-off did bite)
+
+
 def test_order_cutoff_and_planted_copies(world):
     ctx = world["ctx"]
     res = ctx.discover(world["guides"], 4, MAX_OT, jost=True)

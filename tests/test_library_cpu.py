@@ -84,3 +84,18 @@ def test_database_writer_matches_the_oracle_writer(oracle, tmp_path, enzyme, bin
         capi.write_database(path, enzyme, targets & np.uint64((1 << 48) - 1), positions, contigs, bin_width=bin_width)
     with pytest.raises(capi.FlashFryHipError, match="sum of the target counts"):
         capi.write_database(path, enzyme, targets, positions[:-1], contigs, bin_width=bin_width)
+
+
+def test_compare_kernel_spills_no_registers():
+    """every instance of the hot kernel, as hipcc compiles it for gfx950: no scalar or vector register spilled, no scratch, four waves per
+    SIMD (the shipped <9, 11, 3> instance spilled 62 scalar registers, the any-width one 107 + 8 vector ones).
+    profiles/r04/kernel_resources_compare.txt is this table."""
+    import re
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kres.sh"), "k_compare<"], capture_output=True, text=True, timeout=600).stdout
+    rows = [l for l in out.splitlines() if "k_compare<" in l]
+    assert len(rows) >= 17, out
+    for l in rows:
+        sp = [int(x) for x in re.findall(r"spilled +(\d+)", l)]
+        assert sp == [0, 0], l
+        assert int(re.search(r"scratch +(\d+)", l).group(1)) == 0, l
+        assert int(re.search(r"waves/SIMD (\d+)", l).group(1)) >= 4, l

@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """Randomised parity sweep against the oracle (dev tool, GPU box): many seeds x sizes x mismatch budgets x cut-offs through the
 same helpers as tests/test_gpu_parity.py.  Prints one line per case and stops at the first difference.
-  python tools/stress_parity.py [seconds [seed]]"""
+
+  python tools/stress_parity.py [seconds [seed [first case]]] [--oracle inproc|isolated] [--quiet]
+
+--oracle isolated (round 4): the oracle runs in a PROCESS OF ITS OWN (tests/oracle_proc.py) that never loads HIP -- no device write,
+page-locked block or host thread of the library can reach the checker's memory.  --oracle inproc keeps the checker in this process,
+next to the library (the form every earlier sweep had).  Either way FFH_POOL_DEBUG=1 is set: the library's page-locked result blocks
+carry canaries, released blocks a poison pattern (PinnedPool, ffh_api.hip); ffh_debug_pool_errors() must stay 0."""
 import os, sys, time
+os.environ.setdefault("FFH_POOL_DEBUG", "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +19,24 @@ import oracle_lib
 from helpers import make_case, make_enzyme_case, assert_same_hits, assert_same_scores
 from test_gpu_parity import dense_case
 
-oracle = oracle_lib.load()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+mode = "inproc"
+if "--oracle" in sys.argv:
+    mode = sys.argv[sys.argv.index("--oracle") + 1]
+    args.remove(mode)
+quiet = "--quiet" in sys.argv
+assert mode in ("inproc", "isolated")
+if mode == "isolated":
+    import oracle_proc
+    oracle = oracle_proc.RemoteOracle()
+else:
+    oracle = oracle_lib.load()
+L = capi.load_library()
+budget = float(args[0]) if len(args) > 0 else 120.0
+rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 12345)
 t0, n = time.time(), 0
-start = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # replay: skip the cases before this one (same random draws, nothing built)
+start = int(args[2]) if len(args) > 2 else 1      # replay: skip the cases before this one (same random draws, nothing built)
+by_kind = {}
 while time.time() - t0 < budget:
     seed = int(rng.integers(0, 1 << 30))
     kind = int(rng.integers(0, 4))
@@ -39,7 +59,8 @@ while time.time() - t0 < budget:
     if n + 1 < start:
         n += 1
         continue
-    print("case %d seed %d kind %d enzyme %d mm %d max_ot %d par %s bounding %d" % (n + 1, seed, kind, enz, max_mm, max_ot, par, bounding), flush=True)
+    if not quiet:
+        print("case %d seed %d kind %d enzyme %d mm %d max_ot %d par %s bounding %d" % (n + 1, seed, kind, enz, max_mm, max_ot, par, bounding), flush=True)
     if kind == 0:
         odb, t, p, g = make_case(oracle, par[0], par[1], enzyme=3, seed=seed)
     elif kind == 2:
@@ -52,6 +73,8 @@ while time.time() - t0 < budget:
         odb, t, p, g = make_enzyme_case(oracle, enz, par[0], par[1], seed=seed)
     else:
         odb, t, p, g = dense_case(oracle, n_random=par[0], n_guides=par[1], n_dense=par[2], variants=par[3], seed=seed)
+    # the inputs as the checker and the library were given them: they must not change under either
+    t_sum, p_sum, g_copy = int(t.sum(dtype=np.uint64)), int(p.sum(dtype=np.uint64)), g.copy()
     with capi.Context(enz) as ctx:
         ctx.load_soa(t, p)
         ctx.set_bounding(bounding)
@@ -70,26 +93,43 @@ while time.time() - t0 < budget:
     if not np.array_equal(gpu.guide_offsets, ora.guide_offsets) or not np.array_equal(gpu.hit_targets, ora.hit_targets):
         # what differs, and whether the same context gives the same answer when asked again (a stale buffer or a race would not)
         bad = [k for k in range(len(g)) if not np.array_equal(gpu.hits(k), ora.hits(k))]
-        print("MISMATCH case %d: %d guides differ: %s" % (n + 1, len(bad), bad[:10]), flush=True)
+        print("MISMATCH case %d (%s oracle): %d guides differ: %s" % (n + 1, mode, len(bad), bad[:10]), flush=True)
+        print("  inputs unchanged: targets %s positions %s guides %s; %d distinct guides of %d" % (
+            int(t.sum(dtype=np.uint64)) == t_sum, int(p.sum(dtype=np.uint64)) == p_sum, np.array_equal(g, g_copy), len(np.unique(g)), len(g)), flush=True)
         idx = {int(v): i for i, v in enumerate(t)}
-        for k in bad[:4]:
-            a, b = set(int(x) for x in gpu.hits(k)), set(int(x) for x in ora.hits(k))
-            print("  guide %d: gpu %d hits, oracle %d, missing %s extra %s (database indices), overflow gpu %d oracle %d, gpu ot_count %d" % (
-                k, len(a), len(b), sorted(idx[v] for v in b - a)[:8], sorted(idx[v] for v in a - b)[:8], int(gpu.summaries["overflow"][k]), int(ora.full[k]), int(gpu.summaries["ot_count"][k])), flush=True)
+        for k in bad[:6]:
+            a, b = [int(x) for x in gpu.hits(k)], [int(x) for x in ora.hits(k)]
+            print("  guide %d (%016x): gpu list %s, oracle list %s (database indices), overflow gpu %d oracle %d, gpu ot_count %d" % (
+                k, int(g[k]), [idx[v] for v in a][:8], [idx.get(v, -1) for v in b][:8], int(gpu.summaries["overflow"][k]), int(ora.full[k]), int(gpu.summaries["ot_count"][k])), flush=True)
         ora_again = odb.discover(g, max_mm, max_ot)
-        print("  the oracle asked again: %s; the guide array holds %d distinct guides of %d" % (
-            "same answer" if np.array_equal(ora_again.guide_offsets, ora.guide_offsets) and np.array_equal(ora_again.hit_targets, ora.hit_targets) else "ANOTHER answer",
-            len(np.unique(g)), len(g)), flush=True)
+        print("  the same oracle database asked again: %s" % (
+            "same answer" if np.array_equal(ora_again.guide_offsets, ora.guide_offsets) and np.array_equal(ora_again.hit_targets, ora.hit_targets) else "ANOTHER answer"), flush=True)
+        for tag, orc in (("a fresh in-process oracle database", oracle_lib.load()), ("a fresh isolated oracle", __import__("oracle_proc").RemoteOracle())):
+            o2 = orc.db_from_sorted(enz, t, p, contigs=["c1"]).discover(g, max_mm, max_ot)
+            print("  %s: %s" % (tag, "agrees with the library" if np.array_equal(o2.guide_offsets, gpu.guide_offsets) and np.array_equal(o2.hit_targets, gpu.hit_targets) else
+                                "agrees with the first oracle answer" if np.array_equal(o2.guide_offsets, ora.guide_offsets) and np.array_equal(o2.hit_targets, ora.hit_targets) else "a third answer"), flush=True)
         for tag, bnd in (("again, same context settings", bounding), ("unbounded", 0)):
             with capi.Context(enz) as ctx2:
                 ctx2.load_soa(t, p)
                 ctx2.set_bounding(bnd)
                 r2 = ctx2.discover(g, max_mm, max_ot, jost=True)
-                print("  %s: %s" % (tag, "agrees with the oracle" if np.array_equal(r2.guide_offsets, ora.guide_offsets) and np.array_equal(r2.hit_targets, ora.hit_targets) else
-                                    "differs (%d guides)" % sum(1 for k in range(len(g)) if not np.array_equal(r2.hits(k), ora.hits(k)))), flush=True)
+                print("  library %s: %s" % (tag, "agrees with the oracle" if np.array_equal(r2.guide_offsets, ora.guide_offsets) and np.array_equal(r2.hit_targets, ora.hit_targets) else
+                                            "differs (%d guides), %s its first answer" % (sum(1 for k in range(len(g)) if not np.array_equal(r2.hits(k), ora.hits(k))),
+                                                                                        "equal to" if np.array_equal(r2.hit_targets, gpu.hit_targets) else "NOT equal to")), flush=True)
+        print("  pool errors so far: %d" % L.ffh_debug_pool_errors(), flush=True)
     assert_same_hits(gpu, ora)
+    if mode == "isolated":
+        oracle.prefetch(enz, g, ora)
     assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
+    assert int(t.sum(dtype=np.uint64)) == t_sum and int(p.sum(dtype=np.uint64)) == p_sum and np.array_equal(g, g_copy), "an input array changed during the case"
+    assert L.ffh_debug_pool_errors() == 0, "the page-locked pool checks fired"
     n += 1
-    print("ok %3d kind %d enzyme %d T %7d G %4d mm %d max_ot %4d hits %8d bounding %2d slabs %d overflow %d" % (n, kind, enz, len(t), len(g), max_mm, max_ot, gpu.n_hits, bounding, slabs,
-                                                                                                                  int(gpu.summaries["overflow"].sum())), flush=True)
-print("all %d cases agree" % n)
+    by_kind[(kind, enz)] = by_kind.get((kind, enz), 0) + 1
+    if not quiet or n % 500 == 0:
+        print("ok %3d kind %d enzyme %d T %7d G %4d mm %d max_ot %4d hits %8d bounding %2d slabs %d overflow %d" % (n, kind, enz, len(t), len(g), max_mm, max_ot, gpu.n_hits, bounding, slabs,
+                                                                                                                      int(gpu.summaries["overflow"].sum())), flush=True)
+del gpu, only, lean
+import gc
+gc.collect()
+print("all %d cases agree (%s oracle, pool errors %d, %.0f s)" % (n - (start - 1), mode, L.ffh_debug_pool_errors(), time.time() - t0))
+print("cases by (kind, enzyme):", dict(sorted(by_kind.items())))
