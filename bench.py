@@ -480,15 +480,34 @@ def main():
     if sharded and exchange_kind == "native":
         # the library's own communicator; should it not come up on this node (it has never run on more than one GPU), or fail in its
         # first step, all ranks fall back to the torch.distributed form of the same exchange -- and the line says so
+        # Every rank takes every collective of this block, whatever failed where (a rank that skipped the broadcast left the
+        # others waiting in it): rank 0 always broadcasts -- the id, or None when it could not make one --, the ranks agree before any
+        # of them calls ncclCommInitRank, and again after the first step.  What this cannot cover: a rank that dies INSIDE
+        # ncclCommInitRank leaves its peers blocked there (RCCL's own rendezvous).
         err = None
-        try:
-            uid = [capi.comm_unique_id() if rank == 0 else None]
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [capi.comm_unique_id()]
+            except Exception as e:   # noqa: BLE001
+                err = repr(e)
+        if world > 1:
             dist.broadcast_object_list(uid, src=0)
-            comm = capi.Comm.rank(ctx, rank, world if world > 1 else 1, uid[0])
-            reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
-            comm.discover_device(guides_dev.data_ptr(), int(guides_dev.shape[0]), args.max_mismatch, args.max_offtargets, want_summaries=(rank == 0), out=reduced)
-        except Exception as e:   # noqa: BLE001 -- whatever it is, the run goes on with the other exchange
-            err = repr(e)
+        if all_ranks_ok(uid[0] is not None):
+            try:
+                comm = capi.Comm.rank(ctx, rank, world if world > 1 else 1, uid[0])
+            except Exception as e:   # noqa: BLE001
+                err = repr(e)
+            if all_ranks_ok(comm is not None):
+                try:
+                    reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
+                    comm.discover_device(guides_dev.data_ptr(), int(guides_dev.shape[0]), args.max_mismatch, args.max_offtargets, want_summaries=(rank == 0), out=reduced)
+                except Exception as e:   # noqa: BLE001 -- whatever it is, the run goes on with the other exchange
+                    err = repr(e)
+            elif err is None:
+                err = "another rank could not create its communicator"
+        elif err is None:
+            err = "rank 0 could not make the RCCL unique id"
         if not all_ranks_ok(err is None):
             exchange_note = "ffh_comm failed on a rank (%s); torch.distributed exchange used instead" % (err or "another rank")
             if comm is not None:

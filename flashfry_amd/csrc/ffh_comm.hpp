@@ -40,11 +40,18 @@ static RcclApi *rccl_api() {   // nullptr-safe: check ->lib
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // FFH_RCCL_LIBRARY: another file name for the RCCL runtime (a site's own build; the tests name a missing one to take the
+        // "no RCCL on this box" path)
+        const char *forced = std::getenv("FFH_RCCL_LIBRARY");
+        std::string why;
+        for (const char *name : {forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (api.lib) break;
+            const char *e = dlerror();   // (one call: glibc hands the message out once and clears it)
+            if (why.empty()) why = e ? e : "dlopen failed";
+            if (forced) break;
         }
-        if (!api.lib) { api.err = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        if (!api.lib) { api.err = "RCCL is not available: " + why; return; }
         bool ok = true;
         auto sym = [&](const char *n) { void *p = dlsym(api.lib, n); if (!p) { ok = false; api.err = std::string("RCCL lacks ") + n; } return p; };
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
@@ -61,20 +68,55 @@ static RcclApi *rccl_api() {   // nullptr-safe: check ->lib
     return &api;
 }
 
-// COPY transport: out[i] = max / sum over the world's rows of all[world][len]
-__global__ void k_comm_reduce_max_f64(const double *__restrict__ all, uint32_t world, uint64_t len, double *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    double v = all[i];
-    for (uint32_t r = 1; r < world; ++r) v = fmax(v, all[(uint64_t)r * len + i]);
-    out[i] = v;
-}
-__global__ void k_comm_reduce_sum_i32(const int32_t *__restrict__ all, uint32_t world, uint64_t len, int32_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    int32_t v = all[i];
-    for (uint32_t r = 1; r < world; ++r) v += all[(uint64_t)r * len + i];
-    out[i] = v;
+// The local half of the exchange: every rank holds every shard's per-guide aggregates (ONE all-gather of the 88-byte summaries, plus a
+// status record per shard) and folds them itself, in shard order = database order:
+//   * prior of shard r = the saturated position totals of the shards before it (CRISPRSiteOT.full, crispr/CRISPRSiteOT.scala:39-46,
+//     continued across shards);
+//   * a shard whose prior is 0, or whose prior + own total stays below maximumOffTargets, aggregated exactly what the unsharded run
+//     keeps of its hits: its record is used as it is;
+//   * a shard whose prior already reached the limit contributes nothing;
+//   * the ONE shard per guide in which a non-zero prior and its own hits cross the limit kept too much: its record is left out and the
+//     guide is counted in flag[0] -- the owner aggregates it again with the prior (k_guide_epilogue's fix-up form) and a second
+//     round, adjusted = 1, folds the corrected records as they are.  A guide set without OVERFLOW guides (the benchmark's) never
+//     needs the second round: one collective per step.
+// Integer lanes add, overflow / cfd_max / jost_max take the maximum, the closest hit the minimum with its count summed over the
+// shards at that level, the f64 sums are added in shard order (deterministic).  flag[0] bit 31: a shard reported a failure.
+__global__ void k_exchange_reduce(const GuideSummary *__restrict__ all /* [world][n + 1] */, uint32_t n, uint32_t world, uint32_t clamp, int adjusted, uint32_t me,
+                                  uint32_t *__restrict__ prior_out /* [n]: prior of shard `me` (first round only) */, GuideSummary *__restrict__ red, uint32_t *__restrict__ flag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0)
+        for (uint32_t r = 0; r < world; ++r)
+            if (all[(size_t)r * (n + 1) + n].n_hits != 0u) atomicOr(flag, 0x80000000u);
+    if (g >= n) return;
+    GuideSummary acc{};
+    acc.closest = 0xFFFFFFFFu;
+    uint64_t run = 0;
+    bool crossing = false, any = false;
+    for (uint32_t r = 0; r < world; ++r) {
+        const GuideSummary v = all[(size_t)r * (n + 1) + g];
+        bool use = true;
+        if (!adjusted) {
+            const uint32_t t = min(v.ot_count, clamp), p = (uint32_t)(run < clamp ? run : clamp);
+            if (r == me) prior_out[g] = p;
+            run += t;
+            if (p > 0u && (uint64_t)p + t >= clamp) {
+                use = false;
+                if (p >= clamp) acc.overflow = 1u;   // (what the shard's own pass with this prior reports: full before its first hit)
+                else crossing = true;
+            }
+        }
+        if (!use) continue;
+        acc.n_hits += v.n_hits; acc.ot_count += v.ot_count; acc.in_genome += v.in_genome; acc.n_scored += v.n_scored;
+        for (int k = 0; k < 5; ++k) acc.hist[k] += v.hist[k];
+        acc.overflow = max(acc.overflow, v.overflow);
+        acc.cfd_max = fmax(acc.cfd_max, v.cfd_max); acc.jost_max = fmax(acc.jost_max, v.jost_max);
+        if (v.closest < acc.closest) { acc.closest = v.closest; acc.closest_count = v.closest_count; }
+        else if (v.closest == acc.closest && v.closest != 0xFFFFFFFFu) acc.closest_count += v.closest_count;
+        if (!any) { acc.cfd_sum = v.cfd_sum; acc.hsu_sum = v.hsu_sum; acc.jost_sum = v.jost_sum; any = true; }
+        else { acc.cfd_sum += v.cfd_sum; acc.hsu_sum += v.hsu_sum; acc.jost_sum += v.jost_sum; }
+    }
+    if (crossing) atomicAdd(flag, 1u);
+    red[g] = acc;
 }
 
 }  // namespace ffh
@@ -87,11 +129,9 @@ struct ffh_comm {
     std::vector<ffh_ctx *> ctx;          // this process's shards, in database order
     std::vector<ncclComm_t> nccl;        // one per local shard (ALL) or one (RANK)
     struct Buf {
-        DevBuf<uint32_t> totals, all_totals, prior;
-        DevBuf<GuideSummary> summ;
-        DevBuf<double> mx, mx_all, fsum, fsum_all;
-        DevBuf<int32_t> sums, sums_all;
-        hipEvent_t ev = nullptr;
+        DevBuf<uint32_t> totals, prior, flag;    // the shard's own saturated totals, its prior (k_exchange_reduce), {crossing guides | failure bit}
+        DevBuf<GuideSummary> summ, all, red;     // [G + 1] this shard's aggregates + status record; [world][G + 1] everybody's; [G] the reduced ones
+        hipEvent_t ev = nullptr, ev_done = nullptr;   // COPY transport: "my record is ready", "I have read everybody's"
     };
     std::vector<std::unique_ptr<Buf>> buf;
     std::string err;
@@ -99,6 +139,7 @@ struct ffh_comm {
     uint32_t n_guides = 0;
     int max_ot = 0;
     bool exchanged = false;
+    uint32_t crossing = 0;               // guides of the last exchange whose cut-off fell inside a shard with a non-zero prior (second round)
     double scan_ms = 0, exchange_ms = 0;  // host wall time of the last ffh_discover_sharded: scans (all local shards), exchange + copy-out
 };
 
@@ -127,17 +168,26 @@ int comm_all_gather(ffh_comm *cm, uint64_t len, ncclDataType_t dt, Src src, Dst 
                 if (i != j) FFC_HIP(hipStreamWaitEvent(cm->ctx[j]->st, cm->buf[i]->ev, 0));
                 FFC_HIP(hipMemcpyAsync(dst(j) + (uint64_t)i * len, src(i), len * sizeof(T), hipMemcpyDeviceToDevice, cm->ctx[j]->st));
             }
+            FFC_HIP(hipEventRecord(cm->buf[j]->ev_done, cm->ctx[j]->st));
+        }
+        // nobody goes on -- and possibly rewrites its record -- before every peer has read it (a stream that ran ahead
+        // reduced in place into the buffer a late reader was still copying from)
+        for (size_t i = 0; i < L; ++i) {
+            FFC_HIP(hipSetDevice(cm->ctx[i]->device));
+            for (size_t j = 0; j < L; ++j) if (i != j) FFC_HIP(hipStreamWaitEvent(cm->ctx[i]->st, cm->buf[j]->ev_done, 0));
         }
         return FFH_OK;
     }
     RcclApi *R = rccl_api();
     if (L > 1) FFC_NCCL(R->GroupStart());
-    for (size_t i = 0; i < L; ++i) {
-        FFC_HIP(hipSetDevice(cm->ctx[i]->device));
-        FFC_NCCL(R->AllGather(src(i), dst(i), len, dt, cm->nccl[i], cm->ctx[i]->st));
+    int rc = FFH_OK;
+    for (size_t i = 0; i < L && rc == FFH_OK; ++i) {   // (an error inside the group still closes it)
+        if (hipSetDevice(cm->ctx[i]->device) != hipSuccess) { cm->err = "hipSetDevice failed inside the collective"; rc = FFH_E_HIP; break; }
+        const ncclResult_t r = R->AllGather(src(i), dst(i), len, dt, cm->nccl[i], cm->ctx[i]->st);
+        if (r != ncclSuccess) { cm->err = std::string("ncclAllGather: ") + R->GetErrorString(r); rc = FFH_E_HIP; }
     }
-    if (L > 1) FFC_NCCL(R->GroupEnd());
-    return FFH_OK;
+    if (L > 1) { const ncclResult_t r = R->GroupEnd(); if (r != ncclSuccess && rc == FFH_OK) { cm->err = std::string("ncclGroupEnd: ") + R->GetErrorString(r); rc = FFH_E_HIP; } }
+    return rc;
 }
 
 }  // namespace
@@ -162,7 +212,8 @@ static ffh_comm *comm_new(ffh_ctx *const *ctxs, int n) {
     cm->ctx.assign(ctxs, ctxs + n);
     for (int i = 0; i < n; ++i) {
         cm->buf.emplace_back(new ffh_comm::Buf());
-        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipEventCreateWithFlags(&cm->buf.back()->ev, hipEventDisableTiming) != hipSuccess) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipEventCreateWithFlags(&cm->buf.back()->ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&cm->buf.back()->ev_done, hipEventDisableTiming) != hipSuccess) {
             g_create_error = "HIP initialisation of the communicator failed";
             ffh_comm_destroy(cm);
             return nullptr;
@@ -177,6 +228,7 @@ void ffh_comm_destroy(ffh_comm *cm) {
         (void)hipSetDevice(cm->ctx[i]->device);
         (void)hipStreamSynchronize(cm->ctx[i]->st);
         if (i < cm->buf.size() && cm->buf[i]->ev) (void)hipEventDestroy(cm->buf[i]->ev);
+        if (i < cm->buf.size() && cm->buf[i]->ev_done) (void)hipEventDestroy(cm->buf[i]->ev_done);
         if (i < cm->buf.size()) cm->buf[i].reset();   // (device buffers are freed on their device)
     }
     for (auto c : cm->nccl) if (c) (void)rccl_api()->CommDestroy(c);
@@ -236,90 +288,92 @@ int ffh_comm_timings(const ffh_comm *cm, double *scan_ms, double *exchange_ms) {
     return FFH_OK;
 }
 
-// the exchange of the shards' aggregates after every local shard has been scanned: stream-ordered on the contexts' streams, no host
-// round trip until the reduced summaries are copied out
-static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, ffh_guide_summary *summaries_out) {
+// The exchange of the shards' aggregates after every local shard has been scanned: stream-ordered on the contexts' streams.
+//   every shard aggregates as if it were the first one (prior 0: exact for every guide whose cut-off the shards before it do not move)
+//   -> ONE all-gather of the 88-byte summaries + a status record per shard
+//   -> every rank folds all shards' records itself, in shard order (k_exchange_reduce), which also yields its own prior
+//   -> one polled host wait: did any guide's cut-off fall inside a shard with a non-zero prior?  (None in a guide set without
+//      OVERFLOW guides: done.)  If so: those shards aggregate the affected guides again with their prior, a second all-gather, a second fold.
+// Round 3 issued four collectives per step (totals all-gather, MAX all-reduce, SUM all-reduce, f64 all-gather) and two epilogue passes
+// per shard whatever the guides; on xGMI every collective is a latency.  local_rc[i] != 0: shard i could not be scanned -- it still
+// takes part (ranks must not be left waiting inside a collective) and every rank returns the failure.
+static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, ffh_guide_summary *summaries_out, const int *local_rc = nullptr) {
     const size_t L = cm->ctx.size();
     const uint32_t W = (uint32_t)cm->world;
-    const bool copy = cm->mode == FFH_COMM_COPY;
     const unsigned jost = flags & FFH_FINALIZE_JOST;
+    std::vector<int> ok(L, 1);
     for (size_t i = 0; i < L; ++i) {
         ffh_ctx *ctx = cm->ctx[i];
         ffh_comm::Buf &b = *cm->buf[i];
         FFC_HIP(hipSetDevice(ctx->device));
-        FFC_HIP(b.totals.reserve((size_t)G + 1)); FFC_HIP(b.all_totals.reserve((size_t)W * G + 1)); FFC_HIP(b.prior.reserve((size_t)G + 1));
-        FFC_HIP(b.summ.reserve((size_t)G + 1));
-        FFC_HIP(b.mx.reserve((size_t)4 * G + 1)); FFC_HIP(b.sums.reserve((size_t)10 * G + 1)); FFC_HIP(b.fsum.reserve((size_t)3 * G + 1));
-        FFC_HIP(b.fsum_all.reserve((size_t)W * 3 * G + 1));
-        if (copy) { FFC_HIP(b.mx_all.reserve((size_t)W * 4 * G + 1)); FFC_HIP(b.sums_all.reserve((size_t)W * 10 * G + 1)); }
+        FFC_HIP(b.totals.reserve((size_t)G + 1)); FFC_HIP(b.prior.reserve((size_t)G + 1)); FFC_HIP(b.flag.reserve(4));
+        FFC_HIP(b.summ.reserve((size_t)G + 1)); FFC_HIP(b.all.reserve((size_t)W * ((size_t)G + 1))); FFC_HIP(b.red.reserve((size_t)G + 1));
         FFC_HIP(ctx->n_ret.reserve((size_t)G + 1));
-        if (!ctx->scanned || ctx->n_guides != G) { cm->err = "a shard has not been scanned with this guide set"; return FFH_E_STATE; }
+        if (local_rc && local_rc[i]) ok[i] = 0;
+        else if (!ctx->scanned || ctx->n_guides != G) { ok[i] = 0; ctx->err = "the shard has not been scanned with this guide set"; }
+        // a scan bounded by a smaller limit than this exchange asks for lacks hits: scan again, unbounded (as ffh_finalize does)
+        else if (check_bound(ctx, max_ot) != FFH_OK) ok[i] = 0;
     }
-    if (!G) return FFH_OK;
     auto epilogue = [&](size_t i, const uint32_t *d_prior, const uint32_t *d_fix, uint32_t *d_totals) {
         ffh_ctx *ctx = cm->ctx[i];
         (void)hipSetDevice(ctx->device);
-        hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
-                           (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
-                           d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_ot, jost ? 1 : 0, ctx->n_ret.p, cm->buf[i]->summ.p, d_totals, d_fix,
-                           (GuideSummary *)nullptr);
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+                                  (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                                  d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_ot, jost ? 1 : 0, ctx->n_ret.p, cm->buf[i]->summ.p, d_totals, d_fix,
+                                  (GuideSummary *)nullptr);
     };
-    // every shard aggregates as if it were the first one; the same pass yields its saturated totals
-    for (size_t i = 0; i < L; ++i) epilogue(i, nullptr, nullptr, cm->buf[i]->totals.p);
-    int rc = comm_all_gather<uint32_t>(cm, G, ncclUint32, [&](size_t i) { return (const uint32_t *)cm->buf[i]->totals.p; }, [&](size_t j) { return cm->buf[j]->all_totals.p; });
-    if (rc) return rc;
-    for (size_t i = 0; i < L; ++i) {
-        ffh_ctx *ctx = cm->ctx[i];
-        ffh_comm::Buf &b = *cm->buf[i];
-        FFC_HIP(hipSetDevice(ctx->device));
-        hipLaunchKernelGGL(k_exchange_prior, dim3(blocks_for(G, 256)), dim3(256), 0, ctx->st, (const uint32_t *)b.all_totals.p, G, (uint32_t)(cm->first + (int)i), (uint32_t)max_ot, b.prior.p);
-        // ... and only the guides whose cut-off the shards before it move are aggregated again
-        epilogue(i, b.prior.p, b.totals.p, nullptr);
-        hipLaunchKernelGGL(k_exchange_pack, dim3(blocks_for(G, 256)), dim3(256), 0, ctx->st, (const GuideSummary *)b.summ.p, G, b.mx.p, b.sums.p, b.fsum.p);
-    }
-    RcclApi *R = copy ? nullptr : rccl_api();
-    // MAX over (overflow, cfd_max, jost_max, -closest)
-    if (copy) {
-        rc = comm_all_gather<double>(cm, (uint64_t)4 * G, ncclFloat64, [&](size_t i) { return (const double *)cm->buf[i]->mx.p; }, [&](size_t j) { return cm->buf[j]->mx_all.p; });
-        if (rc) return rc;
+    auto gather = [&]() {
+        return comm_all_gather<uint64_t>(cm, ((uint64_t)G + 1) * (sizeof(GuideSummary) / 8), ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->summ.p; },
+                                         [&](size_t j) { return (uint64_t *)cm->buf[j]->all.p; });
+    };
+    auto reduce = [&](int adjusted) -> int {
         for (size_t i = 0; i < L; ++i) {
+            ffh_comm::Buf &b = *cm->buf[i];
             FFC_HIP(hipSetDevice(cm->ctx[i]->device));
-            hipLaunchKernelGGL(k_comm_reduce_max_f64, dim3(blocks_for((uint64_t)4 * G, 256)), dim3(256), 0, cm->ctx[i]->st, (const double *)cm->buf[i]->mx_all.p, W, (uint64_t)4 * G, cm->buf[i]->mx.p);
+            FFC_HIP(hipMemsetAsync(b.flag.p, 0, 8, cm->ctx[i]->st));
+            hipLaunchKernelGGL(k_exchange_reduce, dim3(blocks_for((uint64_t)G + 1, 256)), dim3(256), 0, cm->ctx[i]->st, (const GuideSummary *)b.all.p, G, W, (uint32_t)max_ot, adjusted,
+                               (uint32_t)(cm->first + (int)i), b.prior.p, b.red.p, b.flag.p);
         }
-    } else {
-        if (L > 1) FFC_NCCL(R->GroupStart());
-        for (size_t i = 0; i < L; ++i) { FFC_HIP(hipSetDevice(cm->ctx[i]->device)); FFC_NCCL(R->AllReduce(cm->buf[i]->mx.p, cm->buf[i]->mx.p, (size_t)4 * G, ncclFloat64, ncclMax, cm->nccl[i], cm->ctx[i]->st)); }
-        if (L > 1) FFC_NCCL(R->GroupEnd());
-    }
+        FFC_HIP(hipGetLastError());
+        return FFH_OK;
+    };
+    // every shard aggregates as if it were the first one; the same pass yields its saturated totals.  Record G is the status record.
+    static_assert(sizeof(GuideSummary) % 8 == 0, "gathered as 64-bit words");
     for (size_t i = 0; i < L; ++i) {
         FFC_HIP(hipSetDevice(cm->ctx[i]->device));
-        hipLaunchKernelGGL(k_exchange_mask, dim3(blocks_for(G, 256)), dim3(256), 0, cm->ctx[i]->st, (const GuideSummary *)cm->buf[i]->summ.p, G, (const double *)cm->buf[i]->mx.p, cm->buf[i]->sums.p);
-    }
-    // SUM over the integer lanes
-    if (copy) {
-        rc = comm_all_gather<int32_t>(cm, (uint64_t)10 * G, ncclInt32, [&](size_t i) { return (const int32_t *)cm->buf[i]->sums.p; }, [&](size_t j) { return cm->buf[j]->sums_all.p; });
-        if (rc) return rc;
-        for (size_t i = 0; i < L; ++i) {
-            FFC_HIP(hipSetDevice(cm->ctx[i]->device));
-            hipLaunchKernelGGL(k_comm_reduce_sum_i32, dim3(blocks_for((uint64_t)10 * G, 256)), dim3(256), 0, cm->ctx[i]->st, (const int32_t *)cm->buf[i]->sums_all.p, W, (uint64_t)10 * G, cm->buf[i]->sums.p);
+        if (ok[i]) {
+            epilogue(i, nullptr, nullptr, cm->buf[i]->totals.p);
+            FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, 0, sizeof(GuideSummary), cm->ctx[i]->st));
+        } else {
+            FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p, 0, (size_t)G * sizeof(GuideSummary), cm->ctx[i]->st));
+            FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, 0xFF, sizeof(GuideSummary), cm->ctx[i]->st));
         }
-    } else {
-        if (L > 1) FFC_NCCL(R->GroupStart());
-        for (size_t i = 0; i < L; ++i) { FFC_HIP(hipSetDevice(cm->ctx[i]->device)); FFC_NCCL(R->AllReduce(cm->buf[i]->sums.p, cm->buf[i]->sums.p, (size_t)10 * G, ncclInt32, ncclSum, cm->nccl[i], cm->ctx[i]->st)); }
-        if (L > 1) FFC_NCCL(R->GroupEnd());
     }
-    // the f64 sums: gathered, then added in shard order
-    rc = comm_all_gather<double>(cm, (uint64_t)3 * G, ncclFloat64, [&](size_t i) { return (const double *)cm->buf[i]->fsum.p; }, [&](size_t j) { return cm->buf[j]->fsum_all.p; });
+    int rc = gather();
     if (rc) return rc;
-    for (size_t i = 0; i < L; ++i) {
-        FFC_HIP(hipSetDevice(cm->ctx[i]->device));
-        hipLaunchKernelGGL(k_exchange_unpack, dim3(blocks_for(G, 256)), dim3(256), 0, cm->ctx[i]->st, cm->buf[i]->summ.p, G, (const double *)cm->buf[i]->mx.p, (const int32_t *)cm->buf[i]->sums.p,
-                           (const double *)cm->buf[i]->fsum_all.p, W);
+    rc = reduce(0);
+    if (rc) return rc;
+    uint32_t word = 0;
+    FFC_HIP(hipSetDevice(cm->ctx[0]->device));
+    FFC_HIP(spin_wait(cm->ctx[0], nullptr, cm->buf[0]->flag.p, &word));
+    if (word & 0x80000000u) {   // every rank sees the same records, so every rank leaves here
+        for (size_t i = 0; i < L; ++i) { (void)hipSetDevice(cm->ctx[i]->device); (void)hipStreamSynchronize(cm->ctx[i]->st); }
+        cm->err = "a shard could not be scanned";
+        for (size_t i = 0; i < L; ++i) if (!ok[i]) cm->err = "shard " + std::to_string(cm->first + (int)i) + ": " + cm->ctx[i]->err;
+        return FFH_E_STATE;
     }
-    FFC_HIP(hipGetLastError());
-    if (summaries_out) {
+    cm->crossing = word;
+    if (word) {
+        // ... and only the guides whose cut-off the shards before it move are aggregated again (the kernel leaves the others at once)
+        for (size_t i = 0; i < L; ++i) epilogue(i, cm->buf[i]->prior.p, cm->buf[i]->totals.p, nullptr);
+        rc = gather();
+        if (rc) return rc;
+        rc = reduce(1);
+        if (rc) return rc;
+    }
+    if (summaries_out && G) {
         FFC_HIP(hipSetDevice(cm->ctx[0]->device));
-        FFC_HIP(hipMemcpyAsync(summaries_out, cm->buf[0]->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, cm->ctx[0]->st));
+        FFC_HIP(hipMemcpyAsync(summaries_out, cm->buf[0]->red.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, cm->ctx[0]->st));
     }
     for (size_t i = 0; i < L; ++i) { FFC_HIP(hipSetDevice(cm->ctx[i]->device)); FFC_HIP(hipStreamSynchronize(cm->ctx[i]->st)); }
     return FFH_OK;
@@ -342,10 +396,9 @@ int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides
         scan(0);
         for (auto &t : th) t.join();
     }
-    for (size_t i = 0; i < L; ++i)
-        if (rcs[i]) { cm->err = "shard " + std::to_string(cm->first + (int)i) + ": " + cm->ctx[i]->err; return rcs[i]; }
+    // (a shard that could not be scanned still takes part in the exchange: the other ranks must not be left inside a collective)
     const auto t1 = std::chrono::steady_clock::now();
-    const int rc = comm_exchange(cm, n_guides, max_offtargets, flags, summaries_out);
+    const int rc = comm_exchange(cm, n_guides, max_offtargets, flags, summaries_out, rcs.data());
     if (rc) return rc;
     cm->n_guides = n_guides; cm->max_ot = max_offtargets; cm->exchanged = true;
     cm->scan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -377,7 +430,7 @@ int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_resu
 int ffh_comm_device_summaries(ffh_comm *cm, int local_shard, const void **device_summaries) {
     if (!cm || !device_summaries || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) return FFH_E_ARG;
     if (!cm->exchanged) { cm->err = "ffh_discover_sharded has not run"; return FFH_E_STATE; }
-    *device_summaries = cm->buf[(size_t)local_shard]->summ.p;
+    *device_summaries = cm->buf[(size_t)local_shard]->red.p;
     return FFH_OK;
 }
 

@@ -44,6 +44,15 @@ object GPUTraverser extends Traverser with LazyLogging {
   @native private def resultPositions(res: Long): Array[Long]  // ffh_result_positions
   @native private def resultFree(res: Long): Unit
   @native private def lastError(ctx: Long): String
+  // several GPUs (flashfry.gpu.devices): one context per device, the shards' exchange inside the library
+  @native private def dbOpenHeader(ctx: Long, path: String): Int                        // ffh_db_open_header
+  @native private def dbBins(ctx: Long): Int                                            // ffh_db_info_get: n_bins
+  @native private def dbBinBytes(ctx: Long, bin: Int): Long                             // ffh_db_bin_bytes
+  @native private def createLocalComm(ctxs: Array[Long]): Long                          // ffh_comm_create_local: ffh_comm*, 0 on error
+  @native private def commDestroy(comm: Long): Unit
+  @native private def discoverSharded(comm: Long, guides: Array[Long], maxMismatch: Int, maxOffTargets: Int): Int // ffh_discover_sharded
+  @native private def shardLists(comm: Long, shard: Int): Long                          // ffh_comm_shard_lists: ffh_result*, 0 on error
+  @native private def commLastError(comm: Long): String
 
   /** guides per native call, sized so that no returned Array[Long] can reach the 2^31 elements a JVM array holds: a guide keeps
     * fewer than maxOffTargets + 32767 positions (the hit that crosses the limit is kept whole, BlockReader.scala:147-153 caps a
@@ -57,6 +66,50 @@ object GPUTraverser extends Traverser with LazyLogging {
     a
   }
 
+  /** the devices of a run: -Dflashfry.gpu.devices=0,1,2,3,4,5,6,7 (a device may be named twice: two bin shards on it), else the one of
+    * -Dflashfry.gpu.device (default 0) */
+  def devices: Array[Int] = Option(System.getProperty("flashfry.gpu.devices")) match {
+    case Some(s) if s.trim.nonEmpty => s.split(",").map(_.trim.toInt)
+    case _ => Array(Integer.getInteger("flashfry.gpu.device", 0).intValue)
+  }
+
+  /** contiguous bin ranges, balanced by the bins' payload bytes (what BinaryHeader.uncompressedSize records per bin,
+    * reference/binary/BinaryHeader.scala:54): cut(r) = the first bin of shard r, cut(n) = the number of bins */
+  def binCuts(binBytes: Array[Long], n: Int): Array[Int] = {
+    val total = binBytes.map(_.toDouble).sum
+    val cut = Array.fill(n + 1)(binBytes.length)
+    cut(0) = 0
+    var run = 0.0
+    var r = 1
+    var b = 0
+    while (b < binBytes.length && r < n) {
+      run += binBytes(b).toDouble
+      while (r < n && run >= total * r.toDouble / n.toDouble) { cut(r) = b + 1; r += 1 }
+      b += 1
+    }
+    cut
+  }
+
+  /** replays the retained hits of one result (the whole database, or one bin shard) into the aggregator, guide by guide in database
+    * order: exactly the updateOT sequence the CPU traversers produce for these bins.  The lists are already cut off by the library
+    * (ordered cut-off, CRISPRSiteOT.scala:39-46, continued across shards), so updateOT's own `full` test never rejects a hit and
+    * the overflow callback fires on the same hit it would have fired on */
+  private def replay(res: Long, ctx: Long, batch: Array[crispr.GuideIndex], aggregator: ResultsAggregator) {
+    val off = need(resultOffsets(res), "guide offsets", ctx)
+    val tg = need(resultTargets(res), "hit targets", ctx)
+    val po = need(resultPosOffsets(res), "position offsets", ctx)
+    val ps = need(resultPositions(res), "positions", ctx)
+    batch.indices.foreach { g =>
+      var h = off(g).toInt
+      val end = off(g + 1).toInt
+      while (h < end) {
+        aggregator.updateOT(batch(g), new CRISPRHit(tg(h), java.util.Arrays.copyOfRange(ps, po(h).toInt, po(h + 1).toInt)))
+        h += 1
+      }
+    }
+    Traverser.allTargetsAndPositions += ps.length
+  }
+
   def scan(binaryFile: File,
            header: BinaryHeader,
            traversal: BinTraversal,
@@ -66,12 +119,28 @@ object GPUTraverser extends Traverser with LazyLogging {
            bitCoder: BitEncoding,
            posCoder: BitPosition) {
 
-    val device = Integer.getInteger("flashfry.gpu.device", 0).intValue
-    val ctx = create(device, ParameterPack.parameterPackToIndex(configuration))
-    if (ctx == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
+    val devs = devices
+    val enzyme = ParameterPack.parameterPackToIndex(configuration)
+    val path = binaryFile.getAbsolutePath // the body file; the library reads <path>.header itself (BinaryHeader.scala:115-160)
+    val ctxs = new Array[Long](devs.length)
+    var comm = 0L
     try {
-      // the database path is the body file; the library reads <path>.header itself (BinaryHeader.scala:115-160)
-      if (dbOpen(ctx, binaryFile.getAbsolutePath, 0, 0) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctx))
+      devs.indices.foreach { i =>
+        ctxs(i) = create(devs(i), enzyme)
+        if (ctxs(i) == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
+      }
+      // one GPU: the whole database; several: shard i holds the bins [cut(i), cut(i + 1)) (static, contiguous, balanced by payload)
+      if (devs.length == 1) {
+        if (dbOpen(ctxs(0), path, 0, 0) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
+      } else {
+        if (dbOpenHeader(ctxs(0), path) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
+        val cut = binCuts(Array.tabulate(dbBins(ctxs(0)))(b => dbBinBytes(ctxs(0), b)), devs.length)
+        devs.indices.par.foreach { i => // (the loads are independent: one host thread per device)
+          if (dbOpen(ctxs(i), path, cut(i), cut(i + 1)) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(i)))
+        }
+        comm = createLocalComm(ctxs)
+        if (comm == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
+      }
 
       val guides = aggregator.indexedGuides // GuideIndex(guide, index), sorted by start (ResultsAggregator.scala:34-48)
       if (guides.nonEmpty) {
@@ -79,28 +148,27 @@ object GPUTraverser extends Traverser with LazyLogging {
         val maxOffTargets = aggregator.wrappedGuides.head.otSite.overflowValue
 
         guides.grouped(guidesPerCall(maxOffTargets)).foreach { batch =>
-          val res = discover(ctx, batch.map(_.guide), maxMismatch, maxOffTargets)
-          if (res == 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctx))
-          try {
-            val off = need(resultOffsets(res), "guide offsets", ctx)
-            val tg = need(resultTargets(res), "hit targets", ctx)
-            val po = need(resultPosOffsets(res), "position offsets", ctx)
-            val ps = need(resultPositions(res), "positions", ctx)
-            // replay in database order: exactly the updateOT sequence the CPU traversers produce.  The lists are already cut off by
-            // the library (ordered cut-off, CRISPRSiteOT.scala:39-46), so updateOT's own `full` test never rejects a hit and the
-            // overflow callback fires on the same hit it would have fired on
-            batch.indices.foreach { g =>
-              var h = off(g).toInt
-              val end = off(g + 1).toInt
-              while (h < end) {
-                aggregator.updateOT(batch(g), new CRISPRHit(tg(h), java.util.Arrays.copyOfRange(ps, po(h).toInt, po(h + 1).toInt)))
-                h += 1
-              }
+          if (devs.length == 1) {
+            val res = discover(ctxs(0), batch.map(_.guide), maxMismatch, maxOffTargets)
+            if (res == 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
+            try replay(res, ctxs(0), batch, aggregator) finally resultFree(res)
+          } else {
+            // every shard scans all guides of the batch; the library continues the ordered cut-off across the shards and reduces the
+            // aggregates (RCCL over xGMI between distinct devices).  The shards' lists, replayed in shard order, are the database-order
+            // stream of the single traverser: a guide's hits of shard 0, then of shard 1, ...
+            if (discoverSharded(comm, batch.map(_.guide), maxMismatch, maxOffTargets) != 0)
+              throw new IllegalStateException("GPUTraverser: " + commLastError(comm))
+            devs.indices.foreach { i =>
+              val res = shardLists(comm, i)
+              if (res == 0) throw new IllegalStateException("GPUTraverser: " + commLastError(comm))
+              try replay(res, ctxs(i), batch, aggregator) finally resultFree(res)
             }
-            Traverser.allTargetsAndPositions += ps.length
-          } finally resultFree(res)
+          }
         }
       }
-    } finally destroy(ctx)
+    } finally {
+      if (comm != 0) commDestroy(comm)
+      ctxs.foreach(c => if (c != 0) destroy(c))
+    }
   }
 }

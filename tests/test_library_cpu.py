@@ -3,6 +3,7 @@ and refuses to run without a GPU (no silent fallback).  No compute calls here.""
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -99,3 +100,17 @@ def test_compare_kernel_spills_no_registers():
         assert sp == [0, 0], l
         assert int(re.search(r"scratch +(\d+)", l).group(1)) == 0, l
         assert int(re.search(r"waves/SIMD (\d+)", l).group(1)) >= 4, l
+
+
+def test_a_box_without_rccl_gets_an_error_not_a_crash():
+    """when librccl cannot be opened the communicator entry points return FFH_E_STATE with a message (dlerror() used to be
+    called twice -- the second call returns NULL -- and the std::string built from it crashed).  In a process of its own: the
+    library looks for RCCL once per process."""
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, %r); from flashfry_amd import capi; L = capi.load_library(build=False); "
+            "buf = C.create_string_buffer(128); rc = L.ffh_comm_unique_id(buf); msg = L.ffh_comm_last_error(None); "
+            "print(rc, msg.decode())") % ROOT
+    env = dict(os.environ, FFH_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) != 0 and "RCCL is not available" in msg and "nonexistent" in msg, out.stdout
