@@ -81,7 +81,8 @@ struct Image {  // one bucketed scan image of the database
     bool direct = false;      // direct image (k_bucket_first): database index of a slot = slot + ddelta[bucket], ddelta = gstart + nb + 1
     uint32_t *ddelta() const { return gstart.p + ((size_t)1 << (2 * width)) + 1; }
     int rest = 0;             // bases in the rest key (the ones the bucket id does not hold)
-    DevBuf<uint32_t> range;   // {first, last} non-empty bucket
+    DevBuf<uint32_t> live;    // [2^live_bits] which bucket-id prefixes of live_bits = min(2 width, 12) bits hold a target (k_bucket_live)
+    uint32_t live_bits = 0;
 };
 
 struct Plan { int a, r1, s, r2; };  // prefix width/radius, suffix width/radius (r2 < 0: no suffix pass)
@@ -268,7 +269,7 @@ struct ffh_ctx {
     DevBuf<unsigned long long> part_pairs[2];  // per candidate partition: targets x candidates of its buckets (k_item_bin)
     uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
-    DevBuf<uint32_t> icount, ifill, item_gid, part_items, scan_tmp32;
+    DevBuf<uint32_t> icount, ifill, item_gid, scan_tmp32;
     // candidate binning and work list of one image
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
@@ -428,12 +429,11 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
         if (which == 0) hipLaunchKernelGGL(k_image_scatter<false>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
         else hipLaunchKernelGGL(k_image_scatter<true>, dim3(bl), dim3(256), 0, ctx->st, tg, t_n, ctx->geo, width, im.bstart.p, ctx->ifill.p, keys.p, tidx_in.p, (uint32_t)t_lo);
     }
-    {   // the buckets that hold a target: candidate entries outside them are dropped while they are binned
-        FFH_HIP(im.range.reserve(2));
-        const uint32_t init[2] = {nb, 0u};
-        FFH_HIP(hipMemcpyAsync(im.range.p, init, sizeof init, hipMemcpyHostToDevice, ctx->st));
-        FFH_HIP(hipStreamSynchronize(ctx->st));   // (init lives on this stack frame)
-        hipLaunchKernelGGL(k_bucket_range, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, im.range.p);
+    {   // the partitions that hold a target: candidate entries of the others are dropped before they are enumerated
+        im.live_bits = (uint32_t)std::min(2 * width, kMaxPartBits);
+        FFH_HIP(im.live.reserve((size_t)1 << im.live_bits));
+        FFH_HIP(hipMemsetAsync(im.live.p, 0, ((size_t)4) << im.live_bits, ctx->st));
+        hipLaunchKernelGGL(k_bucket_live, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, (uint32_t)(2 * width) - im.live_bits, im.live.p);
     }
     hipLaunchKernelGGL(k_group_count, dim3(blocks_for(nb, 256)), dim3(256), 0, ctx->st, im.bstart.p, nb, ctx->icount.p);
     exclusive_scan<uint32_t, uint32_t>(ctx->icount.p, nb, im.gstart.p, ctx->scan_tmp32.p, ctx->st);
@@ -500,10 +500,10 @@ static int prepare_database(ffh_ctx *ctx) {
 }
 
 // ---- candidate lists (CSR) + work items of one image (no host synchronisation: counts stay on the device) ------
-// im: the image the candidates are for (the shard's, or one slab's: ffh_scan_bounded); range: {first, last} bucket outside which
-// entries are dropped (device memory); gptr: the ng guides of this launch; seg_at >= 0: also clear the hit segments of guides
+// im: the image the candidates are for (the shard's, or one slab's: ffh_scan_bounded; entries of its partitions without a target
+// are dropped); gptr: the ng guides of this launch; seg_at >= 0: also clear the hit segments of guides
 // seg_at .. seg_at + ng - 1 (their numbers in the caller's array)
-static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im, const uint32_t *range, int radius, const uint64_t *gptr, int64_t seg_at, uint32_t ng,
+static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im, int radius, const uint64_t *gptr, int64_t seg_at, uint32_t ng,
                         uint32_t item_base, uint32_t rank_lo = 0u, uint32_t rank_hi = 63u) {
     const int width = im.width;
     const uint32_t nb = 1u << (2 * width);
@@ -521,7 +521,6 @@ static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im
     FFH_HIP(istart.reserve((size_t)nb + 1));
     FFH_HIP(sc.scan_tmp.reserve(scan_scratch_elems_safe(nb)));
     // exact binning of the implicit (bucket, guide) entries into CSR form (see ffh_kernels.hpp)
-    const uint64_t n_enum = (uint64_t)ng * np;
     ItemGeom ig;
     ig.n_guides = ng; ig.n_pat = np;
     // 1024 buckets per partition keep a partition's candidate ids (~13k at hg38 scale) inside the 56 KB LDS stage of k_item_bin,
@@ -536,8 +535,7 @@ static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im
     if (part_bits > (uint32_t)kMaxPartBits || ig.low_bits > (uint32_t)kMaxLowBits) { ctx->err = "bucket width too large for the candidate binning"; return FFH_E_ARG; }
     ig.n_part = 1u << part_bits;
     ig.item_base = item_base;
-    ig.pat_magic = np < (1u << 18) ? ((1ull << 40) + np - 1) / np : 0;  // x < n_pat + 2^18 <= 2^19 inside k_item_partition
-    ig.range = range;
+    ig.live = im.live.p; ig.live_bits = im.live_bits;
     ig.rank_lo = rank_lo; ig.rank_hi = rank_hi; ig.width = (uint32_t)width;
     const bool filtered = rank_lo > 0u || rank_hi < 63u;   // one slab of a bounded scan: the sizes are counted, not derived
     FFH_HIP(sc.part_hist.reserve((size_t)ig.n_part + 1));
@@ -553,37 +551,24 @@ static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im
     FFH_HIP(sc.part_start.reserve((size_t)ig.n_part + 2));
     uint32_t *part_count = sc.part_fill.p, *part_fill = sc.part_fill.p + ig.n_part + 1;
     hipLaunchKernelGGL(k_guide_part_hist, dim3(kPartHistBlocks), dim3(1024), 0, st, gbucket.p, ng, ig.low_bits, ig.n_part, sc.part_hist.p, sc.part_fill.p, 2u * ig.n_part + 2u);
-    static const bool old_binning = getenv("FFH_BINNING") && std::strcmp(getenv("FFH_BINNING"), "records") == 0;   // A/B: the round-2 form
-    if (!old_binning) {
-        // guides grouped by partition (counting sort on the histogram), then every partition's block enumerates its own entries from
-        // those runs: no intermediate records (ffh_kernels.hpp: k_item_bin_direct)
-        FFH_HIP(sc.gp_start.reserve((size_t)ig.n_part + 2));
-        FFH_HIP(sc.by_part.reserve((size_t)ng + 1));
-        exclusive_scan<uint32_t, uint32_t>(sc.part_hist.p, ig.n_part, sc.gp_start.p, sc.scan_tmp.p, st);
-        hipLaunchKernelGGL(k_guide_by_part, dim3(blocks_for(ng, 1024)), dim3(1024), 0, st, (const uint32_t *)gbucket.p, ng, ig.low_bits, ig.n_part,
-                           (const uint32_t *)sc.gp_start.p, part_fill, sc.by_part.p);
-        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_count);
-        else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
-                                (const uint32_t *)patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                (unsigned long long *)nullptr);
-        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, sc.part_start.p, sc.scan_tmp.p, st);
-        if (!filtered) hipLaunchKernelGGL((k_item_bin_direct<false, false>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
-                                          (const uint32_t *)patterns.p, ig, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p,
-                                          (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
-        else hipLaunchKernelGGL((k_item_bin_direct<false, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
-                                (const uint32_t *)patterns.p, ig, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p, (const uint32_t *)im.bstart.p,
-                                ctx->part_pairs[which].p);
-    } else {
-        FFH_HIP(ctx->part_items.reserve((size_t)n_enum + 1));
-        const unsigned pblocks = blocks_for(n_enum, kPartItemsPerBlock);
-        if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_count);
-        else hipLaunchKernelGGL((k_item_partition<false, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr);
-        exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, sc.part_start.p, sc.scan_tmp.p, st);
-        if (!filtered) hipLaunchKernelGGL((k_item_partition<true, false>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, sc.part_start.p, part_fill, ctx->part_items.p);
-        else hipLaunchKernelGGL((k_item_partition<true, true>), dim3(pblocks), dim3(kPartThreads), 0, st, gbucket.p, patterns.p, ig, sc.part_start.p, part_fill, ctx->part_items.p);
-        hipLaunchKernelGGL(k_item_bin, dim3(ig.n_part), dim3(kPartThreads), 0, st, sc.part_start.p, ctx->part_items.p, ig, istart.p, ctx->item_gid.p,
-                           (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
-    }
+    // guides grouped by partition (counting sort on the histogram), then every partition's block enumerates its own entries from
+    // those runs: no intermediate records (ffh_kernels.hpp: k_item_bin_direct)
+    FFH_HIP(sc.gp_start.reserve((size_t)ig.n_part + 2));
+    FFH_HIP(sc.by_part.reserve((size_t)ng + 1));
+    exclusive_scan<uint32_t, uint32_t>(sc.part_hist.p, ig.n_part, sc.gp_start.p, sc.scan_tmp.p, st);
+    hipLaunchKernelGGL(k_guide_by_part, dim3(blocks_for(ng, 1024)), dim3(1024), 0, st, (const uint32_t *)gbucket.p, ng, ig.low_bits, ig.n_part,
+                       (const uint32_t *)sc.gp_start.p, part_fill, sc.by_part.p);
+    if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_bits, part_count);
+    else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
+                            (const uint32_t *)patterns.p, ig, part_bits, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                            (unsigned long long *)nullptr);
+    exclusive_scan<uint32_t, uint32_t>(part_count, ig.n_part, sc.part_start.p, sc.scan_tmp.p, st);
+    if (!filtered) hipLaunchKernelGGL((k_item_bin_direct<false, false>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
+                                      (const uint32_t *)patterns.p, ig, part_bits, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p,
+                                      (const uint32_t *)im.bstart.p, ctx->part_pairs[which].p);
+    else hipLaunchKernelGGL((k_item_bin_direct<false, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
+                            (const uint32_t *)patterns.p, ig, part_bits, (const uint32_t *)sc.part_start.p, (uint32_t *)nullptr, istart.p, ctx->item_gid.p, (const uint32_t *)im.bstart.p,
+                            ctx->part_pairs[which].p);
     ctx->n_part[which] = ig.n_part;
     FFH_HIP(hipGetLastError());
     return FFH_OK;
@@ -1195,7 +1180,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // instead of 4.7e7, 15.4 against 9.6 ms per step on the repeat-structured workload.  Dropped.)
     if (shared_prefix) {
         FFH_HIP(ctx->item_gid.reserve(n_items_p_all + (uint64_t)n_guides * (uint64_t)np_s + 64));
-        const int rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, ctx->guides.p, -1, n_guides, 0u);
+        const int rc = prepare_side(ctx, st, 0, ctx->img[0], plan.r1, ctx->guides.p, -1, n_guides, 0u);
         if (rc) return rc;
     }
     for (size_t sl = 0; sl < slabs.size() && n_act; ++sl) {
@@ -1215,13 +1200,13 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             // streams' kernels did not overlap on this stack and every event wait added a few microseconds.  One stream.)
             CompareArgs ca{};
             if (plan.r2 >= 0) {
-                rc = prepare_side(ctx, st, 1, *SL.suffix, SL.suffix->range.p, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
+                rc = prepare_side(ctx, st, 1, *SL.suffix, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
                 if (rc) return rc;
                 rc = side_plan(st, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
                 if (rc) return rc;
             } else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
             if (!shared_prefix) {
-                rc = prepare_side(ctx, st, 0, ctx->img[0], ctx->img[0].range.p, plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
+                rc = prepare_side(ctx, st, 0, ctx->img[0], plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
                 if (rc) return rc;
             }
             if (shared_prefix) rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);

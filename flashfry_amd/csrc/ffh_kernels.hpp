@@ -201,14 +201,12 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
 // capacity guess, so skewed guide sets (tiling libraries, repeats) cost nothing extra -- and without per-entry global
 // atomics (device-scope atomics on random addresses run at ~1.3e10/s on MI355X: 4 ms for the 5.6e7 entries of the
 // hg38-scale workload):
-//   A1 k_guide_part_hist + k_part_sizes : the partition (= high bits of the bucket id) sizes, computed without touching
+//   A k_guide_part_hist + k_part_sizes : the partition (= high bits of the bucket id) sizes, computed without touching
 //                           the entries (XOR convolution of two histograms);  exclusive scan of the <= 4096 sizes;
-//   A2 k_item_partition   : a block enumerates 256Ki entries, reserves one run per partition (one atomic each) and writes
-//                           (low bucket bits, guide) records into the partition's exactly-sized staging range;
-//   B  k_item_bin         : one block per partition counts its records per bucket in LDS, scans the counts, writes
-//                           the CSR offsets of its buckets and scatters the guide ids into place (LDS atomics only).
+//   B k_guide_by_part + k_item_bin_direct : the guides grouped by partition, then one block per partition enumerates its own
+//                           entries from those runs, counts them per bucket in LDS, scans the counts, writes the CSR offsets of
+//                           its buckets and puts the guide ids into place (LDS atomics only).
 constexpr int kPartThreads = 1024;
-constexpr int kPartItemsPerBlock = 32768;
 constexpr int kMaxPartBits = 12;   // <= 4096 partitions
 constexpr int kMaxLowBits = 12;    // <= 4096 buckets per partition (11 bits preferred: see prepare_side)
 constexpr int kBinStage = 14336;   // candidate ids staged in LDS per partition (56 KB: two blocks per CU); larger partitions scatter to memory
@@ -219,10 +217,12 @@ struct ItemGeom {
     uint32_t low_bits;       // bucket id = (partition << low_bits) | low
     uint32_t n_part;
     uint32_t item_base;      // first CSR slot of this image (the two images share the item array)
-    uint64_t pat_magic;      // ceil(2^40 / n_pat) when n_pat < 2^18 (then x / n_pat == (x * pat_magic) >> 40 for x < 2^19), else 0
-    const uint32_t *range;   // {first, last} bucket of this image that holds a target: entries outside it are dropped while they are
-                             // binned (a bin shard of a multi-GPU run holds a contiguous eighth of the prefix buckets: seven eighths
-                             // of the (bucket, guide) entries would meet no target)
+    const uint32_t *live;    // [2^live_bits] which of the image's bucket-id prefixes of live_bits bits hold a target (k_bucket_live): the
+    uint32_t live_bits;      // entries of a partition without one are dropped before they are enumerated.  A bin shard of a multi-GPU
+                             // run holds a contiguous eighth of SEQUENCE space; the bucket id keeps the two bit planes apart, so that
+                             // is not a range of ids -- but the partition bits are the first bases' high bits and the first base's
+                             // low bit, and exactly the partitions of the shard's leading bases are alive: an eighth of the entries
+                             // for an eighth of the database (round 3 dropped by {first, last} non-empty bucket: half of them)
     // one slab of a bounded scan (prefix image only): keep the entries whose bucket's first three bases, read as a number 0..63 in
     // sequence order, lie in [rank_lo, rank_hi].  The bucket id holds the planes apart (all high bits, then all low bits), so a
     // slab of the database order is not a range of bucket ids; {0, 63} = everything, and the partition sizes then still come from
@@ -235,26 +235,17 @@ __device__ __forceinline__ uint32_t bucket_rank(uint32_t b, uint32_t width) {
     const uint32_t h = (b >> (2u * width - 3u)) & 7u, l = (b >> (width - 3u)) & 7u;
     return ((h & 4u) << 3) | ((l & 4u) << 2) | ((h & 2u) << 2) | ((l & 2u) << 1) | ((h & 1u) << 1) | (l & 1u);
 }
-template <bool SLAB>
-__device__ __forceinline__ bool entry_kept(uint32_t b, uint32_t part, uint32_t part_lo, uint32_t part_hi, const ItemGeom &ig) {
-    if (part < part_lo || part > part_hi) return false;
-    if (!SLAB) return true;
-    const uint32_t r = bucket_rank(b, ig.width);
-    return r >= ig.rank_lo && r <= ig.rank_hi;
-}
-
-// first and last non-empty bucket of an image (range[0] starts at the bucket count, range[1] at 0)
-__global__ void k_bucket_range(const uint32_t *__restrict__ bstart, uint32_t nb, uint32_t *__restrict__ range) {
+// which bucket-id prefixes of `bits` bits hold a target (live[] zeroed before)
+__global__ void k_bucket_live(const uint32_t *__restrict__ bstart, uint32_t nb, uint32_t shift, uint32_t *__restrict__ live) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb || bstart[b + 1] == bstart[b]) return;
-    const bool first = b == 0 || bstart[b] == bstart[0], last = b == nb - 1 || bstart[b + 1] == bstart[nb];
-    if (first) atomicMin(&range[0], b);
-    if (last) atomicMax(&range[1], b);
+    if (b < nb && bstart[b + 1] != bstart[b]) live[b >> shift] = 1u;
 }
-
-// entry number -> guide number inside a block's window: a 32-bit division costs ~30 instructions per entry and pass
-__device__ __forceinline__ uint32_t div_pat(uint32_t x, const ItemGeom &ig) {
-    return ig.pat_magic ? (uint32_t)(((uint64_t)x * ig.pat_magic) >> 40) : x / ig.n_pat;
+// does partition `part` (the high part_bits bits of a bucket id) hold a target?  Called by a whole wave (lanes share the flags).
+__device__ __forceinline__ bool part_live_wave(const ItemGeom &ig, uint32_t part, uint32_t part_bits, uint32_t lane) {
+    const uint32_t sh = ig.live_bits - part_bits, n = 1u << sh;   // (live_bits >= part_bits: prepare_side)
+    bool any = false;
+    for (uint32_t k = lane; k < n; k += 64) any |= ig.live[(part << sh) + k] != 0u;
+    return __ballot(any) != 0ull;
 }
 
 // exclusive scan over the 1024 threads of a block (16 waves)
@@ -310,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__rest
     }
 }
 // one wave per partition, the lanes stride over the patterns (a thread per partition left 4096 threads walking 529 patterns each: 36 us)
-__global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig,
+__global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits,
                                                     uint32_t *__restrict__ part_count) {
     const uint32_t q = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= ig.n_part) return;
@@ -318,141 +309,17 @@ __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__
     for (uint32_t p = lane; p < ig.n_pat; p += 64) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
-    if (lane == 0) part_count[q] = (q >= (ig.range[0] >> ig.low_bits) && q <= (ig.range[1] >> ig.low_bits)) ? n : 0u;   // partitions without a target take no entries
-}
-
-template <bool WRITE, bool SLAB>
-__global__ __launch_bounds__(kPartThreads) void k_item_partition(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ patterns, ItemGeom ig,
-                                                                 const uint32_t *__restrict__ part_start, uint32_t *__restrict__ part_fill,
-                                                                 uint32_t *__restrict__ part_items) {
-    __shared__ uint32_t cur[1 << kMaxPartBits];
-    const uint64_t total = (uint64_t)ig.n_guides * ig.n_pat;
-    const uint64_t begin = (uint64_t)blockIdx.x * kPartItemsPerBlock;
-    const uint64_t end = min(total, begin + (uint64_t)kPartItemsPerBlock);
-    for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) cur[d] = 0;
-    __syncthreads();
-    // entry i = guide (i / n_pat), pattern (i % n_pat); 32-bit arithmetic relative to the block's first entry
-    const uint32_t g_first = (uint32_t)(begin / ig.n_pat), j_first = (uint32_t)(begin - (uint64_t)g_first * ig.n_pat);
-    const uint32_t n_here = (uint32_t)(end - begin);
-    const uint32_t part_lo = ig.range[0] >> ig.low_bits, part_hi = ig.range[1] >> ig.low_bits;
-    for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
-        const uint32_t x = j_first + o, q = div_pat(x, ig);
-        const uint32_t b = gbucket[g_first + q] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
-        if (entry_kept<SLAB>(b, part, part_lo, part_hi, ig)) atomicAdd(&cur[lds_slot(part)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < ig.n_part; d += kPartThreads) {
-        const uint32_t c = cur[lds_slot(d)];
-        if (!WRITE) { if (c) atomicAdd(&part_fill[d], c); }                              // A1: partition sizes
-        else cur[lds_slot(d)] = c ? part_start[d] + atomicAdd(&part_fill[d], c) : 0u;  // A2: start of this block's run
-    }
-    if (!WRITE) return;
-    __syncthreads();
-    for (uint32_t o = threadIdx.x; o < n_here; o += kPartThreads) {
-        const uint32_t x = j_first + o, q = div_pat(x, ig), g = g_first + q;
-        const uint32_t b = gbucket[g] ^ patterns[x - q * ig.n_pat], part = b >> ig.low_bits;
-        if (!entry_kept<SLAB>(b, part, part_lo, part_hi, ig)) continue;
-        const uint32_t pos = atomicAdd(&cur[lds_slot(part)], 1u);
-        part_items[pos] = ((b & ((1u << ig.low_bits) - 1u)) << kGidBits) | g;
-    }
-}
-
-// One block per partition.  The partition's candidate ids are put in bucket order inside LDS and leave as one
-// contiguous, coalesced copy: scattering 4-byte stores straight to memory costs a partial-line write-back each once the
-// concurrently open output windows exceed the L2 (1.1 ms for the 5.3e7 entries of the hg38-scale prefix image).
-__global__ __launch_bounds__(kPartThreads, 8) void k_item_bin(const uint32_t *__restrict__ part_start, const uint32_t *__restrict__ part_items, ItemGeom ig,
-                                                           uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid, const uint32_t *__restrict__ bstart,
-                                                           unsigned long long *__restrict__ part_pairs /* [n_part]: the partition's executed-pair statistic,
-                                                           sum over its buckets of targets x candidates (k_work_count adds the partitions up) */) {
-    __shared__ uint32_t cnt[1 << kMaxLowBits];
-    __shared__ uint32_t stage[kBinStage];
-    __shared__ uint32_t scan_lds[16];
-    __shared__ unsigned long long pair_lds[16];
-    const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits;
-    for (uint32_t l = threadIdx.x; l < nlow; l += kPartThreads) cnt[l] = 0;
-    __syncthreads();
-    const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
-    const uint32_t *__restrict__ src = part_items + p0;
-    const uint32_t gbase = ig.item_base + p0;  // records of partition d occupy CSR slots [item_base + p0, + n)
-    const uint32_t per = (nlow + kPartThreads - 1) / kPartThreads, l0 = threadIdx.x * per;
-    // exclusive scan of the nlow counters (every thread owns nlow / 1024 consecutive ones, at most 4): CSR offsets out, counters
-    // become scatter cursors
-    auto scan_counters = [&]() {
-        uint32_t mine = 0;
-        for (uint32_t k = 0; k < per; ++k)
-            if (l0 + k < nlow) mine += cnt[lds_slot(l0 + k)];
-        uint32_t tot;
-        uint32_t off = block_exclusive_scan_1024(mine, scan_lds, tot);
-        unsigned long long pairs = 0;
-        for (uint32_t k = 0; k < per; ++k)
-            if (l0 + k < nlow) {
-                const uint32_t c = cnt[lds_slot(l0 + k)];
-                const uint64_t bucket = ((uint64_t)d << ig.low_bits) + l0 + k;
-                istart[bucket] = gbase + off;
-                cnt[lds_slot(l0 + k)] = off;
-                off += c;
-                if (c) pairs += (unsigned long long)c * (bstart[bucket + 1] - bstart[bucket]);
-            }
-        if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) pairs += __shfl_xor(pairs, s, 64);
-        if ((threadIdx.x & 63) == 0) pair_lds[threadIdx.x >> 6] = pairs;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long t = 0;
-            for (int w = 0; w < kPartThreads / 64; ++w) t += pair_lds[w];
-            part_pairs[d] = t;
-        }
-    };
-    if (n <= (uint32_t)kBinStage) {
-        // the usual case: the whole partition sits in registers (14 records per thread, all loads in flight at once), is counted and
-        // placed from there -- one read of the records instead of two, one memory round trip instead of eight
-        constexpr int kR = kBinStage / kPartThreads;
-        static_assert(kR * kPartThreads == kBinStage, "kBinStage is a multiple of the block size");
-        uint32_t r[kR];
-#pragma unroll
-        for (int u = 0; u < kR; ++u) { const uint32_t k = u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
-#pragma unroll
-        for (int u = 0; u < kR; ++u) if ((uint32_t)(u * kPartThreads) + threadIdx.x < n) atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
-        __syncthreads();
-        scan_counters();
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kR; ++u)
-            if ((uint32_t)(u * kPartThreads) + threadIdx.x < n) stage[atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u)] = r[u] & ((1u << kGidBits) - 1u);
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n; k += kPartThreads) item_gid[gbase + k] = stage[k];
-        return;
-    }
-    // oversized partition (skewed guide sets): two passes over the records, scattered stores
-    constexpr int kU = 4;  // records in flight per thread
-    for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
-        uint32_t r[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) if (k0 + u * kPartThreads + threadIdx.x < n) atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u);
-    }
-    __syncthreads();
-    scan_counters();
-    __syncthreads();
-    for (uint32_t k0 = 0; k0 < n; k0 += kPartThreads * kU) {
-        uint32_t r[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) { const uint32_t k = k0 + u * kPartThreads + threadIdx.x; r[u] = k < n ? src[k] : 0xFFFFFFFFu; }
-#pragma unroll
-        for (int u = 0; u < kU; ++u)
-            if (k0 + u * kPartThreads + threadIdx.x < n) item_gid[gbase + atomicAdd(&cnt[lds_slot(r[u] >> kGidBits)], 1u)] = r[u] & ((1u << kGidBits) - 1u);
-    }
+    const bool live = part_live_wave(ig, q, part_bits, lane);
+    if (lane == 0) part_count[q] = live ? n : 0u;   // partitions without a target take no entries
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same CSR without the intermediate records (round 3).  bucket = guide bucket ^ pattern acts on the partition bits and on the low
+// The CSR is built without intermediate records (round 3; round 2 wrote every entry as a 4-byte record into one of 4096 runs first and
+// read it back: 0.33 ms for the prefix side).  bucket = guide bucket ^ pattern acts on the partition bits and on the low
 // bits separately, so the entries of partition q come, for every pattern p, from the guides of ONE partition, q ^ high(p).  With the
 // guides grouped by partition (k_guide_by_part: a counting sort on the histogram k_guide_part_hist leaves anyway; 100 000 guides)
 // the block of partition q enumerates its own entries straight from those runs -- once to count its buckets, once to place the
-// guide ids -- and the 4-byte record per entry that k_item_partition wrote (2.4 x its size in half-filled sectors) and k_item_bin
-// read back is gone: 0.33 -> ~0.15 ms for the 5.3e7 entries of the hg38-scale prefix image.
+// guide ids: ~0.15 ms for the 5.3e7 entries of the hg38-scale prefix image.
 // ---------------------------------------------------------------------------------------------------------
 // guides grouped by partition: by_part[gp_start[part] + k] = (low bucket bits << kGidBits) | guide.  A block of 1024 guides counts
 // its guides per partition in LDS and reserves one run per partition it touches (an image with few partitions -- the suffix side --
@@ -479,7 +346,7 @@ __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restri
 // its rank filter looks at the low bucket bits, so the XOR convolution of k_part_sizes does not apply) -> part_count[d].
 template <bool COUNT, bool SLAB>
 __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint32_t *__restrict__ gp_start, const uint32_t *__restrict__ by_part,
-                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, const uint32_t *__restrict__ part_start,
+                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, const uint32_t *__restrict__ part_start,
                                                                   uint32_t *__restrict__ part_count, uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid,
                                                                   const uint32_t *__restrict__ bstart, unsigned long long *__restrict__ part_pairs) {
     __shared__ uint32_t cnt[1 << kMaxLowBits];
@@ -487,8 +354,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint3
     __shared__ uint32_t scan_lds[16];
     __shared__ unsigned long long pair_lds[16];
     const uint32_t d = blockIdx.x, nlow = 1u << ig.low_bits, lowmask = nlow - 1u;
-    const uint32_t part_lo = ig.range[0] >> ig.low_bits, part_hi = ig.range[1] >> ig.low_bits;
-    const bool live = d >= part_lo && d <= part_hi;   // partitions without a target take no entries
+    const bool live = part_live_wave(ig, d, part_bits, threadIdx.x & 63u);   // partitions without a target take no entries
     // virtual threads = (pattern, slice of the source run): S slices per pattern keep the block busy when there are few patterns.
     // (A wave per slice of the patterns with its lanes side by side on the source run -- coalesced reads -- was measured too: 318
     // against 210 us for the hg38-scale prefix image; the runs are short (~24 guides) and a wave then walks ~33 patterns one after

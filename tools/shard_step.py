@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--guides", type=int, default=100000)
     ap.add_argument("--plan-a", type=int, default=-1, help="force the prefix width (default: the library's choice)")
     ap.add_argument("--plan-r1", type=int, default=-1, help="force the prefix radius")
+    ap.add_argument("--comm", action="store_true", help="time ffh_discover_sharded through a one-rank RCCL communicator on the shard: the sharded run's own code path (device "
+                    "summaries, the all-gather, the local fold, rank 0's copy-out) -- what one rank does, minus the links")
     args = ap.parse_args()
     import torch
     from flashfry_amd import capi, synth
@@ -40,6 +42,20 @@ def main():
             res = ctx.finalize(2000, summaries_only=True)
             ts.append((time.perf_counter() - t0) * 1e3)
             tms.append(ctx.timings().as_dict())
+        if args.comm:
+            with capi.Comm.rank(ctx, 0, 1, capi.comm_unique_id()) as comm:
+                out = np.zeros(args.guides, dtype=capi.SUMMARY_DTYPE)
+                for _ in range(3):
+                    comm.discover_device(gd.data_ptr(), args.guides, 4, 2000, out=out)
+                tc, ex = [], []
+                for _ in range(10):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    comm.discover_device(gd.data_ptr(), args.guides, 4, 2000, out=out)
+                    tc.append((time.perf_counter() - t0) * 1e3)
+                    ex.append(comm.timings())
+                assert out.tobytes() == res.summaries.tobytes()
+                print(json.dumps({"shards": args.shards, "rank": args.rank, "comm_one_rank_ms_per_step": float(np.median(tc)),
+                                  "scan_ms": float(np.median([e["scan_ms"] for e in ex])), "exchange_ms": float(np.median([e["exchange_ms"] for e in ex]))}))
         print(json.dumps({"shards": args.shards, "rank": args.rank, "targets": hi - lo, "ms_per_step": float(np.median(ts)),
                           "breakdown_ms": {k: round(float(np.mean([x[k] for x in tms])), 3) for k in ("prepare_ms", "compare_ms", "sort_ms", "finalize_ms", "total_scan_ms")},
                           "plan": [int(tms[-1]["prefix_bases"]), int(tms[-1]["prefix_radius"]), int(tms[-1]["suffix_radius"])], "tiles_prefix": int(tms[-1]["tiles_prefix"]), "pairs": int(tms[-1]["pairs_prefix"] + tms[-1]["pairs_suffix"]), "hits": int(res.summaries["n_hits"].sum())}))
