@@ -46,6 +46,12 @@ void set_global_error(const std::string &m) { g_create_error = m; }
 
 namespace {
 
+// Every (re)allocation and release of a device buffer, and every new database, moves the epoch on: a captured launch sequence
+// (PrepGraph) holds raw pointers and is only replayed while nothing it could refer to has moved.  While a sequence is being captured
+// on this thread an allocation is refused instead (hipMalloc is not capturable): the caller then runs the sequence uncaptured.
+static std::atomic<uint64_t> g_alloc_epoch{1};
+static thread_local bool t_capturing = false;
+
 template <typename T>
 struct DevBuf {  // device allocation that grows on demand and frees itself (on the device that is current: the entry points set it)
     T *p = nullptr;
@@ -61,6 +67,8 @@ struct DevBuf {  // device allocation that grows on demand and frees itself (on 
     ~DevBuf() { release(); }
     hipError_t reserve(size_t n) {  // contents are NOT preserved
         if (n <= cap) return hipSuccess;
+        if (t_capturing) return hipErrorStreamCaptureUnsupported;
+        g_alloc_epoch.fetch_add(1);
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = n + n / 8 + 64;
@@ -69,7 +77,7 @@ struct DevBuf {  // device allocation that grows on demand and frees itself (on 
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { (void)hipFree(p); g_alloc_epoch.fetch_add(1); } p = nullptr; cap = 0; }
 };
 
 struct Image {  // one bucketed scan image of the database
@@ -297,6 +305,17 @@ struct ffh_ctx {
     DevBuf<GuideSummary> summ;
     ScoreTables *d_tab = nullptr;
 
+    // The candidate-list / work-list kernels of a scan (~26 launches of a few microseconds each: the host cannot issue them as fast
+    // as the device runs them) as ONE captured graph, replayed while the call is the same in everything the launches depend on -- guide
+    // buffer and count, plan, images, buffers (g_alloc_epoch).  The first call of a kind runs uncaptured (it may allocate), the second
+    // captures, the following ones replay.  Work, results and counters are those of the plain launches; FFH_GRAPH=0 switches it off.
+    struct PrepGraph {
+        hipGraphExec_t exec = nullptr;
+        uint64_t key[12] = {}, seen[12] = {}, epoch = 0, seen_epoch = 0;
+        SideArgs side[2];
+        double expect[2] = {0, 0};
+        uint32_t n_part[2] = {0, 0};
+    } pg;
     hipEvent_t ev[8] = {};
     ffh_timings tm{};
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
@@ -451,6 +470,7 @@ static int build_image(ffh_ctx *ctx, int which, int width) { return build_image_
 // targets/positions are already on the device in ctx->targets / ctx->positions
 static int prepare_database(ffh_ctx *ctx) {
     if (ctx->T >= (1ull << 31) - 64) { ctx->err = "more than 2^31 targets in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
+    g_alloc_epoch.fetch_add(1);   // (a new database: nothing captured against the old one may be replayed)
     FFH_HIP(hipEventRecord(ctx->ev[0], ctx->st));
     // counts -> position offsets; validate counts like BlockManager.scala:232-236
     FFH_HIP(ctx->out_cnt.reserve(ctx->T + 1));
@@ -696,6 +716,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
+    if (ctx->pg.exec) (void)hipGraphExecDestroy(ctx->pg.exec);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
@@ -1188,30 +1209,77 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         const unsigned long long slab_start = cursor_before;
         for (uint32_t g0 = 0; g0 < n_act;) {
             const uint32_t ng = std::min(batch, n_act - g0);
-            // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
-            hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(64), 0, st, ctx->d_counters, first_launch ? 1 : 0);
             const uint64_t n_items_p = (uint64_t)ng * (uint64_t)np_p, n_items_s = plan.r2 >= 0 ? (uint64_t)ng * (uint64_t)np_s : 0;
             if (n_items_p + n_items_s >= (1ull << 32) - 64) { ctx->err = "candidate list too large for one batch"; return FFH_E_ARG; }
             FFH_HIP(ctx->item_gid.reserve(n_items_p + n_items_s + 64));
             FFH_HIP(hipEventRecord(ctx->ev[2], st));
-            int rc = FFH_OK;
             // (The two images' candidate lists do not depend on each other and most of their kernels sit on the launch floor, so round 3
             // ran the suffix image's on a second stream, forked and joined with events: 2.14 against 2.13 ms per step -- the two
             // streams' kernels did not overlap on this stack and every event wait added a few microseconds.  One stream.)
             CompareArgs ca{};
-            if (plan.r2 >= 0) {
-                rc = prepare_side(ctx, st, 1, *SL.suffix, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
-                if (rc) return rc;
-                rc = side_plan(st, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
-                if (rc) return rc;
-            } else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
-            if (!shared_prefix) {
-                rc = prepare_side(ctx, st, 0, ctx->img[0], plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
-                if (rc) return rc;
+            auto run_prepare = [&]() -> int {
+                // the pair counters are per launch (a launch that has to be redone with a larger hit buffer must not count twice)
+                hipLaunchKernelGGL(k_compare_setup, dim3(1), dim3(64), 0, st, ctx->d_counters, first_launch ? 1 : 0);
+                int rc = FFH_OK;
+                if (plan.r2 >= 0) {
+                    rc = prepare_side(ctx, st, 1, *SL.suffix, plan.r2, act_guides + g0, -1, ng, (uint32_t)(shared_prefix ? n_items_p_all : n_items_p));
+                    if (rc) return rc;
+                    rc = side_plan(st, 1, *SL.suffix, SL.n_targets, plan.s, plan.r1, np_s, ng, ca.side[1]);   // a pair with <= r1 mismatches in its prefix is the prefix image's to report
+                    if (rc) return rc;
+                } else { ca.side[1] = SideArgs{}; ca.side[1].tidx = ctx->img[1].tidx.p; }
+                if (!shared_prefix) {
+                    rc = prepare_side(ctx, st, 0, ctx->img[0], plan.r1, act_guides + g0, bounded ? -1 : (int64_t)g0, ng, 0u, SL.rank_lo, SL.rank_hi);
+                    if (rc) return rc;
+                }
+                if (shared_prefix) rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
+                else rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
+                return rc;
+            };
+            {
+                static const bool graphs_on = !(getenv("FFH_GRAPH") && atoi(getenv("FFH_GRAPH")) == 0);
+                ffh_ctx::PrepGraph &pg = ctx->pg;
+                const bool eligible = graphs_on && !bounded && !ctx->borrowed && g0 == 0 && ng == n_guides && first_launch;
+                const uint64_t key[12] = {(uint64_t)(uintptr_t)(act_guides + g0), ng, (uint64_t)max_mm, (uint64_t)plan.a, (uint64_t)plan.r1, (uint64_t)(int64_t)plan.r2,
+                                          (uint64_t)(uintptr_t)ctx->img[0].gwords.p, (uint64_t)(uintptr_t)SL.suffix->gwords.p, ctx->compare_grid, (uint64_t)(uintptr_t)ctx->item_gid.p,
+                                          ctx->T, (uint64_t)(uintptr_t)ctx->seg_begin.p};
+                const uint64_t epoch = g_alloc_epoch.load();
+                bool done = false;
+                if (eligible && pg.exec && pg.epoch == epoch && !std::memcmp(pg.key, key, sizeof key)) {
+                    FFH_HIP(hipGraphLaunch(pg.exec, st));
+                    ca.side[0] = pg.side[0]; ca.side[1] = pg.side[1]; expect[0] = pg.expect[0]; expect[1] = pg.expect[1];
+                    ctx->n_part[0] = pg.n_part[0]; ctx->n_part[1] = pg.n_part[1];
+                    done = true;
+                } else if (eligible && pg.seen_epoch == epoch && !std::memcmp(pg.seen, key, sizeof key)) {
+                    if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
+                    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                        t_capturing = true;
+                        const int rc = run_prepare();
+                        t_capturing = false;
+                        hipGraph_t graph = nullptr;
+                        hipError_t e = hipStreamEndCapture(st, &graph);
+                        if (rc == FFH_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&pg.exec, graph, nullptr, nullptr, 0);
+                        else if (e == hipSuccess) e = hipErrorUnknown;
+                        if (graph) (void)hipGraphDestroy(graph);
+                        if (e == hipSuccess) e = hipGraphLaunch(pg.exec, st);
+                        if (e == hipSuccess) {
+                            std::memcpy(pg.key, key, sizeof key); pg.epoch = epoch;
+                            pg.side[0] = ca.side[0]; pg.side[1] = ca.side[1]; pg.expect[0] = expect[0]; pg.expect[1] = expect[1];
+                            pg.n_part[0] = ctx->n_part[0]; pg.n_part[1] = ctx->n_part[1];
+                            done = true;
+                        } else {   // (whatever it was: the plain launches below do the work)
+                            if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
+                            (void)hipGetLastError();
+                            ctx->err.clear();
+                        }
+                    } else (void)hipGetLastError();
+                }
+                if (!done) {
+                    const int rc = run_prepare();
+                    if (rc) return rc;
+                    std::memcpy(pg.seen, key, sizeof key);
+                    pg.seen_epoch = g_alloc_epoch.load();
+                }
             }
-            if (shared_prefix) rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, n_guides, ca.side[0], SL.rank_lo, SL.rank_hi, sl == 0);
-            else rc = side_plan(st, 0, ctx->img[0], ctx->T, plan.a, -1, np_p, ng, ca.side[0]);
-            if (rc) return rc;
             FFH_HIP(hipEventRecord(ctx->ev[3], st));   // (prepare_ms: candidate lists and work lists; compare_ms: the compare launch alone)
             ca.gids = ctx->item_gid.p; ca.hits = ctx->hits.p; ca.cap = (uint64_t)ctx->hits.cap; ca.tbits = ctx->tbits; ca.max_mm = max_mm;
             ca.guide_base[0] = shared_prefix ? 0u : g0; ca.guide_base[1] = g0;
