@@ -1443,43 +1443,6 @@ int ffh_set_bounding(ffh_ctx *ctx, int mode) {
     return FFH_OK;
 }
 
-// The aggregates-only epilogue, in the form that suits the scan's hits per guide: a wave per guide (hg38 scale at <= 4 mismatches: ~116
-// raw hits per guide), or 32 / 16 lanes per guide when the guides have few hits -- a bin shard of a multi-GPU run, a small database,
-// few mismatches -- with the guides that have more left to a second, list-driven launch of the wave form (ffh_kernels.hpp).
-// FFH_EPILOGUE=wave|rows32|rows16 forces one (tests, A/B).
-static hipError_t launch_epilogue(ffh_ctx *ctx, hipStream_t st, const uint32_t *d_prior, const uint32_t *d_fix, uint32_t *d_totals, GuideSummary *d_out,
-                                  GuideSummary *host_out, uint32_t max_ot, int jost) {
-    const uint32_t G = ctx->n_guides;
-    if (!G) return hipSuccess;
-    const uint64_t *st_t = ctx->hit_t_ready ? ctx->hit_t.p : nullptr;
-    int rw = 64;
-    const double mean = (double)ctx->n_raw / (double)G;
-    if (mean <= 5.0) rw = 16; else if (mean <= 20.0) rw = 32;
-    if (const char *f = getenv("FFH_EPILOGUE")) rw = !std::strcmp(f, "rows16") ? 16 : !std::strcmp(f, "rows32") ? 32 : !std::strcmp(f, "wave") ? 64 : rw;
-    if (rw == 64) {
-        hipLaunchKernelGGL(k_guide_epilogue<false>, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, st_t, (const uint64_t *)ctx->hits_sorted,
-                           (const uint64_t *)ctx->targets.p, ctx->tbits, d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, max_ot, jost, ctx->n_ret.p, d_out, d_totals, d_fix, host_out,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-        return hipGetLastError();
-    }
-    hipError_t e = ctx->heavy_list.reserve((size_t)G + 1);
-    if (e != hipSuccess) return e;
-    uint32_t *n_big = (uint32_t *)(ctx->d_counters + 14);
-    e = hipMemsetAsync(n_big, 0, 8, st);
-    if (e != hipSuccess) return e;
-    if (rw == 16) hipLaunchKernelGGL(k_guide_epilogue_rows<16>, dim3(blocks_for(G, 16)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, st_t, (const uint64_t *)ctx->hits_sorted,
-                                     (const uint64_t *)ctx->targets.p, ctx->tbits, d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, max_ot, jost, ctx->n_ret.p, d_out, d_totals, d_fix,
-                                     host_out, ctx->heavy_list.p, n_big);
-    else hipLaunchKernelGGL(k_guide_epilogue_rows<32>, dim3(blocks_for(G, 8)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, st_t, (const uint64_t *)ctx->hits_sorted,
-                            (const uint64_t *)ctx->targets.p, ctx->tbits, d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, max_ot, jost, ctx->n_ret.p, d_out, d_totals, d_fix, host_out,
-                            ctx->heavy_list.p, n_big);
-    // the guides with more hits than a row holds: the wave form over the list (its blocks beyond the list's end leave at once)
-    hipLaunchKernelGGL(k_guide_epilogue<true>, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, st_t, (const uint64_t *)ctx->hits_sorted,
-                       (const uint64_t *)ctx->targets.p, ctx->tbits, d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, max_ot, jost, ctx->n_ret.p, d_out, d_totals, d_fix, host_out,
-                       (const uint32_t *)ctx->heavy_list.p, (const uint32_t *)n_big);
-    return hipGetLastError();
-}
-
 // a bounded scan holds, for a retired guide, only the hits up to the slab in which it reached bound_ot positions
 // -- which is everything a caller with a limit <= bound_ot can ask for.  A larger limit (ffh_discover(A) followed by ffh_finalize /
 // ffh_shard_totals with B > A) needs hits the bounded scan never collected: the guide set is still resident, so the scan is redone
@@ -1600,11 +1563,14 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         // the kernel stores every summary into the result's page-locked block as well (hipHostMalloc memory is mapped into the
         // device's address space): the 88 bytes per guide cross the link under the kernel instead of in a copy after it
         static const bool zero_copy = !(getenv("FFH_SUMMARY_COPY") && atoi(getenv("FFH_SUMMARY_COPY")) == 1);
-        hipError_t e = launch_epilogue(ctx, st, d_prior, nullptr, nullptr, ctx->summ.p, zero_copy ? (GuideSummary *)r->summaries : (GuideSummary *)nullptr,
-                                       (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0);
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
+                                  (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                                  d_prior, ctx->guides.p, ctx->geo,
+                                  ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p, ctx->summ.p, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                  zero_copy ? (GuideSummary *)r->summaries : (GuideSummary *)nullptr);
         // no scan of the per-guide hit counts and no copy of the offsets: nobody needs them to read the aggregates, and whoever
         // asks (ffh_result_guide_offsets / ffh_result_n_hits) gets them folded from the summaries' n_hits on the host
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], st);
+        hipError_t e = hipEventRecord(ctx->ev[1], st);
         if (e == hipSuccess) e = hipGetLastError();
         if (G && e == hipSuccess && !zero_copy) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = spin_wait(ctx, nullptr);
@@ -2207,7 +2173,10 @@ static int shard_epilogue(ffh_ctx *ctx, int max_offtargets, unsigned flags, cons
     const uint32_t G = ctx->n_guides;
     FFH_HIP(ctx->n_ret.reserve((size_t)G + 1));
     if (!d_fix_totals) FFH_HIP(hipEventRecord(ctx->ev[7], ctx->st));
-    FFH_HIP(launch_epilogue(ctx, ctx->st, d_prior, d_fix_totals, d_totals, (GuideSummary *)d_summaries, nullptr, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0));
+    if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+                              (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                              d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_offtargets, (flags & FFH_FINALIZE_JOST) ? 1 : 0, ctx->n_ret.p,
+                              (GuideSummary *)d_summaries, d_totals, d_fix_totals, (GuideSummary *)nullptr);
     FFH_HIP(hipGetLastError());
     if (!d_fix_totals) { FFH_HIP(hipEventRecord(ctx->ev[1], ctx->st)); ctx->finalize_timing_pending = true; }
     FFH_HIP(fence_out(ctx));

@@ -314,11 +314,13 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
         // a scan bounded by a smaller limit than this exchange asks for lacks hits: scan again, unbounded (as ffh_finalize does)
         else if (check_bound(ctx, max_ot) != FFH_OK) ok[i] = 0;
     }
-    auto epilogue = [&](size_t i, const uint32_t *d_prior, const uint32_t *d_fix, uint32_t *d_totals) -> hipError_t {
+    auto epilogue = [&](size_t i, const uint32_t *d_prior, const uint32_t *d_fix, uint32_t *d_totals) {
         ffh_ctx *ctx = cm->ctx[i];
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e == hipSuccess) e = launch_epilogue(ctx, ctx->st, d_prior, d_fix, d_totals, cm->buf[i]->summ.p, nullptr, (uint32_t)max_ot, jost ? 1 : 0);
-        return e;
+        (void)hipSetDevice(ctx->device);
+        if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, ctx->st, ctx->seg_begin.p, ctx->seg_end.p,
+                                  (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
+                                  d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_ot, jost ? 1 : 0, ctx->n_ret.p, cm->buf[i]->summ.p, d_totals, d_fix,
+                                  (GuideSummary *)nullptr);
     };
     auto gather = [&]() {
         return comm_all_gather<uint64_t>(cm, ((uint64_t)G + 1) * (sizeof(GuideSummary) / 8), ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->summ.p; },
@@ -340,7 +342,7 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
     for (size_t i = 0; i < L; ++i) {
         FFC_HIP(hipSetDevice(cm->ctx[i]->device));
         if (ok[i]) {
-            FFC_HIP(epilogue(i, nullptr, nullptr, cm->buf[i]->totals.p));
+            epilogue(i, nullptr, nullptr, cm->buf[i]->totals.p);
             FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, 0, sizeof(GuideSummary), cm->ctx[i]->st));
         } else {
             FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p, 0, (size_t)G * sizeof(GuideSummary), cm->ctx[i]->st));
@@ -363,7 +365,7 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
     cm->crossing = word;
     if (word) {
         // ... and only the guides whose cut-off the shards before it move are aggregated again (the kernel leaves the others at once)
-        for (size_t i = 0; i < L; ++i) FFC_HIP(epilogue(i, cm->buf[i]->prior.p, cm->buf[i]->totals.p, nullptr));
+        for (size_t i = 0; i < L; ++i) epilogue(i, cm->buf[i]->prior.p, cm->buf[i]->totals.p, nullptr);
         rc = gather();
         if (rc) return rc;
         rc = reduce(1);

@@ -743,7 +743,6 @@ __global__ __launch_bounds__(256) void k_guide_aggregate(const uint64_t *__restr
 // against 0.31 ms at hg38 scale, 0.34 against 0.29 ms on an eighth of it.  The chain of dependent loads is hidden better by the
 // three extra waves than by the prefetch.  Two or four guides per wave one after the other, the tables filled once per 8 or 16 guides:
 // 0.335 against 0.313 ms.)
-template <bool LIST>   // LIST: only the guides of glist[0 .. *n_glist) (what k_guide_epilogue_rows left to this kernel); else every guide
 __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
                                                         const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
                                                         const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
@@ -752,9 +751,7 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
                                                         uint32_t *__restrict__ totals_out /* nullable: min(positions of all hits, overflow) */,
                                                         const uint32_t *__restrict__ fix_totals /* nullable: redo only guides the prior changes */,
                                                         GuideSummary *__restrict__ host_out /* nullable: page-locked host copy of out[], written
-                                                        by the kernel itself so that no device-to-host copy follows the launch */,
-                                                        const uint32_t *__restrict__ glist, const uint32_t *__restrict__ n_glist /* LIST only */) {
-    if (LIST && blockIdx.x * 4u >= *n_glist) return;   // (block-uniform, before the tables are staged)
+                                                        by the kernel itself so that no device-to-host copy follows the launch */) {
     __shared__ ScoreTables lt;  // 4.6 KB: the coefficient tables, read with rolled loops (low register count -> 8 waves per SIMD)
     {
         const double *src = reinterpret_cast<const double *>(tab);
@@ -764,9 +761,8 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
     __shared__ WalkLds wk;
     __shared__ GuideSummary out_lds[4];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), gi = blockIdx.x * 4 + wave;
-    if (LIST ? gi >= *n_glist : gi >= n_guides) return;
-    const uint32_t g = LIST ? wave_uniform(glist[gi]) : gi;
+    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), g = blockIdx.x * 4 + wave;
+    if (g >= n_guides) return;
     const uint32_t b = wave_uniform(seg_begin[g]), e = wave_uniform(seg_end[g]), p0 = wave_uniform(prior ? prior[g] : 0u);
     // multi-GPU fix-up pass: a shard's own aggregates (computed with prior 0) stand unless the positions of the shards before it
     // push this guide's running total to the limit inside or before this shard
@@ -839,123 +835,6 @@ __global__ __launch_bounds__(256) void k_guide_epilogue(const uint32_t *__restri
         reinterpret_cast<uint32_t *>(out + g)[lane] = v;
         if (host_out) reinterpret_cast<uint32_t *>(host_out + g)[lane] = v;
     }
-}
-
-// The same epilogue for guides with FEW hits: RW = 16 or 32 lanes per guide, 4 or 2 guides per wave.  A bin shard of a multi-GPU run
-// (an eighth of hg38: 15 raw hits per guide), a chr22-scale database, a <= 3-mismatch scan leave most of a wave's 64 lanes idle in
-// the wave-per-guide form, whose cost is then per guide, not per hit (0.195 ms for 1.5e6 hits where 1.16e7 take 0.31).  Same
-// arithmetic in the same order -- the kept hits of a guide are the lanes 0 .. nk-1 of its row, folded in that order -- so the
-// summaries are bit-identical.  A guide with more than RW raw hits is put on `big` and left to the wave-per-guide kernel (list mode).
-template <int RW>
-__global__ __launch_bounds__(256) void k_guide_epilogue_rows(const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ st,
-                                                             const uint64_t *__restrict__ hit_keys, const uint64_t *__restrict__ targets, int tbits,
-                                                             const uint32_t *__restrict__ prior, const uint64_t *__restrict__ guides, Geometry geo,
-                                                             const ScoreTables *__restrict__ tab, uint32_t n_guides, uint32_t overflow, int want_jost,
-                                                             uint32_t *__restrict__ n_ret, GuideSummary *__restrict__ out, uint32_t *__restrict__ totals_out,
-                                                             const uint32_t *__restrict__ fix_totals, GuideSummary *__restrict__ host_out,
-                                                             uint32_t *__restrict__ big, uint32_t *__restrict__ n_big) {
-    static_assert(RW == 16 || RW == 32, "rows of 16 or 32 lanes");
-    constexpr uint32_t GPW = 64 / RW;   // guides per wave
-    __shared__ ScoreTables lt;
-    {
-        const double *src = reinterpret_cast<const double *>(tab);
-        double *dst = reinterpret_cast<double *>(&lt);
-        for (uint32_t i = threadIdx.x; i < sizeof(ScoreTables) / sizeof(double); i += blockDim.x) dst[i] = src[i];
-    }
-    __shared__ WalkLds wk;
-    __shared__ GuideSummary out_lds[4][GPW];
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), sub = lane / RW, rl = lane % RW;
-    const uint32_t g = (blockIdx.x * 4 + wave) * GPW + sub;
-    bool act = g < n_guides;
-    const uint32_t b = act ? seg_begin[g] : 0u, e = act ? seg_end[g] : 0u, p0 = (act && prior) ? prior[g] : 0u;
-    if (act && fix_totals && !(p0 > 0u && p0 + fix_totals[g] >= overflow)) act = false;   // (the fix-up pass: see k_guide_epilogue)
-    if (act && e - b > (uint32_t)RW) {
-        if (rl == 0) big[atomicAdd(n_big, 1u)] = g;
-        act = false;
-    }
-    if (!__ballot(act)) return;
-    auto row_sum = [](uint32_t v) {
-#pragma unroll
-        for (int d = RW / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        return v;
-    };
-    const uint64_t gd = act ? guides[g] : 0ull;
-    const bool in = act && rl < e - b;
-    const uint64_t t = !in ? 0ull : st ? st[b + rl] : targets[hit_keys[b + rl] & ((1ull << tbits) - 1ull)];
-    const uint32_t c = in ? (uint32_t)(t >> 48) : 0u;
-    uint32_t incl = c;   // inclusive scan inside the row
-#pragma unroll
-    for (int d = 1; d < RW; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (rl >= (uint32_t)d) incl += o;
-    }
-    const bool keep = in && (p0 + (incl - c) < overflow);          // CRISPRSiteOT.addOT / full, crispr/CRISPRSiteOT.scala:39-46
-    const uint64_t kb = __ballot(keep);
-    const uint32_t nk = (uint32_t)__popcll((kb >> (sub * RW)) & ((1ull << RW) - 1ull));   // the kept hits are the row's lanes 0 .. nk-1
-    const uint32_t last = (uint32_t)__shfl((int)incl, (int)(sub * RW + (nk ? nk - 1u : 0u)), 64);
-    const uint32_t run = p0 + (nk ? last : 0u);
-    int mmi = 0xFF;
-    double f = __builtin_nan(""), h = 0.0, j = __builtin_nan("");
-    if (keep) {
-        score_pair(gd, t, geo, &lt, mmi, f, h);
-        if (want_jost && geo.c0 == 3 && mmi != 0) j = jost_pair(gd, t, geo, &lt);
-    }
-    const uint32_t m = keep ? (uint32_t)mmi : 0xFFu, ck = keep ? c : 0u;
-    GuideSummary s;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s.hist[k] = row_sum((m == (uint32_t)k) ? ck : 0u);   // ClosestHit.scala:57-59
-    uint32_t cm = (keep && m > 0) ? m : 0xFFFFFFFFu;                                   // :62-67
-#pragma unroll
-    for (int d = RW / 2; d >= 1; d >>= 1) cm = min(cm, (uint32_t)__shfl_xor(cm, d, 64));
-    const uint32_t closest_count = row_sum((cm != 0xFFFFFFFFu && m == cm) ? ck : 0u);
-    // ordered f64 sums: every lane folds its row's parked addends in lane order; unscored and unkept lanes hold +0.0, which leaves a
-    // non-negative sum bit for bit as it is, so the walk runs over the whole row without a mask
-    const bool sc = keep && f == f;
-    const double fz = sc ? f * (double)c : 0.0, hz = sc ? h : 0.0;
-    double lane_cfd_max = sc ? f : 0.0, cfd_sum = 0.0, hsu_sum = 0.0, jost_sum = 0.0, lane_jost_max = 0.0;
-    const uint32_t n_scored = (uint32_t)__popcll((__ballot(sc) >> (sub * RW)) & ((1ull << RW) - 1ull));
-    walk_park(wk, wave, lane, fz, hz);
-#pragma unroll 4
-    for (int l = 0; l < RW; ++l) {
-        cfd_sum += wk.fh[wave][sub * RW + l][0];
-        hsu_sum += wk.fh[wave][sub * RW + l][1];
-    }
-    if (want_jost) {
-        const bool sj = keep && j == j;
-        lane_jost_max = sj ? j : 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        wk.j[wave][lane] = sj ? j * (double)c : 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-        for (int l = 0; l < RW; ++l) jost_sum += wk.j[wave][sub * RW + l];
-    }
-#pragma unroll
-    for (int d = RW / 2; d >= 1; d >>= 1) {
-        lane_cfd_max = fmax(lane_cfd_max, __shfl_xor(lane_cfd_max, d, 64));
-        lane_jost_max = fmax(lane_jost_max, __shfl_xor(lane_jost_max, d, 64));
-    }
-    s.n_hits = nk; s.ot_count = run - p0; s.overflow = run >= overflow;
-    s.closest = cm; s.closest_count = cm == 0xFFFFFFFFu ? 0u : closest_count;
-    s.in_genome = s.hist[0]; s.n_scored = n_scored;
-    s.cfd_max = lane_cfd_max; s.cfd_sum = cfd_sum; s.hsu_sum = hsu_sum;
-    s.jost_max = lane_jost_max; s.jost_sum = jost_sum;
-    if (act && rl == 0) {
-        out_lds[wave][sub] = s; n_ret[g] = nk;
-        if (totals_out) totals_out[g] = min(run - p0, overflow);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (act)
-        for (uint32_t w = rl; w < 22u; w += RW) {   // coalesced 88-byte stores (k_guide_epilogue)
-            const uint32_t v = reinterpret_cast<const uint32_t *>(&out_lds[wave][sub])[w];
-            reinterpret_cast<uint32_t *>(out + g)[w] = v;
-            if (host_out) reinterpret_cast<uint32_t *>(host_out + g)[w] = v;
-        }
 }
 
 __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ out_off,

@@ -244,46 +244,3 @@ def test_hit_ordering_by_segments_and_by_six_passes_agree_with_the_oracle(capi, 
     assert per_guide.max() > 1024 and (per_guide <= 128).sum() > 50 and ((per_guide > 128) & (per_guide <= 1024)).sum() > 5, (per_guide.max(), tm.n_raw_hits)
     assert_same_hits(gpu, odb.discover(g, 4, 2 ** 31 - 1))
     assert_same_hits(cut, odb.discover(g, 5, 300))
-
-
-@pytest.mark.parametrize("form", ["rows16", "rows32", "wave"])
-def test_the_three_forms_of_the_aggregates_epilogue_are_bit_identical(capi, oracle, monkeypatch, form):
-    """The aggregates-only epilogue runs a wave per guide, or 32 / 16 lanes per guide when the guides have few hits (a bin shard, a small
-    database), leaving guides with more hits than a row holds to a list-driven launch of the wave form (launch_epilogue).
-    FFH_EPILOGUE forces each: the summaries must equal the list path's (which goes through other kernels) bit for bit and the oracle's
-    scores exactly, with guides on both sides of the row sizes, with the cut-off biting, and in a three-shard exchange whose cut-offs
-    fall inside later shards (the fix-up pass with a prior)."""
-    from tests.test_gpu_parity import dense_case
-    monkeypatch.setenv("FFH_EPILOGUE", form)
-    odb, t, p, g = dense_case(oracle, n_random=150_000, n_guides=300, n_dense=40, variants=90, seed=77)
-    for max_ot in (2000, 12):
-        with capi.Context(3) as ctx:
-            ctx.load_soa(t, p)
-            full = ctx.discover(g, 4, max_ot, jost=True)
-            only = ctx.finalize(max_ot, summaries_only=True, jost=True)
-        per = np.diff(full.guide_offsets.astype(np.int64))
-        if max_ot == 2000:
-            assert (per > 32).sum() >= 5 and ((per > 16) & (per <= 32)).sum() >= 1 and (per <= 16).sum() >= 50, np.bincount(np.minimum(per, 40))
-        assert only.summaries.tobytes() == full.summaries.tobytes()
-        ora = odb.discover(g, 4, max_ot)
-        assert_same_hits(full, ora)
-        assert_same_scores(oracle, 3, g, full, ora, jost=True)
-        # three shards by targets, the exchange inside the library (copy transport)
-        T = len(t)
-        cnt = (t >> np.uint64(48)).astype(np.int64)
-        poff = np.concatenate([[0], np.cumsum(cnt)])
-        ctxs = []
-        try:
-            for lo, hi in ((0, T // 3), (T // 3, 2 * T // 3), (2 * T // 3, T)):
-                c = capi.Context(3)
-                c.load_soa(t[lo:hi], p[poff[lo]:poff[hi]])
-                ctxs.append(c)
-            with capi.Comm.local(ctxs) as comm:
-                summ = comm.discover(g, 4, max_ot, jost=True)
-        finally:
-            for c in ctxs:
-                c.close()
-        s = full.summaries
-        for f in ("n_hits", "ot_count", "overflow", "hist", "closest", "closest_count", "in_genome", "n_scored"):
-            assert np.array_equal(s[f], summ[f]), (form, max_ot, f)
-        assert np.array_equal(s["cfd_max"], summ["cfd_max"]) and np.abs(s["cfd_sum"] - summ["cfd_sum"]).max() <= 1e-9 and np.abs(s["hsu_sum"] - summ["hsu_sum"]).max() <= 1e-9
