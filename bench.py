@@ -676,7 +676,10 @@ def main():
             "discover_product_ms": {"default_table": lists_ms["no_positions"], "with_positionOutput": lists_ms["lists"]} if lists_ms else None,
             # ... with this library's per-hit pam*cfd array on top (8 more bytes per hit across the link)
             "discover_with_lists_and_hit_scores_ms": lists_ms["lists_and_hit_scores"] if lists_ms else None,
-            "roofline": {"bound": "valu-issue", "kernel": "ffh::k_compare",
+            "roofline": {"bound": "hbm", "kernel": "ffh::k_compare",
+                         # what keeps the launch from its HBM roofline: vector issue (valu_issue_frac) and, with four waves per SIMD, the
+                         # waves' own LDS round trips (profiles/r04/ab_log.txt)
+                         "limiter": "valu-issue",
                          # SURVEY.md section 8d's HBM figure: algorithmic bytes of the launch against the 8 TB/s data-sheet peak
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_detail": traffic_note, "algorithmic_bytes_per_launch": b_alg, "launch_ms": cmp_ms,
@@ -688,6 +691,13 @@ def main():
                                         "instructions_per_2048_pairs_prefix": ops_p, "instructions_per_2048_pairs_suffix": ops_s},
                          "sq_counters_per_launch": sq or None,
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
+            # the second kernel of the step: one random 8-byte read of the target array per raw hit = one 128-byte line each (no cache
+            # policy changes that: profiles/r03/gather_policy.txt, a bare gather of as many lines takes 0.22-0.26 ms on this part)
+            "roofline_epilogue": {"bound": "hbm", "kernel": "ffh::k_guide_epilogue", "launch_ms": float(np.mean([t["finalize_ms"] for t in tms])),
+                                  "algorithmic_bytes_per_launch": 16 * raw_hits, "line_bytes_per_launch": 136 * raw_hits,
+                                  "achieved": 136 * raw_hits / (float(np.mean([t["finalize_ms"] for t in tms])) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": 136 * raw_hits / (float(np.mean([t["finalize_ms"] for t in tms])) * 1e-3) / 1e9 / 8000.0,
+                                  "note": "achieved counts the 128-byte line every gathered target long costs + the 8-byte key; by SURVEY 8d's 16 B per hit the fraction is 16/136 of this"},
             "cpu_baseline": _CPU_JVM if (_CPU_JVM and _CPU_JVM.get("value")) else cpu,
             "cpu_baseline_port": cpu if (_CPU_JVM and _CPU_JVM.get("value")) else None,
             "cpu_baseline_all_cores": _CPU_MT,

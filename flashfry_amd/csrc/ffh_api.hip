@@ -1286,7 +1286,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             ca.gmap[0] = shared_prefix ? nullptr : (act_map ? act_map + g0 : nullptr);
             ca.gmap[1] = act_map ? act_map + g0 : nullptr;
             if (!launch_compare(ca, ctx->d_counters, ctx->compare_grid, st,
-                                work_list_is_long(expect[0], ctx->compare_grid) && (plan.r2 < 0 || work_list_is_long(expect[1], ctx->compare_grid)))) {
+                                plan.r2 < 0 ? work_list_chunk(expect[0], ctx->compare_grid) : std::min(work_list_chunk(expect[0], ctx->compare_grid), work_list_chunk(expect[1], ctx->compare_grid)))) {
                 ctx->err = "no compare kernel for rest keys of " + std::to_string(ca.side[0].rest) + " + " + std::to_string(ca.side[1].rest) + " bases";
                 return FFH_E_STATE;
             }

@@ -41,7 +41,6 @@ constexpr int FFH_KW = 1024;            // group words parked per wave
 constexpr int FFH_KC = 256;             // candidates parked per wave
 constexpr int FFH_STAGE = 256;          // staged hits per wave
 constexpr int FFH_WAVES_PER_SIMD = 4;   // launch bound (four blocks of four waves per CU: LDS-limited)
-constexpr int FFH_QUEUE_CHUNK = 16;     // work entries a wave draws from its queue at a time (8: 1.07, 16 / 32: 1.06 ms per launch)
 constexpr int FFH_GPL = 6;              // groups per job of a large bucket, about
 constexpr int FFH_PIPE_TRIPS = 2;       // 16-byte pieces of a group's words requested one group ahead (more cost registers)
 constexpr int FFH_MAX_ENTRY_WORK = 2048;   // group tests per work entry of a heavy bucket, at most
@@ -58,7 +57,9 @@ constexpr int kMaxParts = 16;             // jobs per candidate at most (park: f
 constexpr int kMinRest = 7, kMaxRest = 12;   // rest-key widths k_compare has a row form for (19-mers with a 12-base bucket key: 7)
 
 constexpr uint32_t kStatPairs = 4, kStatEntries = 6, kQueue = 32, kQueues = 16;   // cursor[32 + 16 side + k]: the side's k-th work queue (chunks drawn so far)
-constexpr uint32_t kQueueChunk = FFH_QUEUE_CHUNK;   // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
+// cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
+constexpr uint32_t kQueueChunkLong = 16, kQueueChunkMedium = 4;   // work entries a wave draws from its queue at a time (long lists: 8: 1.07, 16 / 32: 1.06 ms per launch;
+                                                                  // the medium-length lists of a bounded scan's slabs: 4)
 
 __host__ __device__ constexpr int group_words(int rest) { return (2 * rest + 1 + 3) & ~3; }   // words per group of 32 targets (16-byte multiple)
 
@@ -463,8 +464,9 @@ __global__ __launch_bounds__(256) void k_work_fill(const uint32_t *__restrict__ 
 // R0 / R1: the rest widths of the prefix / suffix image this instance is compiled for (the row forms are fixed and the kernel's
 // registers are those of max(R0, R1)).  FAR1: r1 + 1 of the suffix image when the instance is compiled for it (scan_row), -1 = read
 // from the arguments.  The host picks the instance (launch_compare).
-// QUEUE: the work entries are dealt through queues (long lists); else a fixed stride (the host decides: launch_compare)
-template <int R0, int R1, int FAR1, bool QUEUE>
+// QC: the work entries are dealt through queues in chunks of QC (16 for long lists, 4 for medium ones); 0: a fixed stride (the host
+// decides from the list lengths it expects: launch_compare)
+template <int R0, int R1, int FAR1, int QC>
 __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(const CompareArgs A, unsigned long long *__restrict__ cursor) {
     __shared__ WaveLds lds_all[kCmpWaves];
     const uint32_t lane = threadIdx.x & 63;
@@ -485,10 +487,10 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         const uint32_t n_total = min(*S.n_list, S.list_cap);
         // The order in which a wave takes work entries.  Entries differ in weight (buckets differ in size, a repeat family's rows are
         // full of hits), and with a fixed stride the launch ended when its unluckiest wave did: 22 % after the mean wave at hg38 scale,
-        // 2 .. 6 x the mean on the repeat-structured workload.  So the entries are dealt in chunks of kQueueChunk: chunk t stands for
+        // 2 .. 6 x the mean on the repeat-structured workload.  So the entries are dealt in chunks of QC: chunk t stands for
         // the entries t, t + C, t + 2 C, ... (C = number of chunks: the pieces of one heavy bucket, neighbours in the list, go to
         // different waves), a wave's first chunk is its own number, every further one the next ticket of its queue -- one atomic with
-        // its round trip per kQueueChunk entries, drawn where the wave has nothing in flight that it could not wait for.  kQueues
+        // its round trip per QC entries, drawn where the wave has nothing in flight that it could not wait for.  kQueues
         // queues per side, each with its share of the waves and of the chunks: same-address atomics complete at ~90 per microsecond
         // on this part, and one queue for 4096 waves made the draws themselves the bottleneck (chunks of 4: 1.98 ms per launch
         // against 1.14 with the fixed stride).
@@ -497,15 +499,16 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         // (a list with fewer than two chunks per wave -- a small database, a bin shard, the slabs of a bounded scan -- keeps the fixed
         // stride: chunks of 16 would leave most waves without work, and smaller chunks mean a draw, with its exposed round trip,
         // per entry or two: measured 0.46 against 0.29 ms per step at chr22 scale, 0.39 against 0.25 ms per launch on an eighth
-        // of hg38.  The host picks the instance from the list lengths it expects; decided in here, per side at run time, the
-        // queue's gain at hg38 scale was gone -- 1.13 against 1.05 ms per launch.)
-        constexpr uint32_t chunk_len = kQueueChunk ? kQueueChunk : 1u;
+        // of hg38.  Lists in between -- the slabs of a bounded scan on a genome-scale database -- take chunks of 4 (9.24 against 9.48 ms
+        // per step of the repeat-structured workload).  The host picks the instance from the list lengths it expects; decided in here,
+        // per side at run time, the queue's gain at hg38 scale was gone -- 1.13 against 1.05 ms per launch.)
+        constexpr uint32_t chunk_len = QC ? (uint32_t)QC : 1u;
         const uint32_t n_waves = gridDim.x * kCmpWaves;
         const uint32_t n_chunks = (n_total + chunk_len - 1u) / chunk_len;
         uint32_t chunk = blockIdx.x * kCmpWaves + wave, chunk_j = 0, stride_q = chunk;
         const uint32_t n_queues = min(kQueues, gridDim.x), my_queue = blockIdx.x % n_queues;   // (every queue has a block that draws from it)
         auto next_q = [&]() -> uint32_t {   // uniform
-            if constexpr (!QUEUE || kQueueChunk == 0) { const uint32_t r = stride_q < n_total ? stride_q : kEnd; stride_q += n_waves; return r; }
+            if constexpr (QC == 0) { const uint32_t r = stride_q < n_total ? stride_q : kEnd; stride_q += n_waves; return r; }
             if (chunk_j == chunk_len) {
                 uint32_t t = 0;
                 if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(cursor + kQueue + side * kQueues + my_queue, 1ull);
@@ -755,20 +758,21 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
 // the row form per row with a switch: its registers were the widest form's plus the switch's, 107 scalar and 8 vector registers
 // spilled -- every small database, every 19-mer and Cpf1 scan ran on it.)
 template <int R0, int R1, int FAR1>
-inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool queue) {
-    if (queue) hipLaunchKernelGGL((k_compare<R0, R1, FAR1, true>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
-    else hipLaunchKernelGGL((k_compare<R0, R1, FAR1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+inline void launch_compare_as(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, int chunk) {
+    if (chunk >= (int)kQueueChunkLong) hipLaunchKernelGGL((k_compare<R0, R1, FAR1, (int)kQueueChunkLong>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+    else if (chunk > 0) hipLaunchKernelGGL((k_compare<R0, R1, FAR1, (int)kQueueChunkMedium>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+    else hipLaunchKernelGGL((k_compare<R0, R1, FAR1, 0>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
 template <int R0, int R1>
 inline void launch_compare_pair(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_compare<R0, R1, -1, false>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
+    hipLaunchKernelGGL((k_compare<R0, R1, -1, 0>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
-// long_lists: both images' work lists are expected to hold at least two queue chunks per wave (work_list_is_long).
+// chunk: the queue chunk both images' expected list lengths allow (work_list_chunk: two chunks per wave at least), 0 = fixed stride.
 // Returns false for a pair of rest widths no instance exists for (the host refuses such images when they are built).
-inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, bool long_lists) {
+inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, int chunk) {
     static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;   // tests: the per-pair instances for every plan
-    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0 / 1: never / always (tests; read per launch)
-    const bool queue = queue_env < 0 ? long_lists : queue_env != 0;
+    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0: never, 1 / 16: chunks of 16, 4: chunks of 4 (tests; read per launch)
+    const int queue = queue_env < 0 ? chunk : queue_env == 1 ? (int)kQueueChunkLong : queue_env;
     const bool two = ca.side[1].n_list != nullptr;
     const int r0 = (int)ca.side[0].rest, far = two ? ca.side[1].r_far + 1 : 0;
     int r1 = two ? (int)ca.side[1].rest : 0;
@@ -793,6 +797,9 @@ inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, un
         default: return false;
     }
 }
-inline bool work_list_is_long(double expected_entries, unsigned grid) { return kQueueChunk != 0 && expected_entries >= 2.0 * kQueueChunk * grid * kCmpWaves; }
+inline int work_list_chunk(double expected_entries, unsigned grid) {
+    const double waves = (double)grid * kCmpWaves;
+    return expected_entries >= 2.0 * kQueueChunkLong * waves ? (int)kQueueChunkLong : expected_entries >= 2.0 * kQueueChunkMedium * waves ? (int)kQueueChunkMedium : 0;
+}
 
 }  // namespace ffh

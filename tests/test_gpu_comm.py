@@ -143,3 +143,30 @@ def test_cli_devices_flag_goes_through_the_library_exchange(capi, case, tmp_path
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+def test_a_shard_that_was_not_scanned_fails_the_exchange_on_every_shard_instead_of_hanging(capi, case):
+    """a failing shard used to return before the collectives, leaving its peers inside them.  Now it takes part in the
+    all-gather with a status record and every shard's caller gets the error (here: the exchange-alone entry point with one of two
+    shards never scanned)."""
+    odb, targets, positions, guides, sizes = case
+    ctxs = []
+    try:
+        for lo, hi, plo, phi in shard_slices(targets, sizes, 2):
+            c = capi.Context(3)
+            c.load_soa(targets[lo:hi], positions[plo:phi])
+            ctxs.append(c)
+        ctxs[0].scan(guides, 4)
+        with capi.Comm.local(ctxs) as comm:
+            with pytest.raises(capi.FlashFryHipError) as e:
+                comm.exchange(len(guides), 40)
+            assert "shard 1" in str(e.value) and "not been scanned" in str(e.value)
+            ctxs[1].scan(guides, 4)              # ... and the communicator is still usable
+            summ = comm.exchange(len(guides), 40)
+        with capi.Context(3) as full_ctx:
+            full_ctx.load_soa(targets, positions)
+            full = full_ctx.discover(guides, 4, 40)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert np.array_equal(full.summaries["n_hits"], summ["n_hits"]) and np.array_equal(full.summaries["overflow"], summ["overflow"])

@@ -909,11 +909,13 @@ def test_work_list_that_outgrows_its_first_allocation_and_piled_up_candidates(ca
         assert int(got.summaries["overflow"].sum()) > 0
 
 
-def test_work_queues_of_the_compare_launch_on_short_lists(capi, oracle, monkeypatch):
-    """the queue instance of k_compare is picked for long work lists only (hg38 scale: the full-scale tests and the bench's own
-    verification run it); FFH_WORK_QUEUE=1 forces it here, where most waves find their queue empty after their first chunk and
-    the lists end inside a chunk -- every entry must still be taken exactly once"""
-    monkeypatch.setenv("FFH_WORK_QUEUE", "1")
+@pytest.mark.parametrize("chunk", ["1", "4"])
+def test_work_queues_of_the_compare_launch_on_short_lists(capi, oracle, monkeypatch, chunk):
+    """the queue instances of k_compare are picked for long work lists (chunks of 16: hg38 scale -- the full-scale tests and the bench's
+    own verification run it) and medium ones (chunks of 4: the slabs of a bounded scan at genome scale); FFH_WORK_QUEUE=1 / 4 forces
+    them here, where most waves find their queue empty after their first chunk and the lists end inside a chunk -- every entry must
+    still be taken exactly once"""
+    monkeypatch.setenv("FFH_WORK_QUEUE", chunk)
     for seed, n_t, n_g, mm in ((3, 250_000, 400, 4), (4, 70_000, 150, 3), (5, 300, 7, 5)):
         odb, t, p, g = make_case(oracle, n_t, n_g, enzyme=3, seed=seed)
         with capi.Context(3) as ctx:
@@ -928,3 +930,34 @@ def test_work_queues_of_the_compare_launch_on_short_lists(capi, oracle, monkeypa
         got, want = ctx.discover(g, 4, 300), odb.discover(g, 4, 300)
         assert_same_hits(got, want)
         assert_same_scores(oracle, 3, g, got, want)
+
+
+def test_repeated_scans_replay_the_captured_launch_sequence(capi, oracle):
+    """From the third scan of a kind on, a context replays the candidate-list / work-list launches as one captured graph (PrepGraph,
+    ffh_api.hip) -- while the guide COUNT, the plan, the images and the device buffers are unchanged.  The guides' CONTENT may change
+    (the graph holds pointers, not values), a different count or mismatch budget must fall back to plain launches and later be
+    captured on its own: every one of these calls against the oracle, and the first three answers again at the end."""
+    odb, t, p, g = make_case(oracle, 180_000, 300, enzyme=3, seed=91)
+    _, _, _, g2 = make_case(oracle, 1_000, 300, enzyme=3, seed=92)          # other guides, same count
+    g2 = np.concatenate([g[:40], g2[40:]])                                    # (some with hits in this database)
+    want = {}
+
+    def check(ctx, guides, mm, tag):
+        got = ctx.discover(guides, mm, 2000)
+        if tag not in want:
+            want[tag] = odb.discover(guides, mm, 2000)
+        assert_same_hits(got, want[tag])
+        return got
+
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for _ in range(4):                       # plain, plain (seen), captured, replayed
+            check(ctx, g, 4, "a")
+        for _ in range(2):
+            check(ctx, g2, 4, "b")               # replayed with other guides in the same buffer
+        check(ctx, g[:123], 4, "c")              # another count: plain launches
+        for _ in range(4):
+            check(ctx, g, 3, "d")                # another mismatch budget: its own capture
+        got = check(ctx, g, 4, "a")
+        again = check(ctx, g2, 4, "b")
+        assert got.n_hits > 0 and again.n_hits > 0

@@ -94,7 +94,7 @@ def test_compare_kernel_spills_no_registers():
     import re
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kres.sh"), "k_compare<"], capture_output=True, text=True, timeout=600).stdout
     rows = [l for l in out.splitlines() if "k_compare<" in l]
-    assert len(rows) >= 17, out
+    assert len(rows) >= 20, out
     for l in rows:
         sp = [int(x) for x in re.findall(r"spilled +(\d+)", l)]
         assert sp == [0, 0], l
