@@ -111,6 +111,17 @@ VALU_CYCLES_FULL_RATE = 2.8
 VALU_CYCLES_HALF_RATE = 4.4
 
 
+def epilogue_roofline(raw_hits, ms):
+    """the second kernel of the step, priced by the 128-byte line every gathered target long costs + the 8-byte key.  None when the
+    step's epilogue was not timed on its own (the sharded step: it runs inside ffh_discover_sharded)."""
+    if not ms or ms <= 0 or not raw_hits:
+        return None
+    gbps = 136 * raw_hits / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ffh::k_guide_epilogue", "launch_ms": ms, "algorithmic_bytes_per_launch": 16 * raw_hits, "line_bytes_per_launch": 136 * raw_hits,
+            "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+            "note": "achieved counts the 128-byte line every gathered target long costs + the 8-byte key; by SURVEY 8d's 16 B per hit the fraction is 16/136 of this"}
+
+
 def pair_step_valu(rest_bases, far):
     """VALU instructions of one bit-sliced step (64 lanes x 32 targets = 2048 pair tests) with `rest_bases` bases outside the bucket
     id: two per base for the mismatch words, the carry-save adder tree (one v_bitop3 per sum / per carry), four for count <= budget,
@@ -693,11 +704,7 @@ def main():
                          "device_copy_GBps": stream_gbps, "frac_of_device_copy": achieved / stream_gbps if stream_gbps else None},
             # the second kernel of the step: one random 8-byte read of the target array per raw hit = one 128-byte line each (no cache
             # policy changes that: profiles/r03/gather_policy.txt, a bare gather of as many lines takes 0.22-0.26 ms on this part)
-            "roofline_epilogue": {"bound": "hbm", "kernel": "ffh::k_guide_epilogue", "launch_ms": float(np.mean([t["finalize_ms"] for t in tms])),
-                                  "algorithmic_bytes_per_launch": 16 * raw_hits, "line_bytes_per_launch": 136 * raw_hits,
-                                  "achieved": 136 * raw_hits / (float(np.mean([t["finalize_ms"] for t in tms])) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                  "frac": 136 * raw_hits / (float(np.mean([t["finalize_ms"] for t in tms])) * 1e-3) / 1e9 / 8000.0,
-                                  "note": "achieved counts the 128-byte line every gathered target long costs + the 8-byte key; by SURVEY 8d's 16 B per hit the fraction is 16/136 of this"},
+            "roofline_epilogue": epilogue_roofline(raw_hits, float(np.mean([t["finalize_ms"] for t in tms]))),
             "cpu_baseline": _CPU_JVM if (_CPU_JVM and _CPU_JVM.get("value")) else cpu,
             "cpu_baseline_port": cpu if (_CPU_JVM and _CPU_JVM.get("value")) else None,
             "cpu_baseline_all_cores": _CPU_MT,
