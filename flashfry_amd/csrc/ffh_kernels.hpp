@@ -365,14 +365,23 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint3
         for (uint32_t v = threadIdx.x; v < V; v += kPartThreads) {
             const uint32_t p = v / S, sl = v - p * S;
             const uint32_t pat = patterns[p], src = d ^ (pat >> ig.low_bits), plo = pat & lowmask;
-            const uint32_t k1 = gp_start[src + 1];
-            for (uint32_t k = gp_start[src] + sl; k < k1; k += S) {
-                const uint32_t rec = by_part[k], low = (rec >> kGidBits) ^ plo;
-                if (SLAB) {
-                    const uint32_t r = bucket_rank((d << ig.low_bits) | low, ig.width);
-                    if (r < ig.rank_lo || r > ig.rank_hi) continue;
+            const uint32_t k0 = gp_start[src], k1 = gp_start[src + 1];
+            // four records of the run per trip, requested together: the kernel is a chain of dependent L2 round trips (pattern -> run
+            // bounds -> records) at full occupancy, so what shortens it is loads in flight per thread, not more threads
+            for (uint32_t k = k0 + sl; k < k1; k += 4u * S) {
+                uint32_t rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rec[u] = k + (uint32_t)u * S < k1 ? by_part[k + (uint32_t)u * S] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k + (uint32_t)u * S >= k1) break;
+                    const uint32_t low = (rec[u] >> kGidBits) ^ plo;
+                    if (SLAB) {
+                        const uint32_t r = bucket_rank((d << ig.low_bits) | low, ig.width);
+                        if (r < ig.rank_lo || r > ig.rank_hi) continue;
+                    }
+                    fn(low, rec[u] & ((1u << kGidBits) - 1u));
                 }
-                fn(low, rec & ((1u << kGidBits) - 1u));
             }
         }
     };

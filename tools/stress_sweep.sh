@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/stress_sweep.sh <seconds> <workers per mode> [out dir]: the randomised parity sweep (tools/stress_parity.py) in both checker
+# tools/stress_sweep.sh <seconds> <workers per mode> [out dir] (SEED_BASE=4000: the workers' seeds are SEED_BASE + 100 k + mode): the randomised parity sweep (tools/stress_parity.py) in both checker
 # modes at once -- <workers> processes with the in-process oracle and <workers> with the oracle isolated in a process of its own, every
 # one with its own seed, sharing the box's GPU -- plus the replay of round 3's unexplained case (seed 99, from case 5165 on) in both
 # modes.  FFH_POOL_DEBUG=1 (canaries + poison on the page-locked result blocks) in all of them.  One summary at the end.
@@ -11,7 +11,7 @@ for mode in inproc isolated; do
   timeout $((secs + 900)) python tools/stress_parity.py 240 99 5165 --oracle $mode --quiet > $out/replay99_$mode.log 2>&1 &
   pids+=($!)
   for k in $(seq 1 $nw); do
-    seed=$((4000 + 100 * k + ( $( [ $mode = inproc ] && echo 1 || echo 2 ) )))
+    seed=$((${SEED_BASE:-4000} + 100 * k + ( $( [ $mode = inproc ] && echo 1 || echo 2 ) )))
     timeout $((secs + 900)) python tools/stress_parity.py $secs $seed --oracle $mode --quiet > $out/${mode}_$seed.log 2>&1 &
     pids+=($!)
   done
