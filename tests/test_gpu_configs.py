@@ -77,14 +77,22 @@ def test_config_c1_one_guide_vs_chr22_scale(capi, oracle, chr22):
     assert_same_scores(oracle, 3, g, gpu, ora)
 
 
-def test_randomised_parity_slice(capi, oracle):
+@pytest.mark.parametrize("checker", ["inproc", "isolated"])
+def test_randomised_parity_slice(capi, oracle, checker, monkeypatch):
     """tools/stress_parity.py for a bounded time: seeds x database sizes x guide counts x 0-6 mismatches x cut-offs x ALL SIX
-    packs (every third case walks through the enzymes 1 .. 6 in turn)"""
+    packs (every third case walks through the enzymes 1 .. 6 in turn).  Once with the oracle in this process and once with it in a
+    process of its own that never loads HIP (tests/oracle_proc.py: nothing the library does to host memory can reach that checker);
+    the library's page-locked result blocks carry canaries and poison meanwhile (FFH_POOL_DEBUG, ffh_debug_pool_errors)."""
     from tests.test_gpu_parity import dense_case
     from tests.helpers import make_enzyme_case
-    rng = np.random.default_rng(20260928)
+    monkeypatch.setenv("FFH_POOL_DEBUG", "1")   # (read once per process: effective when this is the first test to create a result)
+    if checker == "isolated":
+        from tests import oracle_proc
+        oracle = oracle_proc.RemoteOracle()
+    rng = np.random.default_rng(20260928 if checker == "inproc" else 20260929)
     t0, n, seen = time.time(), 0, set()
-    while time.time() - t0 < 60.0 or len(seen) < 6:
+    budget = 60.0 if checker == "inproc" else 30.0
+    while time.time() - t0 < budget or len(seen) < 6:
         seed = int(rng.integers(0, 1 << 30))
         max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
         max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
@@ -106,10 +114,13 @@ def test_randomised_parity_slice(capi, oracle):
             assert only.summaries.tobytes() == gpu.summaries.tobytes()
         ora = odb.discover(g, max_mm, max_ot)
         assert_same_hits(gpu, ora)
+        if checker == "isolated":
+            oracle.prefetch(enz, g, ora)
         assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
         seen.add(enz)
         n += 1
-    assert n >= 20 and seen == {1, 2, 3, 4, 5, 6}, "the slice should get through a few dozen cases in a minute (%d, enzymes %s)" % (n, sorted(seen))
+    assert capi.load_library().ffh_debug_pool_errors() == 0
+    assert n >= 12 and seen == {1, 2, 3, 4, 5, 6}, "the slice should get through a few dozen cases in a minute (%d, enzymes %s)" % (n, sorted(seen))
 
 
 _RAW_UNBOUNDED = {}   # raw hits of the unbounded runs of the repeat-genome test (the parametrisation runs bounding 0 first)
