@@ -274,9 +274,13 @@ int ffh_finalize_shard_fixup(ffh_ctx *ctx, int max_offtargets, unsigned flags, c
 
 /* ---------------------------------------------------------------------------------------------------------
  * The bin-sharded discover as ONE library call (BASELINE.json configs[3]): every shard scans all
- * guides, then the shards exchange (1) their per-guide position totals (all-gather) so that the ordered cut-off of
- * CRISPRSiteOT.addOT / full (crispr/CRISPRSiteOT.scala:39-46) continues across shards in database order and (2) the
- * per-guide aggregates (all-reduce MAX, all-reduce SUM, all-gather of the f64 sums, added in shard order).  The collectives
+ * guides and aggregates them as if it were the first shard, then ONE all-gather moves every shard's 88-byte per-guide aggregates
+ * (which hold its saturated position totals) to every rank and each rank folds them in shard order itself: the running totals are
+ * every shard's prior, so that the ordered cut-off of CRISPRSiteOT.addOT / full (crispr/CRISPRSiteOT.scala:39-46) continues across
+ * shards in database order; integer lanes add, maxima and the closest hit reduce, the f64 sums are added in shard order.  Only a
+ * guide whose cut-off falls inside a shard that has a non-zero prior makes that shard aggregate it again (a second all-gather;
+ * never taken by a guide set without OVERFLOW guides).  A shard that could not be scanned takes part with a status record: every
+ * rank returns the error, none is left inside a collective.  The collectives
  * are issued BY THE LIBRARY on the contexts' streams -- RCCL over xGMI (librccl is opened on first use) -- so a JVM host
  * (GPUTraverser) or the C++ CLI gets the reduce without any framework above the C ABI.  Replaces, for N GPUs, the one
  * traverser chosen in modules/OffTargetDiscovery.scala:119-135.
