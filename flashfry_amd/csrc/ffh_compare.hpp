@@ -171,7 +171,7 @@ struct alignas(16) WaveLds {
 };
 
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
-constexpr uint32_t kChunkMax = 8192;   // hit-buffer slots a wave reserves at a time, at most
+constexpr uint32_t kChunkMin = 512, kChunkMax = 8192;   // hit-buffer slots a wave reserves at a time from its second flush on: at least, at most
 struct HitStage {
     WaveLds *W;              // W->stage: this wave's staged hits, guide of this batch << 32 | side << 31 | slot in the side's image
     uint32_t fill;
@@ -199,11 +199,15 @@ struct HitStage {
         const uint32_t old_left = chunk_left;
         unsigned long long new_pos = 0;
         if (fill > old_left) {
-            // a wave with few hits (the usual <= 4-mismatch scan: ~3000 per wave) reserves exactly what it holds -- no padding, an
-            // atomic per flush is harmless there; past 4096 hits it reserves an eighth of what it has produced so far (at most
-            // kChunkMax): the padding left at the end stays ~6 % of its hits, the number of atomics logarithmic in them
+            // Every reservation is an atomic on the ONE hit cursor, and same-address atomics complete at ~90 per microsecond on this
+            // part: at hg38 scale (4096 waves x ~2800 hits, a flush per ~190) reserving exactly what a flush holds kept the cursor busy
+            // two thirds of the launch (1.015 -> 0.945 ms with chunks of 512; the repeat-structured workload's compare 4.1 -> 2.7 ms:
+            // profiles/r04/ab_log.txt 15).  So: a wave's FIRST flush reserves exactly what it holds (a wave of a small scan flushes once,
+            // at its end: no padding, the hit buffer of a chr22-scale call stays a few thousand keys), every further one at least
+            // kChunkMin slots, and past 4096 hits an eighth of what the wave has produced so far (at most kChunkMax): the padding left
+            // at the end stays a few per cent of the hits, the number of atomics per wave small.
             const uint32_t need = fill - old_left;
-            const uint32_t want = n_real < 4096 ? need : max(min((uint32_t)(n_real >> 3), kChunkMax), need);
+            const uint32_t want = n_real == 0u ? need : n_real < 4096u ? max(need, kChunkMin) : max(min(n_real >> 3, kChunkMax), need);
             if (lane == 0) new_pos = atomicAdd(cursor, (unsigned long long)want);
             new_pos = ((unsigned long long)uni((uint32_t)(new_pos >> 32)) << 32) | uni((uint32_t)new_pos);
             chunk_pos = new_pos + (fill - old_left);
