@@ -1245,10 +1245,15 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                 const uint64_t epoch = g_alloc_epoch.load();
                 bool done = false;
                 if (eligible && pg.exec && pg.epoch == epoch && !std::memcmp(pg.key, key, sizeof key)) {
-                    FFH_HIP(hipGraphLaunch(pg.exec, st));
-                    ca.side[0] = pg.side[0]; ca.side[1] = pg.side[1]; expect[0] = pg.expect[0]; expect[1] = pg.expect[1];
-                    ctx->n_part[0] = pg.n_part[0]; ctx->n_part[1] = pg.n_part[1];
-                    done = true;
+                    if (hipGraphLaunch(pg.exec, st) == hipSuccess) {
+                        ca.side[0] = pg.side[0]; ca.side[1] = pg.side[1]; expect[0] = pg.expect[0]; expect[1] = pg.expect[1];
+                        ctx->n_part[0] = pg.n_part[0]; ctx->n_part[1] = pg.n_part[1];
+                        done = true;
+                    } else {   // (a replay that cannot be launched: forget the graph, the plain launches below do the work)
+                        (void)hipGetLastError();
+                        (void)hipGraphExecDestroy(pg.exec);
+                        pg.exec = nullptr;
+                    }
                 } else if (eligible && pg.seen_epoch == epoch && !std::memcmp(pg.seen, key, sizeof key)) {
                     if (pg.exec) { (void)hipGraphExecDestroy(pg.exec); pg.exec = nullptr; }
                     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
