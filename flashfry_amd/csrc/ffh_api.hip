@@ -46,10 +46,9 @@ void set_global_error(const std::string &m) { g_create_error = m; }
 
 namespace {
 
-// Every (re)allocation and release of a device buffer, and every new database, moves the epoch on: a captured launch sequence
-// (PrepGraph) holds raw pointers and is only replayed while nothing it could refer to has moved.  While a sequence is being captured
-// on this thread an allocation is refused instead (hipMalloc is not capturable): the caller then runs the sequence uncaptured.
-static std::atomic<uint64_t> g_alloc_epoch{1};
+// A captured launch sequence (PrepGraph) holds raw pointers: it is only replayed while every buffer it refers to is where it was
+// (prep_signature: address and capacity of each, per context).  While a sequence is being captured on this thread an allocation is
+// refused (hipMalloc is not capturable): the caller then runs the sequence uncaptured.
 static thread_local bool t_capturing = false;
 
 template <typename T>
@@ -68,7 +67,6 @@ struct DevBuf {  // device allocation that grows on demand and frees itself (on 
     hipError_t reserve(size_t n) {  // contents are NOT preserved
         if (n <= cap) return hipSuccess;
         if (t_capturing) return hipErrorStreamCaptureUnsupported;
-        g_alloc_epoch.fetch_add(1);
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = n + n / 8 + 64;
@@ -77,7 +75,7 @@ struct DevBuf {  // device allocation that grows on demand and frees itself (on 
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) { (void)hipFree(p); g_alloc_epoch.fetch_add(1); } p = nullptr; cap = 0; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
 struct Image {  // one bucketed scan image of the database
@@ -277,6 +275,8 @@ struct ffh_ctx {
     DevBuf<unsigned long long> part_pairs[2];  // per candidate partition: targets x candidates of its buckets (k_item_bin)
     uint32_t n_part[2] = {0, 0};
     std::pair<int, int> patterns_key[2] = {{-1, -1}, {-1, -1}};  // (width, radius) of the pattern list resident in patterns[side]
+    uint64_t db_gen = 0;        // moves on with every database load
+    uint64_t pattern_gen = 0;   // moves on with every pattern upload: a captured launch sequence reads patterns[side] and must not outlive its content
     DevBuf<uint32_t> icount, ifill, item_gid, scan_tmp32;
     // candidate binning and work list of one image
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
@@ -307,11 +307,11 @@ struct ffh_ctx {
 
     // The candidate-list / work-list kernels of a scan (~26 launches of a few microseconds each: the host cannot issue them as fast
     // as the device runs them) as ONE captured graph, replayed while the call is the same in everything the launches depend on -- guide
-    // buffer and count, plan, images, buffers (g_alloc_epoch).  The first call of a kind runs uncaptured (it may allocate), the second
+    // buffer and count, plan, images, buffers (prep_signature), database and pattern generation.  The first call of a kind runs uncaptured (it may allocate), the second
     // captures, the following ones replay.  Work, results and counters are those of the plain launches; FFH_GRAPH=0 switches it off.
     struct PrepGraph {
         hipGraphExec_t exec = nullptr;
-        uint64_t key[12] = {}, seen[12] = {}, epoch = 0, seen_epoch = 0;
+        uint64_t key[13] = {}, seen[13] = {}, epoch = 0, seen_epoch = 0;
         SideArgs side[2];
         double expect[2] = {0, 0};
         uint32_t n_part[2] = {0, 0};
@@ -470,7 +470,7 @@ static int build_image(ffh_ctx *ctx, int which, int width) { return build_image_
 // targets/positions are already on the device in ctx->targets / ctx->positions
 static int prepare_database(ffh_ctx *ctx) {
     if (ctx->T >= (1ull << 31) - 64) { ctx->err = "more than 2^31 targets in one shard; split the bins across more GPUs"; return FFH_E_ARG; }
-    g_alloc_epoch.fetch_add(1);   // (a new database: nothing captured against the old one may be replayed)
+    ++ctx->db_gen;   // (a new database: nothing captured against the old one may be replayed)
     FFH_HIP(hipEventRecord(ctx->ev[0], ctx->st));
     // counts -> position offsets; validate counts like BlockManager.scala:232-236
     FFH_HIP(ctx->out_cnt.reserve(ctx->T + 1));
@@ -535,6 +535,7 @@ static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im
         FFH_HIP(patterns.reserve(np));
         FFH_HIP(hipMemcpyAsync(patterns.p, pat.data(), (size_t)np * 4, hipMemcpyHostToDevice, st));
         ctx->patterns_key[which] = std::make_pair(width, std::min(radius, width));
+        ++ctx->pattern_gen;
     }
     FFH_HIP(gbucket.reserve(ng));
     FFH_HIP(ctx->gtab[which].reserve((size_t)ng + 64));
@@ -1091,6 +1092,30 @@ static int select_images(ffh_ctx *ctx, int max_mm) {
     return FFH_OK;
 }
 
+// Address and capacity of every device buffer the candidate-list / work-list launches of a scan read or write (prepare_side, side_plan
+// and the SideArgs they fill), folded into one word: a captured sequence is replayed only while this is what it was when the sequence
+// was captured.  Per context: another context's allocations (another shard's thread, a finalize buffer that grows) do not touch it.
+static uint64_t prep_signature(const ffh_ctx *ctx, const Image &suffix) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ctx->db_gen;
+    auto mix = [&](const void *p, size_t cap) {
+        h ^= (uint64_t)(uintptr_t)p + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h ^= (uint64_t)cap + 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    };
+    mix(ctx->guides.p, ctx->guides.cap); mix(ctx->seg_begin.p, ctx->seg_begin.cap); mix(ctx->seg_end.p, ctx->seg_end.cap);
+    mix(ctx->item_gid.p, ctx->item_gid.cap);
+    for (int w = 0; w < 2; ++w) {
+        mix(ctx->gtab[w].p, ctx->gtab[w].cap); mix(ctx->gbucket[w].p, ctx->gbucket[w].cap); mix(ctx->patterns[w].p, ctx->patterns[w].cap);
+        mix(ctx->istart[w].p, ctx->istart[w].cap); mix(ctx->part_pairs[w].p, ctx->part_pairs[w].cap);
+        const ffh_ctx::SideScratch &sc = ctx->side_scr[w];
+        mix(sc.part_fill.p, sc.part_fill.cap); mix(sc.part_hist.p, sc.part_hist.cap); mix(sc.part_start.p, sc.part_start.cap);
+        mix(sc.gp_start.p, sc.gp_start.cap); mix(sc.by_part.p, sc.by_part.cap); mix(sc.scan_tmp.p, sc.scan_tmp.cap);
+        mix(ctx->wl_count[w].p, ctx->wl_count[w].cap); mix(ctx->wl_off[w].p, ctx->wl_off[w].cap); mix(ctx->wl_list[w].p, ctx->wl_list[w].cap);
+        const Image &im = w == 0 ? ctx->img[0] : suffix;
+        mix(im.bstart.p, im.bstart.cap); mix(im.gstart.p, im.gstart.cap); mix(im.gwords.p, im.gwords.cap); mix(im.tidx.p, im.tidx.cap); mix(im.live.p, im.live.cap);
+    }
+    return h | 1ull;   // (never 0: the value of "nothing seen yet")
+}
+
 // bound_ot > 0: the caller will not ask for more than bound_ot positions per guide (maximumOffTargets), so a guide whose positions
 // reach it in the slabs scanned so far is retired from the later ones
 static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm, uint32_t bound_ot) {
@@ -1239,10 +1264,14 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                 static const bool graphs_on = !(getenv("FFH_GRAPH") && atoi(getenv("FFH_GRAPH")) == 0);
                 ffh_ctx::PrepGraph &pg = ctx->pg;
                 const bool eligible = graphs_on && !bounded && !ctx->borrowed && g0 == 0 && ng == n_guides && first_launch;
-                const uint64_t key[12] = {(uint64_t)(uintptr_t)(act_guides + g0), ng, (uint64_t)max_mm, (uint64_t)plan.a, (uint64_t)plan.r1, (uint64_t)(int64_t)plan.r2,
+                // (pattern_gen: the captured kernels read ctx->patterns[side], which prepare_side overwrites IN PLACE -- no reallocation, no
+                // epoch change -- when a scan with another (width, radius) comes in between: ADVICE r4.  A plain run that uploads moves
+                // the generation on, so only a run that found both lists resident can be followed by a capture, and a capture never
+                // contains the upload.)
+                const uint64_t key[13] = {(uint64_t)(uintptr_t)(act_guides + g0), ng, (uint64_t)max_mm, (uint64_t)plan.a, (uint64_t)plan.r1, (uint64_t)(int64_t)plan.r2,
                                           (uint64_t)(uintptr_t)ctx->img[0].gwords.p, (uint64_t)(uintptr_t)SL.suffix->gwords.p, ctx->compare_grid, (uint64_t)(uintptr_t)ctx->item_gid.p,
-                                          ctx->T, (uint64_t)(uintptr_t)ctx->seg_begin.p};
-                const uint64_t epoch = g_alloc_epoch.load();
+                                          ctx->T, (uint64_t)(uintptr_t)ctx->seg_begin.p, ctx->pattern_gen};
+                const uint64_t epoch = prep_signature(ctx, *SL.suffix);
                 bool done = false;
                 if (eligible && pg.exec && pg.epoch == epoch && !std::memcmp(pg.key, key, sizeof key)) {
                     if (hipGraphLaunch(pg.exec, st) == hipSuccess) {
@@ -1282,7 +1311,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                     const int rc = run_prepare();
                     if (rc) return rc;
                     std::memcpy(pg.seen, key, sizeof key);
-                    pg.seen_epoch = g_alloc_epoch.load();
+                    pg.seen_epoch = prep_signature(ctx, *SL.suffix);
                 }
             }
             FFH_HIP(hipEventRecord(ctx->ev[3], st));   // (prepare_ms: candidate lists and work lists; compare_ms: the compare launch alone)

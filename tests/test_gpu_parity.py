@@ -961,3 +961,35 @@ def test_repeated_scans_replay_the_captured_launch_sequence(capi, oracle):
         got = check(ctx, g, 4, "a")
         again = check(ctx, g2, 4, "b")
         assert got.n_hits > 0 and again.n_hits > 0
+
+
+def test_captured_sequence_is_not_replayed_over_another_budgets_patterns(capi, oracle):
+    """the captured launches read the context's pattern lists, which a scan with another mismatch budget overwrites in
+    place (smaller list, same allocation).  A, A, A, A (captured, replayed), B ONCE, A again must not replay A's graph over B's
+    patterns; the same with B as a bounded scan and as a batched scan (neither is ever captured itself)."""
+    odb, t, p, g = make_case(oracle, 180_000, 300, enzyme=3, seed=93)
+    want = {mm: odb.discover(g, mm, 2000) for mm in (2, 3, 4)}
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for _ in range(4):
+            assert_same_hits(ctx.discover(g, 4, 2000), want[4])
+        assert_same_hits(ctx.discover(g, 3, 2000), want[3])          # once: uploads the <= 3 patterns, captures nothing
+        for _ in range(4):
+            assert_same_hits(ctx.discover(g, 4, 2000), want[4])
+        ctx.set_bounding(1)
+        assert_same_hits(ctx.discover(g, 2, 2000), want[2])          # a bounded scan with a third budget
+        ctx.set_bounding(0)
+        for _ in range(4):
+            assert_same_hits(ctx.discover(g, 4, 2000), want[4])
+        os.environ["FFH_MAX_GUIDE_BATCH"] = "64"
+        try:
+            with capi.Context(3) as other:                               # (the batch limit is read when a context is created)
+                other.load_soa(t, p)
+                for _ in range(4):
+                    assert_same_hits(other.discover(g[:64], 4, 2000), odb.discover(g[:64], 4, 2000))
+                assert_same_hits(other.discover(g, 3, 2000), want[3])  # batched: five launches, never captured
+                for _ in range(3):
+                    assert_same_hits(other.discover(g[:64], 4, 2000), odb.discover(g[:64], 4, 2000))
+        finally:
+            del os.environ["FFH_MAX_GUIDE_BATCH"]
+        assert_same_hits(ctx.discover(g, 4, 2000), want[4])
