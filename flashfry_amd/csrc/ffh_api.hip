@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/flashfry_hip.h"
+#include "ffh_debug.hpp"
 #include "ffh_dbfile.hpp"
 #include "ffh_ingest.hpp"
 #include "ffh_inflate.hpp"
@@ -106,10 +107,6 @@ struct Evt {
 // handed out again and when the pool dies (a device or host write into a block nobody owns: a late DMA, a stale pointer).
 // ffh_debug_pool_errors() counts what the checks found.
 static std::atomic<unsigned long long> g_pool_errors{0};
-static bool pool_debug() {
-    static const bool on = std::getenv("FFH_POOL_DEBUG") && std::atoi(std::getenv("FFH_POOL_DEBUG")) == 1;
-    return on;
-}
 static bool all_bytes(const void *p, size_t n, unsigned char v) {
     const unsigned char *b = (const unsigned char *)p;
     for (size_t i = 0; i < n; ++i) if (b[i] != v) return false;
@@ -119,13 +116,13 @@ struct PinnedPool {
     static constexpr unsigned char kCanary = 0xA5, kPoison = 0xDB;
     std::mutex m;
     std::vector<std::pair<void *, size_t>> free_blocks;
+    bool debug = false;       // FFH_POOL_DEBUG (ffh_debug.hpp), set when the context is created
+    long limit_mb = 0;        // FFH_PINNED_LIMIT_MB: the most page-locked host memory ONE result block may take (page-locked memory is a
+                              // resource the host shares with everything else on the node); a result that needs more fails with
+                              // FFH_E_NOMEM instead of pinning it
+    bool pool_debug() const { return debug; }
     void *get(size_t bytes, size_t &cap) {
-        // FFH_PINNED_LIMIT_MB: the most page-locked host memory ONE result block may take (page-locked memory is a resource the host
-        // shares with everything else on the node); a result that needs more fails with FFH_E_NOMEM instead of pinning it
-        if (const char *lim = std::getenv("FFH_PINNED_LIMIT_MB")) {
-            const long long mb = std::atoll(lim);
-            if (mb > 0 && bytes > (size_t)mb << 20) return nullptr;
-        }
+        if (limit_mb > 0 && bytes > (size_t)limit_mb << 20) return nullptr;
         void *p = nullptr;
         {
             std::lock_guard<std::mutex> g(m);
@@ -160,7 +157,7 @@ struct PinnedPool {
         if (free_blocks.size() >= 6) { check_poison(free_blocks.front()); (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
         free_blocks.emplace_back(p, cap);
     }
-    static void check_poison(const std::pair<void *, size_t> &b) {
+    void check_poison(const std::pair<void *, size_t> &b) const {
         if (pool_debug() && !all_bytes(b.first, b.second, kPoison)) {
             g_pool_errors.fetch_add(1);
             fprintf(stderr, "[ffh pool debug] a released page-locked block (%zu bytes) was written to before it was freed\n", b.second);
@@ -251,6 +248,8 @@ struct ffh_ctx {
     unsigned compare_grid = 256 * 4;
     bool scan_timing_pending = false, finalize_timing_pending = false, hit_t_ready = false;
     uint32_t max_guide_batch = 0;  // 0 = as many guides per compare launch as the candidate list allows
+    Switches sw;                   // the environment switches, read once by ffh_create (ffh_debug.hpp)
+    bool too_many_hits = false;    // the last scan stopped at sw.raw_hit_limit raw hits: the caller splits the guide set (discover_split)
 
     // scan state
     DevBuf<uint64_t> guides;
@@ -420,8 +419,7 @@ static int build_image_into(ffh_ctx *ctx, Image &im, int which, int width, uint6
     DevBuf<uint32_t> &keys = ctx->tmp_keys, &tidx_in = ctx->tmp_tidx;   // the counting sort's output, bit-sliced below (shared by the two images:
                                                                          // allocating and freeing GB-sized buffers costs tens of ms each)
     // a prefix image over a 3'-PAM database in sequence order keeps its buckets in database order: no slot -> index array (k_bucket_first)
-    static const bool allow_direct = !(getenv("FFH_NO_DIRECT") && atoi(getenv("FFH_NO_DIRECT")) == 1);
-    im.direct = allow_direct && which == 0 && ctx->geo.c0 != 0 && ctx->db_sorted;
+    im.direct = !ctx->sw.no_direct && which == 0 && ctx->geo.c0 != 0 && ctx->db_sorted;
     FFH_HIP(im.bstart.reserve((size_t)nb + 1));
     FFH_HIP(im.gstart.reserve(2 * ((size_t)nb + 1)));   // (+ ddelta behind it)
     FFH_HIP(im.gwords.reserve((size_t)max_groups * GW + kKW + 64));
@@ -615,8 +613,7 @@ __global__ void k_publish(const unsigned long long *__restrict__ counters, volat
 // pageable host memory -- a stack variable -- is only known to have landed after a stream synchronisation, not when a later kernel's
 // store is seen (the number of guides still active after a slab was read that way; once in ~60 000 randomised cases it was stale).
 static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, nullable */, const uint32_t *word = nullptr, uint32_t *word_out = nullptr) {
-    static const bool no_spin = getenv("FFH_NO_SPIN") && atoi(getenv("FFH_NO_SPIN")) == 1;
-    if (no_spin || !ctx->h_pub) {
+    if (ctx->sw.no_spin || !ctx->h_pub) {
         if (out) { hipError_t e = hipMemcpyAsync(out, ctx->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->st); if (e != hipSuccess) return e; }
         if (word) { hipError_t e = hipMemcpyAsync(word_out, word, 4, hipMemcpyDeviceToHost, ctx->st); if (e != hipSuccess) return e; }
         return hipStreamSynchronize(ctx->st);
@@ -683,8 +680,10 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     if (!ctx) { g_create_error = "out of memory"; return nullptr; }
     ctx->device = device_id;
     if (enzyme_index) set_enzyme(ctx, enzyme_index);  // 0: taken from the database header by ffh_db_open / ffh_db_open_header
-    if (const char *e = std::getenv("FFH_COMPARE_GRID")) { const long v = std::atol(e); if (v > 0) ctx->compare_grid = (unsigned)v; }
-    if (const char *e = std::getenv("FFH_MAX_GUIDE_BATCH")) { const long v = std::atol(e); if (v > 0) ctx->max_guide_batch = (uint32_t)v; }
+    ctx->sw = Switches::from_env();
+    if (ctx->sw.compare_grid) ctx->compare_grid = ctx->sw.compare_grid;
+    ctx->max_guide_batch = ctx->sw.max_guide_batch;
+    ctx->pool->debug = ctx->sw.pool_debug; ctx->pool->limit_mb = ctx->sw.pinned_limit_mb;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_st, hipStreamNonBlocking);
     ctx->st = ctx->own_st;
@@ -880,8 +879,7 @@ int ffh_db_open(ffh_ctx *ctx, const char *db_path, uint32_t bin_begin, uint32_t 
     const int64_t *payload = nullptr;  // first long of bin_begin's payload
     size_t m0 = 0, m1 = 0;
     member_range(body, need_lo, need_hi, m0, m1);
-    const char *where = std::getenv("FFH_INFLATE");  // "host": inflate on the host threads instead of on the device
-    bool on_device = !(where && std::strcmp(where, "host") == 0) && m1 > m0;
+    bool on_device = !ctx->sw.inflate_host && m1 > m0;   // (FFH_INFLATE=host: inflate on the host threads instead of on the device)
     if (on_device && (need_lo - body.members[m0].uoff) % 8) on_device = false;  // the payload must stay 8-byte aligned inside the members' output
     ctx->load_device_inflate_ms = 0;
     if (on_device) {
@@ -1119,6 +1117,7 @@ static uint64_t prep_signature(const ffh_ctx *ctx, const Image &suffix) {
 // bound_ot > 0: the caller will not ask for more than bound_ot positions per guide (maximumOffTargets), so a guide whose positions
 // reach it in the slabs scanned so far is retired from the later ones
 static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mm, uint32_t bound_ot) {
+    if (ctx) ctx->too_many_hits = false;
     if (!ctx || (n_guides && !guides) || max_mm < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (ctx->img[0].width < 0) { ctx->err = "no database loaded"; return FFH_E_STATE; }
     FFH_HIP(hipSetDevice(ctx->device));
@@ -1185,8 +1184,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
         FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
         // (FFH_WORK_LIST_LIMIT: test aid -- a first list that small, so that the run-again path below is taken)
-        const char *lim = getenv("FFH_WORK_LIST_LIMIT");
-        FFH_HIP(ctx->wl_list[which].reserve(lim && atol(lim) > 0 ? std::min<size_t>((size_t)max_entries, (size_t)atol(lim)) : (size_t)max_entries));
+        FFH_HIP(ctx->wl_list[which].reserve(ctx->sw.work_list_limit > 0 ? std::min<size_t>((size_t)max_entries, (size_t)ctx->sw.work_list_limit) : (size_t)max_entries));
         FFH_HIP(ctx->side_scr[which].scan_tmp.reserve(scan_scratch_elems_safe(n_bat)));
         hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
                            ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u,
@@ -1216,8 +1214,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // work list; a retired guide is made unreachable in the guide table: k_bound_update) instead of enumerating it again, with a
     // counting pass, for every slab.  Needs the whole guide set in one batch and maxMismatch + r1 < prefix width (true of every
     // two-image plan the cost model picks); otherwise the prefix side is binned per slab on the packed active set.
-    const bool shared_prefix = bounded && n_guides <= batch && max_mm + plan.r1 < plan.a &&
-                               !(getenv("FFH_SLAB_PREFIX") && std::strcmp(getenv("FFH_SLAB_PREFIX"), "per-slab") == 0);
+    const bool shared_prefix = bounded && n_guides <= batch && max_mm + plan.r1 < plan.a && !ctx->sw.slab_prefix_per_slab;
     const uint64_t n_items_p_all = (uint64_t)n_guides * (uint64_t)np_p;
     // (Who is retired after a slab is decided on exact position totals: the slab's hits ordered by guide, their target longs
     // gathered, the counts added up, ~0.35 ms per slab.  Round 3 tried a cheaper lower bound -- the compare kernel adding up, per
@@ -1261,7 +1258,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                 return rc;
             };
             {
-                static const bool graphs_on = !(getenv("FFH_GRAPH") && atoi(getenv("FFH_GRAPH")) == 0);
+                const bool graphs_on = ctx->sw.graph;
                 ffh_ctx::PrepGraph &pg = ctx->pg;
                 const bool eligible = graphs_on && !bounded && !ctx->borrowed && g0 == 0 && ng == n_guides && first_launch;
                 // (pattern_gen: the captured kernels read ctx->patterns[side], which prepare_side overwrites IN PLACE -- no reallocation, no
@@ -1325,7 +1322,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             // queue's draws only cost (0.282 against 0.238 ms per launch)
             int chunk = plan.r2 < 0 ? work_list_chunk(expect[0], ctx->compare_grid) : std::min(work_list_chunk(expect[0], ctx->compare_grid), work_list_chunk(expect[1], ctx->compare_grid));
             if (!bounded && chunk < (int)kQueueChunkLong) chunk = 0;
-            if (!launch_compare(ca, ctx->d_counters, ctx->compare_grid, st, chunk)) {
+            if (!launch_compare(ca, ctx->d_counters, ctx->compare_grid, st, chunk, ctx->sw.generic_compare, ctx->sw.work_queue)) {
                 ctx->err = "no compare kernel for rest keys of " + std::to_string(ca.side[0].rest) + " + " + std::to_string(ca.side[1].rest) + " bases";
                 return FFH_E_STATE;
             }
@@ -1336,9 +1333,16 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             FFH_HIP(hipGetLastError());
             first_launch = false;
             const unsigned long long cursor = cnt[0];
-            // segments, sort offsets and the epilogue index hits with 32 bits: more raw hits than that in one shard is an error, not a
-            // silently wrong result (the bulge path has the same guard)
-            if (cursor >= (1ull << 32) - 64) { ctx->err = "more than 2^32 raw hits in one scan: lower maxMismatch, split the guide set, or shard the bins over more GPUs"; return FFH_E_ARG; }
+            // segments, sort offsets and the epilogue index hits with 32 bits: ONE scan never holds more raw hits than that.
+            // ffh_discover / ffh_discover_sharded / ffh_discover_bulge then bound the scan and, if that is not enough, split the guide set
+            // and merge the parts' results (discover_split): the reference is slow on such a guide set, not wrong
+            // (BlockManager.scala:212-254), so the library does not refuse it either.  A caller of the two-step ffh_scan / ffh_finalize
+            // gets this error and splits itself.
+            if (cursor >= ctx->sw.raw_hit_limit) {
+                ctx->too_many_hits = true;
+                ctx->err = "more than 2^32 raw hits in one scan: ffh_discover splits such a guide set by itself; with ffh_scan / ffh_finalize pass fewer guides per call";
+                return FFH_E_ARG;
+            }
             bool redo = false;
             if (cursor > ctx->hits.cap) {  // hit buffer too small: grow it and redo this batch (earlier batches are kept, copied device to device)
                 DevBuf<uint64_t> bigger;
@@ -1418,8 +1422,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
     // ---- order the hits by (guide, database index) ----
     // Two device-wide passes group them by guide, then one wave per guide orders its segment by ranking (ffh_prims.hpp: k_segsort;
     // guides inside repeat families go to k_segsort_heavy).  FFH_SORT=lsd keeps the six-pass LSD sort over all key bits (A/B).
-    const char *sort_env = getenv("FFH_SORT");   // "lsd" / "seg": force one of the two (A/B runs, tests of the heavy-segment path)
-    const bool full_lsd = sort_env && std::strcmp(sort_env, "lsd") == 0, force_seg = sort_env && std::strcmp(sort_env, "seg") == 0;
+    const bool full_lsd = ctx->sw.sort_mode == 1, force_seg = ctx->sw.sort_mode == 2;   // FFH_SORT: force one of the two (A/B runs, tests of the heavy-segment path)
     ctx->hits_sorted = ctx->hits.p;
     bool segments_done = false;
     if (ctx->n_raw && ctx->n_raw <= kSmallSort) {
@@ -1601,7 +1604,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         r->scores_valid = ctx->geo.cas9_23;
         // the kernel stores every summary into the result's page-locked block as well (hipHostMalloc memory is mapped into the
         // device's address space): the 88 bytes per guide cross the link under the kernel instead of in a copy after it
-        static const bool zero_copy = !(getenv("FFH_SUMMARY_COPY") && atoi(getenv("FFH_SUMMARY_COPY")) == 1);
+        const bool zero_copy = !ctx->sw.summary_copy;
         if (G) hipLaunchKernelGGL(k_guide_epilogue, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p,
                                   (const uint64_t *)(ctx->hit_t_ready ? ctx->hit_t.p : nullptr), (const uint64_t *)ctx->hits_sorted, (const uint64_t *)ctx->targets.p, ctx->tbits,
                                   d_prior, ctx->guides.p, ctx->geo,
@@ -1692,11 +1695,67 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
     return FFH_OK;
 }
 
-int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
-    if (max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+// ---- a scan the reference would finish is never refused -------------------------------------------------------------------------------
+// One scan holds fewer than 2^32 raw hits (32-bit segment arithmetic).  A guide set that collects more -- <= 5 or 6 mismatches on a
+// repeat-rich genome -- is first scanned BOUNDED (what the auto rule switches on after any scan with more than 2048 raw hits per guide:
+// guides that have reached maximumOffTargets are retired slab by slab, as the reference stops feeding a full guide,
+// crispr/ResultsAggregator.scala:61-69), and if that still overflows the guide set is halved, the halves are discovered one after the
+// other and their results concatenated (guides are independent of each other everywhere on the path).
+static int scan_retry_bounded(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets) {
     int rc = ffh_scan_bounded(ctx, guides, n_guides, max_mismatch, max_offtargets);
-    if (rc) return rc;
-    return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
+    if (rc && ctx && ctx->too_many_hits && !ctx->bound_mode && ctx->bound_auto && ctx->slabs_state >= 0 && max_offtargets > 0) {
+        ctx->bound_mode = 1;
+        rc = ffh_scan_bounded(ctx, guides, n_guides, max_mismatch, max_offtargets);
+    }
+    return rc;
+}
+static ffh_result *merge_results(ffh_ctx *ctx, const ffh_result *a, const ffh_result *b, unsigned flags) {
+    const bool lists = !(flags & FFH_FINALIZE_SUMMARIES_ONLY), want_pos = lists && !(flags & FFH_FINALIZE_NO_POSITIONS), want_cfd = lists && !(flags & FFH_FINALIZE_NO_HIT_SCORES);
+    const uint32_t Ga = a->n_guides, Gb = b->n_guides;
+    const uint64_t Ha = lists ? a->n_hits : 0, Hb = lists ? b->n_hits : 0;
+    ffh_result *r = new (std::nothrow) ffh_result();
+    if (!r || !r->allocate(ctx->pool, Ga + Gb, Ha + Hb, lists, want_cfd, want_pos) || (want_pos && !r->allocate_positions(a->n_positions + b->n_positions))) { delete r; return nullptr; }
+    r->scores_valid = a->scores_valid;
+    if (Ga) std::memcpy(r->summaries, a->summaries, (size_t)Ga * sizeof(ffh_guide_summary));
+    if (Gb) std::memcpy(r->summaries + Ga, b->summaries, (size_t)Gb * sizeof(ffh_guide_summary));
+    if (!lists) { r->offsets_pending = true; return r; }
+    std::memcpy(r->guide_offsets, a->guide_offsets, ((size_t)Ga + 1) * 8);
+    for (uint32_t g = 0; g <= Gb; ++g) r->guide_offsets[Ga + g] = Ha + b->guide_offsets[g];
+    auto cat = [&](auto *dst, const auto *pa, const auto *pb) {
+        if (!dst) return;
+        if (Ha) std::memcpy(dst, pa, (size_t)Ha * sizeof(*dst));
+        if (Hb) std::memcpy(dst + Ha, pb, (size_t)Hb * sizeof(*dst));
+    };
+    cat(r->hit_targets, a->hit_targets, b->hit_targets);
+    cat(r->hit_mm, a->hit_mm, b->hit_mm);
+    if (want_cfd) cat(r->hit_cfd, a->hit_cfd, b->hit_cfd);
+    if (want_pos) {
+        r->pos_offsets_pending = true;   // folded from the counts in the hit target longs when first asked for (settle_pos_offsets)
+        if (a->n_positions) std::memcpy(r->positions, a->positions, (size_t)a->n_positions * 8);
+        if (b->n_positions) std::memcpy(r->positions + a->n_positions, b->positions, (size_t)b->n_positions * 8);
+    }
+    return r;
+}
+static int discover_split(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
+    int rc = scan_retry_bounded(ctx, guides, n_guides, max_mismatch, max_offtargets);
+    if (!rc) return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
+    if (!ctx || !ctx->too_many_hits || n_guides < 2) return rc;
+    const uint32_t h = n_guides / 2;
+    ffh_result *a = nullptr, *b = nullptr;
+    rc = discover_split(ctx, guides, h, max_mismatch, max_offtargets, flags, &a);
+    if (!rc) rc = discover_split(ctx, guides + h, n_guides - h, max_mismatch, max_offtargets, flags, &b);
+    if (!rc) {
+        *out = merge_results(ctx, a, b, flags);
+        if (!*out) { ctx->err = "out of (pinned) host memory"; rc = FFH_E_NOMEM; }
+        else ctx->err.clear();
+    }
+    delete a; delete b;
+    return rc;
+}
+
+int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
+    if (max_offtargets < 0 || !out) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    return discover_split(ctx, guides, n_guides, max_mismatch, max_offtargets, flags, out);
 }
 
 int ffh_score_lists(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, const uint64_t *guide_offsets, const uint64_t *hit_targets, ffh_result **out) {
@@ -2002,7 +2061,35 @@ struct ffh_bulge_result {
 
 extern "C" {
 
+static int bulge_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_bulge, unsigned flags, ffh_bulge_result **out);
+// (more candidate records than one search holds: the guide set is halved and the halves' results are concatenated, as ffh_discover does)
 int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_bulge, unsigned flags, ffh_bulge_result **out) {
+    if (!ctx || !out) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
+    ctx->too_many_hits = false;
+    int rc = bulge_impl(ctx, guides, n_guides, max_mismatch, max_bulge, flags, out);
+    if (!rc || !ctx->too_many_hits || n_guides < 2) return rc;
+    const uint32_t h = n_guides / 2;
+    ffh_bulge_result *a = nullptr, *b = nullptr;
+    rc = ffh_discover_bulge(ctx, guides, h, max_mismatch, max_bulge, flags, &a);
+    if (!rc) rc = ffh_discover_bulge(ctx, guides + h, n_guides - h, max_mismatch, max_bulge, flags, &b);
+    if (!rc) {
+        try {
+            const uint64_t Ha = a->hit_targets.size();
+            a->n_guides = n_guides;
+            a->guide_offsets.reserve((size_t)n_guides + 1);
+            for (uint32_t g = 1; g <= n_guides - h; ++g) a->guide_offsets.push_back(Ha + b->guide_offsets[g]);
+            a->hit_targets.insert(a->hit_targets.end(), b->hit_targets.begin(), b->hit_targets.end());
+            a->hit_mm.insert(a->hit_mm.end(), b->hit_mm.begin(), b->hit_mm.end());
+            a->hit_type.insert(a->hit_type.end(), b->hit_type.begin(), b->hit_type.end());
+            a->hit_pos.insert(a->hit_pos.end(), b->hit_pos.begin(), b->hit_pos.end());
+            *out = a; a = nullptr;
+            ctx->err.clear();
+        } catch (const std::bad_alloc &) { ctx->err = "out of host memory"; rc = FFH_E_NOMEM; }
+    }
+    delete a; delete b;
+    return rc;
+}
+static int bulge_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_bulge, unsigned flags, ffh_bulge_result **out) {
     if (!ctx || !out || (n_guides && !guides) || max_mismatch < 0 || max_bulge < 0 || max_bulge > 1) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (ctx->img[0].width < 0) { ctx->err = "no database loaded"; return FFH_E_STATE; }
     if (ctx->enzyme != 1) { ctx->err = "the bulge search is specified for Cas12a / Cpf1 (enzyme index 1) only"; return FFH_E_ARG; }
@@ -2080,12 +2167,16 @@ int ffh_discover_bulge(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, 
             unsigned long long found = 0;
             FFH_HIP(hipMemcpyAsync(&found, cursor, 8, hipMemcpyDeviceToHost, st));
             FFH_HIP(hipStreamSynchronize(st));
+            if (found >= ctx->sw.raw_hit_limit) {   // (sort offsets are 32-bit: ffh_discover_bulge splits the guide set)
+                ctx->too_many_hits = true;
+                ctx->err = "more than 2^32 bulge candidate records in one search";
+                return FFH_E_ARG;
+            }
             if (found <= cap) { n_hits = found; break; }
             cap = (size_t)(found + found / 8);  // the buffer was too small: grow to what the scan found and run it again
         }
     }
     if (n_hits) {
-        if (n_hits >= (1ull << 32) - 64) { ctx->err = "more than 2^32 bulge hits"; return FFH_E_ARG; }
         const uint32_t nb = sort_nblocks(n_hits);
         FFH_HIP(alt_k.reserve(n_hits)); FFH_HIP(alt_v.reserve(n_hits));
         FFH_HIP(table.reserve((size_t)kSortTableDigits * nb + 8)); FFH_HIP(offs.reserve((size_t)kSortTableDigits * nb + 8));

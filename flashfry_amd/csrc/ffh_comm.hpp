@@ -80,13 +80,17 @@ static RcclApi *rccl_api() {   // nullptr-safe: check ->lib
 //     round, adjusted = 1, folds the corrected records as they are.  A guide set without OVERFLOW guides (the benchmark's) never
 //     needs the second round: one collective per step.
 // Integer lanes add, overflow / cfd_max / jost_max take the maximum, the closest hit the minimum with its count summed over the
-// shards at that level, the f64 sums are added in shard order (deterministic).  flag[0] bit 31: a shard reported a failure.
+// shards at that level, the f64 sums are added in shard order (deterministic).  flag[0] bit 31: a shard reported a failure; bit 30: a
+// failure OTHER than "more raw hits than one scan holds" (status word kStatusTooManyHits), after which every rank halves the guide set.
+constexpr uint32_t kStatusTooManyHits = 0xFEFEFEFEu;   // (a status record is a memset: 0x00 fine, 0xFE this, 0xFF any other failure)
 __global__ void k_exchange_reduce(const GuideSummary *__restrict__ all /* [world][n + 1] */, uint32_t n, uint32_t world, uint32_t clamp, int adjusted, uint32_t me,
                                   uint32_t *__restrict__ prior_out /* [n]: prior of shard `me` (first round only) */, GuideSummary *__restrict__ red, uint32_t *__restrict__ flag) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g == 0)
-        for (uint32_t r = 0; r < world; ++r)
-            if (all[(size_t)r * (n + 1) + n].n_hits != 0u) atomicOr(flag, 0x80000000u);
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t status = all[(size_t)r * (n + 1) + n].n_hits;
+            if (status != 0u) atomicOr(flag, status == kStatusTooManyHits ? 0x80000000u : 0xC0000000u);
+        }
     if (g >= n) return;
     GuideSummary acc{};
     acc.closest = 0xFFFFFFFFu;
@@ -122,6 +126,7 @@ __global__ void k_exchange_reduce(const GuideSummary *__restrict__ all /* [world
 }  // namespace ffh
 
 enum { FFH_COMM_COPY = 0, FFH_COMM_ALL = 1, FFH_COMM_RANK = 2 };
+constexpr int kSplitGuides = -1000;   // internal: comm_exchange -> discover_sharded_split (never returned through the C ABI)
 
 struct ffh_comm {
     int mode = FFH_COMM_COPY;
@@ -346,7 +351,7 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
             FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, 0, sizeof(GuideSummary), cm->ctx[i]->st));
         } else {
             FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p, 0, (size_t)G * sizeof(GuideSummary), cm->ctx[i]->st));
-            FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, 0xFF, sizeof(GuideSummary), cm->ctx[i]->st));
+            FFC_HIP(hipMemsetAsync(cm->buf[i]->summ.p + G, cm->ctx[i]->too_many_hits ? 0xFE : 0xFF, sizeof(GuideSummary), cm->ctx[i]->st));
         }
     }
     int rc = gather();
@@ -360,7 +365,7 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
         for (size_t i = 0; i < L; ++i) { (void)hipSetDevice(cm->ctx[i]->device); (void)hipStreamSynchronize(cm->ctx[i]->st); }
         cm->err = "a shard could not be scanned";
         for (size_t i = 0; i < L; ++i) if (!ok[i]) cm->err = "shard " + std::to_string(cm->first + (int)i) + ": " + cm->ctx[i]->err;
-        return FFH_E_STATE;
+        return (word & 0x40000000u) ? FFH_E_STATE : kSplitGuides;
     }
     cm->crossing = word;
     if (word) {
@@ -379,8 +384,36 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
     return FFH_OK;
 }
 
+static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out);
+// A guide set that collects more raw hits than one scan holds on ANY shard: every rank learns it from the status records of the same
+// exchange, so every rank halves the guide set at the same place and runs the halves one after the other (no extra collective).  The
+// per-guide summaries of the halves are concatenated; hit lists and device summaries then belong to the last part only, so
+// ffh_comm_shard_lists / ffh_comm_device_summaries refuse until a call that was not split.
+static int discover_sharded_split(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out,
+                                  bool &split) {
+    int rc = discover_sharded_once(cm, guides, n_guides, max_mismatch, max_offtargets, flags, summaries_out);
+    if (rc != kSplitGuides) return rc;
+    if (n_guides < 2) return FFH_E_STATE;
+    split = true;
+    const uint32_t h = n_guides / 2;
+    const double scan0 = cm->scan_ms, ex0 = cm->exchange_ms;
+    rc = discover_sharded_split(cm, guides, h, max_mismatch, max_offtargets, flags, summaries_out, split);
+    const double scan1 = cm->scan_ms, ex1 = cm->exchange_ms;
+    if (!rc) rc = discover_sharded_split(cm, guides + h, n_guides - h, max_mismatch, max_offtargets, flags, summaries_out ? summaries_out + h : nullptr, split);
+    cm->scan_ms += scan0 + scan1; cm->exchange_ms += ex0 + ex1;
+    return rc;
+}
 int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
     if (!cm || (n_guides && !guides) || max_mismatch < 0 || max_offtargets < 0) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
+    bool split = false;
+    const int rc = discover_sharded_split(cm, guides, n_guides, max_mismatch, max_offtargets, flags, summaries_out, split);
+    if (!rc && split) {
+        cm->exchanged = false;
+        cm->err = "the guide set was split (more raw hits than one scan holds): hit lists and device summaries are per call -- pass fewer guides per ffh_discover_sharded";
+    }
+    return rc;
+}
+static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
     const size_t L = cm->ctx.size();
     cm->exchanged = false;
     const auto t0 = std::chrono::steady_clock::now();
@@ -388,7 +421,7 @@ int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides
     // would run the GPUs one after the other); each shard is bounded by its own totals (the prior of the lower shards could only
     // retire more guides)
     std::vector<int> rcs(L, FFH_OK);
-    auto scan = [&](size_t i) { rcs[i] = ffh_scan_bounded(cm->ctx[i], guides, n_guides, max_mismatch, max_offtargets); };
+    auto scan = [&](size_t i) { rcs[i] = scan_retry_bounded(cm->ctx[i], guides, n_guides, max_mismatch, max_offtargets); };
     if (L == 1) scan(0);
     else {
         std::vector<std::thread> th;
@@ -399,10 +432,10 @@ int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides
     // (a shard that could not be scanned still takes part in the exchange: the other ranks must not be left inside a collective)
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = comm_exchange(cm, n_guides, max_offtargets, flags, summaries_out, rcs.data());
-    if (rc) return rc;
-    cm->n_guides = n_guides; cm->max_ot = max_offtargets; cm->exchanged = true;
     cm->scan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     cm->exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    if (rc) return rc;
+    cm->n_guides = n_guides; cm->max_ot = max_offtargets; cm->exchanged = true;
     return FFH_OK;
 }
 
@@ -412,7 +445,7 @@ int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsig
     cm->exchanged = false;
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = comm_exchange(cm, n_guides, max_offtargets, flags, summaries_out);
-    if (rc) return rc;
+    if (rc) return rc == kSplitGuides ? FFH_E_STATE : rc;   // (the caller scanned the shards itself: it splits the guide set itself)
     cm->n_guides = n_guides; cm->max_ot = max_offtargets; cm->exchanged = true;
     cm->exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     return FFH_OK;
@@ -420,7 +453,7 @@ int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsig
 
 int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_result **out) {
     if (!cm || !out || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
-    if (!cm->exchanged) { cm->err = "ffh_discover_sharded has not run"; return FFH_E_STATE; }
+    if (!cm->exchanged) { if (cm->err.empty()) cm->err = "ffh_discover_sharded has not run"; return FFH_E_STATE; }
     ffh_ctx *ctx = cm->ctx[(size_t)local_shard];
     const int rc = ffh_finalize(ctx, cm->buf[(size_t)local_shard]->prior.p, cm->max_ot, (flags & ~FFH_FINALIZE_SUMMARIES_ONLY) | FFH_FINALIZE_PRIOR_ON_DEVICE, out);
     if (rc) { std::lock_guard<std::mutex> g(cm->err_m); cm->err = ctx->err; }

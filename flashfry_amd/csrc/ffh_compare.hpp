@@ -773,9 +773,9 @@ inline void launch_compare_pair(const CompareArgs &ca, unsigned long long *curso
 }
 // chunk: the queue chunk both images' expected list lengths allow (work_list_chunk: two chunks per wave at least), 0 = fixed stride.
 // Returns false for a pair of rest widths no instance exists for (the host refuses such images when they are built).
-inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, int chunk) {
-    static const bool generic_only = getenv("FFH_GENERIC_COMPARE") && atoi(getenv("FFH_GENERIC_COMPARE")) == 1;   // tests: the per-pair instances for every plan
-    const int queue_env = getenv("FFH_WORK_QUEUE") ? atoi(getenv("FFH_WORK_QUEUE")) : -1;   // 0: never, 1 / 16: chunks of 16, 4: chunks of 4 (tests; read per launch)
+// generic_only / queue_env: the context's FFH_GENERIC_COMPARE / FFH_WORK_QUEUE switches (ffh_debug.hpp; tests: the per-pair instances for
+// every plan; 0: never a queue, 1 / 16: chunks of 16, 4: chunks of 4, -1: by list length)
+inline bool launch_compare(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st, int chunk, bool generic_only, int queue_env) {
     const int queue = queue_env < 0 ? chunk : queue_env == 1 ? (int)kQueueChunkLong : queue_env;
     const bool two = ca.side[1].n_list != nullptr;
     const int r0 = (int)ca.side[0].rest, far = two ? ca.side[1].r_far + 1 : 0;

@@ -833,9 +833,10 @@ def test_direct_prefix_image_equals_the_indexed_one(capi, oracle, monkeypatch):
 
 
 def test_error_paths_added_since_round_1(capi, oracle, monkeypatch):
-    """(1) a scan that would collect 2^32 raw hits or more is refused, not wrapped; (2) a result whose page-locked block would exceed
-    FFH_PINNED_LIMIT_MB fails with FFH_E_NOMEM and leaves the context usable; (3) image widths the compare kernel has no row form
-    for are refused when the database is made resident"""
+    """(1) a guide set that collects 2^32 raw hits or more is not refused (round 5): ffh_discover halves it and concatenates the
+    parts' results -- here every (guide, target) pair is a hit, 4.5e9 of them; the two-step ffh_scan still reports the limit;
+    (2) a result whose page-locked block would exceed FFH_PINNED_LIMIT_MB fails with FFH_E_NOMEM and leaves the context usable;
+    (3) image widths the compare kernel has no row form for are refused when the database is made resident"""
     rng = np.random.default_rng(77)
     raw = np.unique(rng.integers(0, 1 << 40, size=4_400_000, dtype=np.uint64))
     t = (raw << np.uint64(6)) | np.uint64(0b101010) | (np.uint64(1) << np.uint64(48))
@@ -844,17 +845,23 @@ def test_error_paths_added_since_round_1(capi, oracle, monkeypatch):
     assert len(t) * len(g) >= 2 ** 32
     with capi.Context(3) as ctx:
         ctx.load_soa(t, p)
+        ctx.set_bounding(0)                                           # (bounding alone would keep this scan small: the split is what is tested)
         with pytest.raises(capi.FlashFryHipError, match="2\\^32 raw hits") as e:
-            ctx.discover(g, 20, 2000, summaries_only=True)            # maxMismatch >= the guide length: every pair is a hit
+            ctx.scan(g, 20)                                           # maxMismatch >= the guide length: every pair is a hit
         assert e.value.code == -1
-        ok = ctx.discover(g[:16], 3, 2000)                            # the context survives the refusal
-        monkeypatch.setenv("FFH_PINNED_LIMIT_MB", "1")
+        big = ctx.discover(g, 20, 2000, summaries_only=True)          # split in two: 2.25e9 raw hits each
+        assert np.all(big.summaries["n_hits"] == 2000) and np.all(big.summaries["ot_count"] == 2000) and np.all(big.summaries["overflow"] == 1)
+        assert big.n_hits == 2000 * len(g)
+        ok = ctx.discover(g[:16], 3, 2000)                            # the context goes on
+    monkeypatch.setenv("FFH_PINNED_LIMIT_MB", "1")                    # (read when a context is created: ffh_debug.hpp)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
         with pytest.raises(capi.FlashFryHipError, match="pinned") as e:
             ctx.discover(g[:256], 9, 2 ** 31 - 1)                     # ~4e6 hits: a result block of tens of MB
         assert e.value.code == -6
-        monkeypatch.delenv("FFH_PINNED_LIMIT_MB")
         again = ctx.discover(g[:16], 3, 2000)
         assert again.summaries.tobytes() == ok.summaries.tobytes()
+    monkeypatch.delenv("FFH_PINNED_LIMIT_MB")
     odb, t2, p2, g2 = make_case(oracle, 5000, 10, enzyme=3, seed=1)
     with capi.Context(3) as ctx:
         with pytest.raises(capi.FlashFryHipError, match="prefix_bases"):
@@ -993,3 +1000,52 @@ def test_captured_sequence_is_not_replayed_over_another_budgets_patterns(capi, o
         finally:
             del os.environ["FFH_MAX_GUIDE_BATCH"]
         assert_same_hits(ctx.discover(g, 4, 2000), want[4])
+
+
+def test_a_guide_set_with_more_raw_hits_than_one_scan_holds_is_split_not_refused(capi, oracle, monkeypatch):
+    """where one scan would collect more raw hits than its 32-bit segment arithmetic holds (FFH_RAW_HIT_LIMIT puts
+    that limit at 2048 here) the library first bounds the scan and then halves the guide set, as often as needed, and concatenates the
+    parts: lists, positions, per-hit scores and aggregates must be those of the oracle's single pass -- <= 6 mismatches on a database
+    with dense neighbourhoods, bounding on, off and automatic, lists and aggregates-only."""
+    odb, t, p, g = dense_case(oracle, n_random=120_000, n_guides=500, n_dense=60, variants=200, seed=57)
+    monkeypatch.setenv("FFH_RAW_HIT_LIMIT", "2048")   # (the scans below collect 5 000 - 12 000 raw hits: several levels of halving)
+    for mm, max_ot in ((6, 2000), (5, 40), (6, 2 ** 31 - 1)):
+        want = odb.discover(g, mm, max_ot)
+        for bounding in (0, 1, -1):
+            with capi.Context(3) as ctx:
+                ctx.load_soa(t, p)
+                ctx.set_bounding(bounding)
+                with pytest.raises(capi.FlashFryHipError, match="2\\^32 raw hits"):
+                    ctx.scan(g, mm)                                   # the two-step entry point reports the limit
+                got = ctx.discover(g, mm, max_ot, jost=True)
+                assert_same_hits(got, want)
+                if mm == 5:
+                    assert_same_scores(oracle, 3, g, got, want, jost=True)
+                only = ctx.discover(g, mm, max_ot, summaries_only=True, jost=True)
+                assert only.summaries.tobytes() == got.summaries.tobytes() and only.n_hits == got.n_hits
+                slim = ctx.discover(g, mm, max_ot, positions=False, hit_scores=False)
+                assert np.array_equal(slim.hit_targets, got.hit_targets) and np.array_equal(slim.guide_offsets, got.guide_offsets)
+    monkeypatch.delenv("FFH_RAW_HIT_LIMIT")
+
+
+def test_bulge_search_splits_a_guide_set_with_more_candidate_records_than_one_search_holds(capi, monkeypatch):
+    """the bulge path of VERDICT r4 next 7: with the record limit at 512 (FFH_RAW_HIT_LIMIT) the seeded search and the brute force halve
+    the guide set as often as needed; the concatenated result is the unsplit one"""
+    rng = np.random.default_rng(4242)
+    guides40 = rng.integers(0, 1 << 40, size=300, dtype=np.uint64)
+    targets, positions = _cas12a_database(rng, 60_000, guides40, 12)
+    guides = guides40 | np.uint64(0b11111100 << 40) | np.uint64(1 << 48)
+    with capi.Context(1) as ctx:
+        ctx.load_soa(targets, positions)
+        whole = ctx.discover_bulge(guides, 3, 1)
+    assert len(whole.hit_targets) > 2000
+    monkeypatch.setenv("FFH_RAW_HIT_LIMIT", "512")
+    with capi.Context(1) as ctx:
+        ctx.load_soa(targets, positions)
+        parts = ctx.discover_bulge(guides, 3, 1)
+        brute = ctx.discover_bulge(guides[:64], 3, 1, brute_force=True)
+    monkeypatch.delenv("FFH_RAW_HIT_LIMIT")
+    for name in ("guide_offsets", "hit_targets", "hit_mismatches", "hit_bulge_type", "hit_bulge_position"):
+        assert np.array_equal(getattr(parts, name), getattr(whole, name)), name
+    n64 = int(whole.guide_offsets[64])
+    assert np.array_equal(brute.hit_targets, whole.hit_targets[:n64]) and np.array_equal(brute.guide_offsets, whole.guide_offsets[:65])
