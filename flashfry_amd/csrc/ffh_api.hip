@@ -1171,8 +1171,11 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         S.nb = 1u << (2 * width); S.width = (uint32_t)width; S.rest = (uint32_t)im.rest; S.r_far = r_far;
         const double cap_g = std::floor((double)kKW / group_words(im.rest));
         const double avg_t = (double)n_targets / (double)S.nb, avg_g = avg_t / 32.0 + (avg_t > 0 ? 0.5 : 0.0), avg_c = (double)ng * n_patterns / (double)S.nb;
-        const double by_groups = std::floor(0.75 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.7 * kKC / std::max(avg_c, 0.05));
+        // (round 5: 0.85 / 0.8 of the strip instead of 0.75 / 0.7 -- 15 instead of 13 prefix buckets per entry at hg38 scale: fuller rows and
+        // 13 % fewer entries to park, 1.000 against 1.026 ms per launch, profiles/r05/ab_log.txt 1)
+        const double by_groups = std::floor(0.85 * cap_g / std::max(avg_g, 0.25)), by_cands = std::floor(0.8 * kKC / std::max(avg_c, 0.05));
         S.NB = (uint32_t)std::max(1.0, std::min((double)kMaxNB, std::min(by_groups, by_cands)));
+        if (ctx->sw.nb_force[which] > 0) S.NB = (uint32_t)std::min(ctx->sw.nb_force[which], kMaxNB);
         S.split = (uint32_t)cap_g;
         const uint32_t n_bat = (S.nb + S.NB - 1) / S.NB;
         {   // batches that have a target and a candidate: the shard's part of prefix-key space (plan_cost), the slab's ranks
@@ -1332,6 +1335,13 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             FFH_HIP(spin_wait(ctx, cnt));
             FFH_HIP(hipGetLastError());
             first_launch = false;
+            if (FFH_TRIP_STATS) {   // (variant builds only: tools/build_variant.sh ... FFH_TRIP_STATS=1)
+                unsigned long long ts[14];
+                FFH_HIP(hipMemcpy(ts, ctx->d_counters + 16, sizeof ts, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[trip stats] suffix: rows %llu steps %llu parks %llu pushes %llu hit_steps %llu lane_steps %llu | prefix: rows %llu steps %llu parks %llu pushes %llu hit_steps %llu "
+                        "lane_steps %llu | flushes %llu flush_iterations %llu | entries %llu %llu hits %llu\n", ts[6], ts[7], ts[8], ts[9], ts[10], ts[11], ts[0], ts[1], ts[2], ts[3], ts[4], ts[5],
+                        ts[12], ts[13], cnt[kStatEntries], cnt[kStatEntries + 1], cnt[1]);
+            }
             const unsigned long long cursor = cnt[0];
             // segments, sort offsets and the epilogue index hits with 32 bits: ONE scan never holds more raw hits than that.
             // ffh_discover / ffh_discover_sharded / ffh_discover_bulge then bound the scan and, if that is not enough, split the guide set
@@ -1438,7 +1448,33 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         // (segments of thousands of hits -- a 5-mismatch scan, guides inside repeat families -- are what the device-wide passes are
         // good at: beyond 256 raw hits per guide on average the six-pass sort is taken)
         const bool many = ctx->n_raw > 256ull * std::max<uint32_t>(n_guides, 1u);
-        if (full_lsd || (many && !force_seg)) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
+        // (round 5) a moderate number of hits -- a few thousand per bin of <= 2048 guides: one unstable most-significant-digit pass into
+        // 2^B bins + one launch that orders every bin inside LDS and leaves the segment bounds (ffh_prims.hpp: k_msd_*, k_binsort)
+        int B = 0;
+        while (B < std::min(gbits, (int)kMsdMaxBits) && (ctx->n_raw >> B) > 4096) ++B;
+        const int sub_bits = gbits - B;
+        const bool bins_fit = sub_bits <= kBinMaxSubBits && (double)ctx->n_raw / (double)(1u << B) <= 0.65 * kBinCap;
+        if (bins_fit && !full_lsd && !force_seg && (!many || ctx->sw.sort_mode == 3)) {
+            const uint32_t nbins = 1u << B, nbm = msd_nblocks(ctx->n_raw);
+            const int shift = ctx->tbits + gbits - B;
+            FFH_HIP(ctx->sort_table.reserve((size_t)nbins * nbm + 1));
+            FFH_HIP(ctx->sort_offs.reserve((size_t)nbins * nbm + 1));
+            FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)nbins * nbm)));
+            FFH_HIP(ctx->heavy_list.reserve((size_t)std::max<uint32_t>(n_guides, nbins) + 1));
+            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup)
+            hipLaunchKernelGGL(k_msd_hist, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)ctx->hits.p, ctx->n_raw, shift, nbins, ctx->tbits, n_guides, ctx->sort_table.p, nbm);
+            exclusive_scan<uint32_t, uint32_t>(ctx->sort_table.p, (uint64_t)nbins * nbm, ctx->sort_offs.p, ctx->scan_tmp32.p, st);
+            hipLaunchKernelGGL(k_msd_scatter, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)ctx->hits.p, ctx->hits_alt.p, ctx->n_raw, shift, nbins, ctx->tbits, n_guides,
+                               (const uint32_t *)ctx->sort_offs.p, nbm);
+            // (the scatter dropped the chunk padding: from here on the scan holds its n_real_hits real hits, contiguously)
+            hipLaunchKernelGGL(k_binsort, dim3(nbins), dim3(kMsdThreads), 0, st, ctx->hits_alt.p, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, (uint64_t)n_real_hits, ctx->tbits,
+                               sub_bits, n_guides, ctx->seg_begin.p, ctx->seg_end.p, ctx->heavy_list.p, n_heavy);
+            hipLaunchKernelGGL(k_binsort_heavy, dim3(256), dim3(256), 0, st, ctx->hits_alt.p, ctx->hits.p, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, (uint64_t)n_real_hits,
+                               (const uint32_t *)ctx->heavy_list.p, (const uint32_t *)n_heavy, ctx->tbits, sub_bits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
+            ctx->hits_sorted = ctx->hits_alt.p;
+            ctx->n_raw = n_real_hits;
+            segments_done = true;
+        } else if (full_lsd || (many && !force_seg)) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
         else {
             FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
             uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup)

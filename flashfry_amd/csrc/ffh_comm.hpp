@@ -126,6 +126,7 @@ __global__ void k_exchange_reduce(const GuideSummary *__restrict__ all /* [world
 }  // namespace ffh
 
 enum { FFH_COMM_COPY = 0, FFH_COMM_ALL = 1, FFH_COMM_RANK = 2 };
+static const char *const kSplitMessage = "the guide set was split (more raw hits than one scan holds): hit lists and device summaries are per call -- pass fewer guides per ffh_discover_sharded";
 constexpr int kSplitGuides = -1000;   // internal: comm_exchange -> discover_sharded_split (never returned through the C ABI)
 
 struct ffh_comm {
@@ -144,6 +145,7 @@ struct ffh_comm {
     uint32_t n_guides = 0;
     int max_ot = 0;
     bool exchanged = false;
+    bool was_split = false;              // the last ffh_discover_sharded halved its guide set: hit lists / device summaries are refused
     uint32_t crossing = 0;               // guides of the last exchange whose cut-off fell inside a shard with a non-zero prior (second round)
     double scan_ms = 0, exchange_ms = 0;  // host wall time of the last ffh_discover_sharded: scans (all local shards), exchange + copy-out
 };
@@ -407,10 +409,8 @@ int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides
     if (!cm || (n_guides && !guides) || max_mismatch < 0 || max_offtargets < 0) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
     bool split = false;
     const int rc = discover_sharded_split(cm, guides, n_guides, max_mismatch, max_offtargets, flags, summaries_out, split);
-    if (!rc && split) {
-        cm->exchanged = false;
-        cm->err = "the guide set was split (more raw hits than one scan holds): hit lists and device summaries are per call -- pass fewer guides per ffh_discover_sharded";
-    }
+    cm->was_split = !rc && split;
+    if (cm->was_split) cm->exchanged = false;
     return rc;
 }
 static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
@@ -442,7 +442,7 @@ static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t 
 // the exchange alone, for callers that scanned the shards themselves (ffh_scan / ffh_scan_bounded on every local context)
 int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
     if (!cm || max_offtargets < 0) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
-    cm->exchanged = false;
+    cm->exchanged = false; cm->was_split = false;
     const auto t1 = std::chrono::steady_clock::now();
     const int rc = comm_exchange(cm, n_guides, max_offtargets, flags, summaries_out);
     if (rc) return rc == kSplitGuides ? FFH_E_STATE : rc;   // (the caller scanned the shards itself: it splits the guide set itself)
@@ -453,7 +453,7 @@ int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsig
 
 int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_result **out) {
     if (!cm || !out || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
-    if (!cm->exchanged) { if (cm->err.empty()) cm->err = "ffh_discover_sharded has not run"; return FFH_E_STATE; }
+    if (!cm->exchanged) { cm->err = cm->was_split ? kSplitMessage : "ffh_discover_sharded has not run"; return FFH_E_STATE; }
     ffh_ctx *ctx = cm->ctx[(size_t)local_shard];
     const int rc = ffh_finalize(ctx, cm->buf[(size_t)local_shard]->prior.p, cm->max_ot, (flags & ~FFH_FINALIZE_SUMMARIES_ONLY) | FFH_FINALIZE_PRIOR_ON_DEVICE, out);
     if (rc) { std::lock_guard<std::mutex> g(cm->err_m); cm->err = ctx->err; }
@@ -462,7 +462,7 @@ int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_resu
 
 int ffh_comm_device_summaries(ffh_comm *cm, int local_shard, const void **device_summaries) {
     if (!cm || !device_summaries || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) return FFH_E_ARG;
-    if (!cm->exchanged) { cm->err = "ffh_discover_sharded has not run"; return FFH_E_STATE; }
+    if (!cm->exchanged) { cm->err = cm->was_split ? kSplitMessage : "ffh_discover_sharded has not run"; return FFH_E_STATE; }
     *device_summaries = cm->buf[(size_t)local_shard]->red.p;
     return FFH_OK;
 }

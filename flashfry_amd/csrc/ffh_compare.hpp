@@ -44,6 +44,8 @@ constexpr int FFH_WAVES_PER_SIMD = 4;   // launch bound (four blocks of four wav
 constexpr int FFH_GPL = 6;              // groups per job of a large bucket, about
 constexpr int FFH_PIPE_TRIPS = 2;       // 16-byte pieces of a group's words requested one group ahead (more cost registers)
 constexpr int FFH_MAX_ENTRY_WORK = 2048;   // group tests per work entry of a heavy bucket, at most
+constexpr int FFH_TRIP_STATS = 0;          // 1 (tools/build_variant.sh only): the kernel counts its rows, steps, parks, pushes and flushes per image
+                                           // (cursor[16..27], printed by scan_impl) -- the trip counts of profiles/r05/compare_attribution.md
 constexpr int kCmpThreads = 256;           // four waves, each with its own LDS strip: no block-level synchronisation in the kernel
 constexpr int kCmpWaves = kCmpThreads / 64;
 constexpr int kKW = FFH_KW;                // group words parked per wave (4 KB: 51 groups of 20 words, 42 of 24)
@@ -105,6 +107,7 @@ __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int fir
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
     if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
     if (threadIdx.x >= kQueue && threadIdx.x < kQueue + 2 * kQueues) cursor[threadIdx.x] = 0ull;  // the two images' work queues (k_compare)
+    if (FFH_TRIP_STATS && threadIdx.x >= 16 && threadIdx.x < 30) cursor[threadIdx.x] = 0ull;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -185,6 +188,7 @@ struct HitStage {
     unsigned long long chunk_pos;
     uint32_t chunk_left;
     uint32_t n_real;         // (a scan of 2^32 raw hits or more is refused by the host)
+    uint32_t st_push = 0, st_flush = 0, st_flush_it = 0;   // FFH_TRIP_STATS
 
     __device__ __forceinline__ void flush() {
         wave_lds_fence();
@@ -220,6 +224,7 @@ struct HitStage {
         // a pass of its own over all hits.  (Requesting the look-ups of all staged records -- four per lane -- before the first key
         // is stored, for the rows of a repeat family where a wave flushes after every third step: nothing gained there, 1.12
         // against 1.04 ms per launch at hg38 scale, where a flush holds a handful of records; dropped.)
+        if (FFH_TRIP_STATS) { ++st_flush; st_flush_it += (fill + 63u) >> 6; }
         for (uint32_t i = lane; i < fill; i += 64) {
             const unsigned long long dst = i < old_left ? old_pos + i : new_pos + (i - old_left);
             if (dst < cap) {
@@ -253,6 +258,7 @@ struct HitStage {
     // wave-uniform call: `lanes` = ballot of `hit`
     __device__ __forceinline__ void push(uint64_t lanes, bool hit, uint32_t gid, uint32_t slot) {
         if (hit) ((lds_u64 *)W->stage)[fill + mbcnt(lanes)] = ((uint64_t)gid << 32) | slot;
+        if (FFH_TRIP_STATS) ++st_push;
         fill += (uint32_t)__popcll(lanes);
         if (fill > kStage - 64) flush();  // always leave room for one more wave-wide batch
     }
@@ -263,6 +269,7 @@ struct RowCtx {
     HitStage *hs;
     int max_mm, r_far;
     uint32_t width;
+    uint32_t st_rows = 0, st_steps = 0, st_hit_steps = 0, st_lane_steps = 0;   // FFH_TRIP_STATS (per image: reset by run_side)
 };
 
 // One row: 64 jobs, one per lane -- one candidate guide against `trips` consecutive groups of its bucket.
@@ -273,7 +280,7 @@ struct RowCtx {
 //   0 none (prefix image), 1 .. 4 count >= FAR as one or two v_bitop3 on the count's bit planes, -1 taken from c.r_far at run time
 //   EARLY: 16-byte pieces of a group's words requested one group ahead (registers: the any-width instance cannot afford them)
 template <int R, int FAR, int EARLY, int SIDE>
-__device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t sbase,
+__device__ __forceinline__ void scan_row(RowCtx &c, uint32_t rest, uint32_t d, uint32_t gid, uint32_t trips, uint32_t gword, uint32_t sbase,
                                          const uint32_t *strip) {
     constexpr int GW = group_words(R);
     lds_c4 *gp = (lds_c4 *)(strip + gword);            // per lane, 16-byte aligned (GW is a multiple of 4)
@@ -309,7 +316,9 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
     // groups): one compare per step for both.  (Written as `for (; ballot(t < trips);) ... if (t >= trips) hit = 0` the compiler
     // materialised the condition in a register and compared twice: five vector instructions per step instead of two.)
     uint64_t live = __builtin_amdgcn_ballot_w64(trips != 0u);
+    if (FFH_TRIP_STATS) ++c.st_rows;
     for (uint32_t t = 0; live; ++t) {
+        if (FFH_TRIP_STATS) { ++c.st_steps; c.st_lane_steps += (uint32_t)__popcll(live); }
         fetch(IE{}, IN{});
         uint32_t m[R];
 #pragma unroll
@@ -345,6 +354,7 @@ __device__ __forceinline__ void scan_row(const RowCtx &c, uint32_t rest, uint32_
         live = __builtin_amdgcn_ballot_w64(t + 1u < trips);
         const uint64_t lanes = __builtin_amdgcn_ballot_w64(hit != 0u);
         if (lanes) {   // rare per lane, usual per wave: the lanes with a non-zero mask stage one record per set bit (almost always one)
+            if (FFH_TRIP_STATS) ++c.st_hit_steps;
             const uint32_t slot0 = (sbase + (t << 5)) | ((uint32_t)SIDE << 31);
             uint64_t more = lanes;
             do {
@@ -532,6 +542,16 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
         constexpr uint32_t GW = (uint32_t)group_words(RC);
         rc.r_far = S.r_far;
         rc.width = S.width;
+        uint32_t st_parks = 0;
+        const uint32_t push0 = hs.st_push;
+        rc.st_rows = rc.st_steps = rc.st_hit_steps = rc.st_lane_steps = 0;
+        auto stats_out = [&]() {
+            if (FFH_TRIP_STATS && lane == 0) {
+                atomicAdd(cursor + 16 + side * 6 + 0, (unsigned long long)rc.st_rows); atomicAdd(cursor + 16 + side * 6 + 1, (unsigned long long)rc.st_steps);
+                atomicAdd(cursor + 16 + side * 6 + 2, (unsigned long long)st_parks); atomicAdd(cursor + 16 + side * 6 + 3, (unsigned long long)(hs.st_push - push0));
+                atomicAdd(cursor + 16 + side * 6 + 4, (unsigned long long)rc.st_hit_steps); atomicAdd(cursor + 16 + side * 6 + 5, (unsigned long long)rc.st_lane_steps);
+            }
+        };
 
         // ---- the pipeline.  A work entry lives in lanes 0..5 of ONE vector register ({first bucket, buckets, g0, g1, c0, c1}: scalar
         //      registers are the scarce resource here) and is read out with v_readlane where a stage needs it.  An entry past the end
@@ -723,6 +743,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                 }
                 // everything requested a batch ago has arrived (the compiler's waits cover it): park it
                 const uint32_t n_jobs = k1 > k0 ? park(b0, nbv, t0, t1, k0, k1, kreg, greg_a, ereg, dG0, dI0) : 0u;
+                if (FFH_TRIP_STATS) ++st_parks;
                 uint32_t nk = k0 + (uint32_t)kKC, nt = t0;
                 if (nk >= c1) { nk = c0; nt = t0 + cap_g; }
                 const bool last = nt >= g1;
@@ -749,9 +770,11 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             E0 = E1; E1 = E2; E2 = E3; E3 = E4;
             ends >>= 1;
         }
+        stats_out();
     };
     run_side(std::integral_constant<int, 1>{});
     run_side(std::integral_constant<int, 0>{});
+    if (FFH_TRIP_STATS && lane == 0) { atomicAdd(cursor + 28, (unsigned long long)hs.st_flush); atomicAdd(cursor + 29, (unsigned long long)hs.st_flush_it); }
     hs.finish();
 }
 

@@ -25,10 +25,11 @@ struct Switches {
     long work_list_limit = 0;        // FFH_WORK_LIST_LIMIT: first size of the compare launch's work list (forces the run-again path)
     bool slab_prefix_per_slab = false;   // FFH_SLAB_PREFIX=per-slab: a bounded scan bins the prefix candidates per slab
     bool graph = true;               // FFH_GRAPH=0: never replay the candidate-list launches as a captured graph
-    int sort_mode = 0;               // FFH_SORT=lsd (1) / seg (2): force one of the two hit orderings (0: by hits per guide)
+    int sort_mode = 0;               // FFH_SORT=lsd (1) / seg (2) / bin (3): force one of the hit orderings (0: by the number of hits)
     bool summary_copy = false;       // FFH_SUMMARY_COPY=1: the summaries leave in a copy after the epilogue instead of under it
     bool generic_compare = false;    // FFH_GENERIC_COMPARE=1: the per-width-pair instances of k_compare for every plan
     int work_queue = -1;             // FFH_WORK_QUEUE=0 / 1 / 16 / 4: how the compare launch deals its work entries (-1: by list length)
+    int nb_force[2] = {0, 0};        // FFH_NB_PREFIX / FFH_NB_SUFFIX: buckets per work entry of the image (A/B; 0: side_plan's rule)
     uint64_t raw_hit_limit = (1ull << 32) - 64;   // FFH_RAW_HIT_LIMIT: raw hits one scan may collect before the guide set is split (tests: 2^20)
 
     static Switches from_env() {
@@ -45,10 +46,11 @@ struct Switches {
         { const long v = num("FFH_WORK_LIST_LIMIT", 0); s.work_list_limit = v > 0 ? v : 0; }
         s.slab_prefix_per_slab = is("FFH_SLAB_PREFIX", "per-slab");
         s.graph = num("FFH_GRAPH", 1) != 0;
-        s.sort_mode = is("FFH_SORT", "lsd") ? 1 : is("FFH_SORT", "seg") ? 2 : 0;
+        s.sort_mode = is("FFH_SORT", "lsd") ? 1 : is("FFH_SORT", "seg") ? 2 : is("FFH_SORT", "bin") ? 3 : 0;
         s.summary_copy = num("FFH_SUMMARY_COPY", 0) == 1;
         s.generic_compare = num("FFH_GENERIC_COMPARE", 0) == 1;
         s.work_queue = (int)num("FFH_WORK_QUEUE", -1);
+        s.nb_force[0] = (int)num("FFH_NB_PREFIX", 0); s.nb_force[1] = (int)num("FFH_NB_SUFFIX", 0);
         { const long v = num("FFH_RAW_HIT_LIMIT", 0); if (v > 0) s.raw_hit_limit = (uint64_t)v; }
         return s;
     }

@@ -414,80 +414,317 @@ __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, co
         if ((uint32_t)r < K && (uint32_t)r * 64u + lane < n) keys[b + rank[r]] = k[r];
 }
 
-// one block per listed segment: LSD radix sort over the low `tbits` bits, 8 bits per pass, 4096 keys per step (the ranking of
-// k_sort_scatter with the digits' running cursors kept in LDS), ping-pong between the segment's ranges of `keys` and `alt`; the result
-// ends in `keys`
+// LSD radix sort of keys[0 .. n) over their low `bits` bits by ONE block of 256 threads, 8 bits per pass, 4096 keys per step (the ranking
+// of k_sort_scatter with the digits' running cursors kept in LDS), ping-pong between `keys` and `alt`; the result ends in `keys`.
+struct BlockSortLds {
+    uint32_t cursor[256];
+    uint32_t wcnt[4][256];
+    uint32_t scan_lds[8];
+};
+__device__ __forceinline__ void block_lsd_sort(uint64_t *__restrict__ keys, uint64_t *__restrict__ alt, uint32_t n, int bits, BlockSortLds &L) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint64_t *src = keys, *dst = alt;
+    for (int shift = 0; shift < bits; shift += 8) {
+        L.cursor[t] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += 256) atomicAdd(&L.cursor[(uint32_t)(src[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        uint32_t tot;
+        const uint32_t start = block_exclusive_scan<uint32_t>(L.cursor[t], L.scan_lds, tot);
+        L.cursor[t] = start;
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += kSortChunk) {
+            const uint32_t here = min((uint32_t)kSortChunk, n - c0);
+            uint64_t kreg[kSortRows];
+#pragma unroll
+            for (int r = 0; r < kSortRows; ++r) {
+                const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                kreg[r] = i < here ? src[c0 + i] : 0ull;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) L.wcnt[w][t] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kSortRows; ++r) {
+                const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                if (i < here) atomicAdd(&L.wcnt[wave][(uint32_t)(kreg[r] >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            {   // digit t: where each wave's keys of this step go; the digit's cursor moves on
+                const uint32_t c0w = L.wcnt[0][t], c1w = L.wcnt[1][t], c2w = L.wcnt[2][t], c3w = L.wcnt[3][t], base = L.cursor[t];
+                L.wcnt[0][t] = base; L.wcnt[1][t] = base + c0w; L.wcnt[2][t] = base + c0w + c1w; L.wcnt[3][t] = base + c0w + c1w + c2w;
+                L.cursor[t] = base + c0w + c1w + c2w + c3w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kSortRows; ++r) {
+                const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+                const bool valid = i < here;
+                const uint32_t d = (uint32_t)(kreg[r] >> shift) & 255u;
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const uint64_t bal = __ballot((d >> bb) & 1);
+                    peers &= ((d >> bb) & 1) ? bal : ~bal;
+                }
+                const uint32_t rank = mbcnt(peers);
+                uint32_t pos = 0;
+                if (valid) pos = L.wcnt[wave][d] + rank;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (valid && rank == (uint32_t)__popcll(peers) - 1u) L.wcnt[wave][d] = pos + 1u;   // last peer advances the wave's cursor
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (valid) dst[pos] = kreg[r];
+            }
+            __syncthreads();
+        }
+        uint64_t *x = src; src = dst; dst = x;
+    }
+    if (src != keys)
+        for (uint32_t i = t; i < n; i += 256) keys[i] = src[i];
+    __syncthreads();
+}
+
+// one block per listed segment (a guide with more than kSegWaveMax raw hits): its keys ordered by the low `tbits` bits
 __global__ __launch_bounds__(256) void k_segsort_heavy(uint64_t *__restrict__ keys, uint64_t *__restrict__ alt, const uint32_t *__restrict__ seg_begin,
                                                        const uint32_t *__restrict__ seg_end, const uint32_t *__restrict__ heavy_list,
                                                        const uint32_t *__restrict__ n_heavy, int tbits) {
-    __shared__ uint32_t cursor[256];
-    __shared__ uint32_t wcnt[4][256];
-    __shared__ uint32_t scan_lds[8];
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ BlockSortLds L;
     const uint32_t nh = *n_heavy;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t g = heavy_list[h], b = seg_begin[g], n = seg_end[g] - b;
-        uint64_t *src = keys + b, *dst = alt + b;
-        for (int shift = 0; shift < tbits; shift += 8) {
-            cursor[t] = 0;
-            __syncthreads();
-            for (uint32_t i = t; i < n; i += 256) atomicAdd(&cursor[(uint32_t)(src[i] >> shift) & 255u], 1u);
-            __syncthreads();
-            uint32_t tot;
-            const uint32_t start = block_exclusive_scan<uint32_t>(cursor[t], scan_lds, tot);
-            cursor[t] = start;
-            __syncthreads();
-            for (uint32_t c0 = 0; c0 < n; c0 += kSortChunk) {
-                const uint32_t here = min((uint32_t)kSortChunk, n - c0);
-                uint64_t kreg[kSortRows];
+        block_lsd_sort(keys + b, alt + b, n, tbits, L);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ordering the hits of a scan with a moderate number of them (round 5; the step the benchmark times): TWO passes over the keys instead of
+// ~eight.
+//   1. k_msd_hist / scan / k_msd_scatter: ONE most-significant-digit pass groups the keys by the top B <= 11 bits of the guide field into
+//      2^B bins of a few thousand keys each.  Nothing downstream depends on the order inside a bin, so the scatter is not stable: a key's
+//      place in its block's run of a digit is the value an LDS atomic returns (k_sort_scatter ranks every row with eight ballots).
+//      16 384 keys per block: at 2048 digits a block still writes runs of ~8 keys.
+//   2. k_binsort: one block per bin, the bin never leaves the CU.  The bin's keys are counted per guide in LDS (its guides are the
+//      2^sub_bits consecutive ones the digit names), their database indices are put in guide order inside LDS, and every wave then
+//      takes guides: it ranks the guide's indices against each other (all pairs: v_readlane for <= 128 keys, LDS broadcasts beyond),
+//      which is the key's final place, and writes key and segment bounds.  This is k_segments + k_segsort + the second device-wide
+//      pass in one launch, with the keys read once from memory.
+// The all-ones padding keys of the compare waves' chunks are dropped by the first pass: behind it the array holds the scan's real hits only.
+// A bin with more keys than the LDS arrays hold (a guide inside a repeat family) is listed and sorted by k_binsort_heavy through
+// memory; a scan with more hits per bin than the arrays hold ON AVERAGE keeps the multi-pass path (hit_ordering_plan).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMsdThreads = 1024;
+constexpr int kMsdRows = 16;
+constexpr int kMsdChunk = kMsdThreads * kMsdRows;          // 16 384 keys per block
+constexpr int kMsdMaxBits = 11;
+constexpr uint32_t kBinCap = 12288;                         // keys of a bin k_binsort holds in LDS (12 per thread)
+constexpr int kBinRows = kBinCap / kMsdThreads;
+constexpr int kBinMaxSubBits = 11;                          // guides per bin <= 2048
+
+inline uint32_t msd_nblocks(uint64_t n) { return (uint32_t)((n + kMsdChunk - 1) / kMsdChunk); }
+
+// exclusive scan over the 1024 threads of a block
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds /* >= 16 */, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
 #pragma unroll
-                for (int r = 0; r < kSortRows; ++r) {
-                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
-                    kreg[r] = i < here ? src[c0 + i] : 0ull;
-                }
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) wcnt[w][t] = 0;
-                __syncthreads();
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t s = lds[w];
+        if ((uint32_t)w < wave) off += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return off + incl - v;
+}
+
+// (keys whose guide field is >= n_guides are the all-ones padding of the compare waves' last chunks: counted nowhere and dropped by the
+// scatter, so the bins hold hits only and their total is the scan's number of real hits)
+__global__ __launch_bounds__(kMsdThreads) void k_msd_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift, uint32_t nbins, int tbits, uint32_t n_guides,
+                                                           uint32_t *__restrict__ table /* [nbins][nblocks] */, uint32_t nblocks) {
+    __shared__ uint32_t h[1 << kMsdMaxBits];
+    for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) h[d] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kMsdChunk;
+    uint64_t kreg[kMsdRows];
 #pragma unroll
-                for (int r = 0; r < kSortRows; ++r) {
-                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
-                    if (i < here) atomicAdd(&wcnt[wave][(uint32_t)(kreg[r] >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                {   // digit t: where each wave's keys of this step go; the digit's cursor moves on
-                    const uint32_t c0w = wcnt[0][t], c1w = wcnt[1][t], c2w = wcnt[2][t], c3w = wcnt[3][t], base = cursor[t];
-                    wcnt[0][t] = base; wcnt[1][t] = base + c0w; wcnt[2][t] = base + c0w + c1w; wcnt[3][t] = base + c0w + c1w + c2w;
-                    cursor[t] = base + c0w + c1w + c2w + c3w;
-                }
-                __syncthreads();
+    for (int r = 0; r < kMsdRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * kMsdThreads + threadIdx.x;
+        kreg[r] = i < n ? keys[i] : ~0ull;
+    }
 #pragma unroll
-                for (int r = 0; r < kSortRows; ++r) {
-                    const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
-                    const bool valid = i < here;
-                    const uint32_t d = (uint32_t)(kreg[r] >> shift) & 255u;
-                    uint64_t peers = __ballot(valid);
+    for (int r = 0; r < kMsdRows; ++r)
+        if ((kreg[r] >> tbits) < n_guides) atomicAdd(&h[(uint32_t)(kreg[r] >> shift) & (nbins - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) table[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+__global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift, uint32_t nbins, int tbits,
+                                                              uint32_t n_guides, const uint32_t *__restrict__ offs /* scanned [nbins][nblocks] */, uint32_t nblocks) {
+    __shared__ uint64_t staged[kMsdChunk];                  // the chunk, digit-ordered (128 KB)
+    __shared__ uint32_t cnt[1 << kMsdMaxBits], dig_start[1 << kMsdMaxBits], dig_goff[1 << kMsdMaxBits];
+    __shared__ uint32_t scan_lds[16];
+    const uint32_t t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * kMsdChunk;
+    const uint32_t here = (uint32_t)min((uint64_t)kMsdChunk, n - base);
+    uint64_t kreg[kMsdRows];
+    uint16_t rank[kMsdRows];
 #pragma unroll
-                    for (int bb = 0; bb < 8; ++bb) {
-                        const uint64_t bal = __ballot((d >> bb) & 1);
-                        peers &= ((d >> bb) & 1) ? bal : ~bal;
-                    }
-                    const uint32_t rank = mbcnt(peers);
-                    uint32_t pos = 0;
-                    if (valid) pos = wcnt[wave][d] + rank;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (valid && rank == (uint32_t)__popcll(peers) - 1u) wcnt[wave][d] = pos + 1u;   // last peer advances the wave's cursor
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (valid) dst[pos] = kreg[r];
-                }
-                __syncthreads();
+    for (int r = 0; r < kMsdRows; ++r) {
+        const uint32_t i = (uint32_t)r * kMsdThreads + t;
+        kreg[r] = i < here ? keys[base + i] : ~0ull;
+    }
+    for (uint32_t d = t; d < nbins; d += kMsdThreads) { cnt[d] = 0; dig_goff[d] = offs[(uint64_t)d * nblocks + blockIdx.x]; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kMsdRows; ++r) {
+        rank[r] = 0;
+        if ((kreg[r] >> tbits) < n_guides) rank[r] = (uint16_t)atomicAdd(&cnt[(uint32_t)(kreg[r] >> shift) & (nbins - 1u)], 1u);
+    }
+    __syncthreads();
+    uint32_t staged_n = 0;
+    {   // digits 2t, 2t + 1: start of the digit's run inside the chunk
+        const uint32_t c0 = 2u * t < nbins ? cnt[2u * t] : 0u, c1 = 2u * t + 1u < nbins ? cnt[2u * t + 1u] : 0u;
+        const uint32_t s = block_scan_1024(c0 + c1, scan_lds, staged_n);
+        if (2u * t < nbins) dig_start[2u * t] = s;
+        if (2u * t + 1u < nbins) dig_start[2u * t + 1u] = s + c0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kMsdRows; ++r)
+        if ((kreg[r] >> tbits) < n_guides) staged[dig_start[(uint32_t)(kreg[r] >> shift) & (nbins - 1u)] + rank[r]] = kreg[r];
+    __syncthreads();
+    for (uint32_t i = t; i < staged_n; i += kMsdThreads) {
+        const uint64_t key = staged[i];
+        const uint32_t d = (uint32_t)(key >> shift) & (nbins - 1u);
+        out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
+    }
+}
+
+// rank of each of a lane's keys among the c keys idx[0 .. c) of a guide (distinct 32-bit database indices), and the keys' final place
+// keys[rank] = hi | index.  c <= 128: the other keys come through v_readlane (no memory round trip in the loop); beyond, from LDS, four
+// per broadcast step, the lane's own keys in chunks of kBinRankRows x 64.
+constexpr int kBinRankRows = 8;
+__device__ __forceinline__ void rank_segment(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
+    if (c <= 128u) {
+        const uint32_t a0 = lane < c ? idx[lane] : 0xFFFFFFFFu, a1 = 64u + lane < c ? idx[64u + lane] : 0xFFFFFFFFu;
+        const uint32_t n0 = min(c, 64u), n1 = c - n0;
+        uint32_t r0 = 0, r1 = 0;
+        // (lanes past the segment hold all-ones: never below a real index, so the steps run in fours without a remainder)
+        auto steps = [&](uint32_t src, uint32_t cnt) {
+            for (uint32_t j = 0; j < cnt; j += 4) {
+                const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)j), v1 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 1u));
+                const uint32_t v2 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 2u)), v3 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 3u));
+                r0 += (v0 < a0 ? 1u : 0u) + (v1 < a0 ? 1u : 0u) + (v2 < a0 ? 1u : 0u) + (v3 < a0 ? 1u : 0u);
+                r1 += (v0 < a1 ? 1u : 0u) + (v1 < a1 ? 1u : 0u) + (v2 < a1 ? 1u : 0u) + (v3 < a1 ? 1u : 0u);
             }
-            uint64_t *x = src; src = dst; dst = x;
+        };
+        steps(a0, n0);
+        if (n1) steps(a1, n1);
+        if (lane < c) keys[r0] = hi | a0;
+        if (64u + lane < c) keys[r1] = hi | a1;
+        return;
+    }
+    for (uint32_t c0 = 0; c0 < c; c0 += (uint32_t)kBinRankRows * 64u) {
+        uint32_t a[kBinRankRows], rank[kBinRankRows];
+#pragma unroll
+        for (int r = 0; r < kBinRankRows; ++r) {
+            const uint32_t i = c0 + (uint32_t)r * 64u + lane;
+            a[r] = i < c ? idx[i] : 0xFFFFFFFFu;
+            rank[r] = 0;
         }
-        if (src != keys + b)
-            for (uint32_t i = t; i < n; i += 256) keys[b + i] = src[i];
+        for (uint32_t j = 0; j < c; j += 4) {   // (uniform addresses: LDS broadcasts)
+            const uint32_t v0 = idx[j], v1 = j + 1u < c ? idx[j + 1u] : 0xFFFFFFFFu, v2 = j + 2u < c ? idx[j + 2u] : 0xFFFFFFFFu, v3 = j + 3u < c ? idx[j + 3u] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < kBinRankRows; ++r) rank[r] += (v0 < a[r] ? 1u : 0u) + (v1 < a[r] ? 1u : 0u) + (v2 < a[r] ? 1u : 0u) + (v3 < a[r] ? 1u : 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < kBinRankRows; ++r)
+            if (c0 + (uint32_t)r * 64u + lane < c) keys[rank[r]] = hi | a[r];
+    }
+}
+
+// bin d = keys [offs[d * nblocks], offs[(d + 1) * nblocks]) of `keys` (the digit-major table k_msd_scatter used: block 0's offset of a
+// digit is where the digit's run begins); in place.
+__global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ keys, const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t nbins, uint64_t n_total,
+                                                          int tbits, int sub_bits, uint32_t n_guides, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
+                                                          uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ n_heavy) {
+    __shared__ uint32_t idx[kBinCap];
+    __shared__ uint32_t cnt[(1 << kBinMaxSubBits) + 2], start[(1 << kBinMaxSubBits) + 2];
+    __shared__ uint32_t scan_lds[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), bin = blockIdx.x;
+    const uint32_t b0 = offs[(uint64_t)bin * nblocks], b1 = bin + 1u < nbins ? offs[(uint64_t)(bin + 1u) * nblocks] : (uint32_t)n_total, n = b1 - b0;
+    if (n == 0u) return;
+    if (n > kBinCap) {
+        if (t == 0) heavy_list[atomicAdd(n_heavy, 1u)] = bin;
+        return;
+    }
+    const uint32_t nsub = 1u << sub_bits, mask = tbits >= 32 ? 0xFFFFFFFFu : (1u << tbits) - 1u;
+    for (uint32_t s = t; s <= nsub; s += kMsdThreads) cnt[s] = 0;
+    __syncthreads();
+    uint64_t kreg[kBinRows];
+    uint16_t rk[kBinRows];
+    auto sub_of = [&](uint64_t key) { return (uint32_t)(key >> tbits) & (nsub - 1u); };
+#pragma unroll
+    for (int r = 0; r < kBinRows; ++r) {
+        const uint32_t i = (uint32_t)r * kMsdThreads + t;
+        kreg[r] = 0; rk[r] = 0;
+        if (i < n) { kreg[r] = keys[b0 + i]; rk[r] = (uint16_t)atomicAdd(&cnt[sub_of(kreg[r])], 1u); }
+    }
+    __syncthreads();
+    {   // exclusive scan of the nsub + 1 counters (<= 2049: three per thread at most)
+        uint32_t c[3], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const uint32_t s = 3u * t + (uint32_t)k; c[k] = s <= nsub ? cnt[s] : 0u; sum += c[k]; }
+        uint32_t tot;
+        uint32_t off = block_scan_1024(sum, scan_lds, tot);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const uint32_t s = 3u * t + (uint32_t)k; if (s <= nsub) start[s] = off; off += c[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kBinRows; ++r) {
+        const uint32_t i = (uint32_t)r * kMsdThreads + t;
+        if (i < n) idx[start[sub_of(kreg[r])] + rk[r]] = (uint32_t)kreg[r] & mask;
+    }
+    __syncthreads();
+    // every wave takes guides of the bin; all of the bin's keys are in registers / LDS by now, so writing in place is safe
+    for (uint32_t s = wave; s < nsub; s += kMsdThreads / 64) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[s]);
+        if (c == 0u) continue;
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[s]), guide = (bin << sub_bits) | s;
+        if (lane == 0) { seg_begin[guide] = b0 + st; seg_end[guide] = b0 + st + c; }
+        rank_segment(idx + st, c, (uint64_t)guide << tbits, keys + b0 + st, lane);
+    }
+}
+
+// the bins k_binsort listed: sorted through memory by their low tbits + sub_bits bits, then the guides' segments found in the sorted run
+__global__ __launch_bounds__(256) void k_binsort_heavy(uint64_t *__restrict__ keys, uint64_t *__restrict__ alt, const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t nbins,
+                                                       uint64_t n_total, const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ n_heavy, int tbits, int sub_bits,
+                                                       uint32_t n_guides, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end) {
+    __shared__ BlockSortLds L;
+    const uint32_t nh = *n_heavy;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t bin = heavy_list[h];
+        const uint32_t b0 = offs[(uint64_t)bin * nblocks], b1 = bin + 1u < nbins ? offs[(uint64_t)(bin + 1u) * nblocks] : (uint32_t)n_total, n = b1 - b0;
+        uint64_t *k = keys + b0;
+        block_lsd_sort(k, alt + b0, n, tbits + sub_bits, L);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint64_t g = k[i] >> tbits;
+            if (g >= n_guides) continue;
+            if (i == 0 || (k[i - 1] >> tbits) != g) seg_begin[g] = b0 + i;
+            if (i == n - 1 || (k[i + 1] >> tbits) != g) seg_end[g] = b0 + i + 1u;
+        }
         __syncthreads();
     }
 }
