@@ -611,30 +611,60 @@ __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__r
     }
 }
 
-// rank of each of a lane's keys among the c keys idx[0 .. c) of a guide (distinct 32-bit database indices), and the keys' final place
-// keys[rank] = hi | index.  c <= 128: the other keys come through v_readlane (no memory round trip in the loop); beyond, from LDS, four
-// per broadcast step, the lane's own keys in chunks of kBinRankRows x 64.
+// One wave orders the c distinct 32-bit database indices idx[0 .. c) of a guide and writes the keys hi | index in that order.
+// c <= 256: a bitonic network over one, two or four registers per lane -- element e of the sequence lives in lane e & 63 of register
+// e >> 6, absent elements are all-ones and end up behind the others; the partner of a compare-exchange comes through the LDS crossbar
+// (ds_bpermute, no memory access) or is the lane's other register: ~230 instructions for a guide of 65 .. 128 keys.  (Round 4 ranked every key against all others -- c / 4 steps of four v_readlane and
+// eight half-rate v_cmp: ~700 instructions for the usual 116 keys, 0.15 ms of the hg38-scale step on the vector pipes alone.)
+// Beyond 256 keys: ranking against the whole segment out of LDS, four keys per broadcast step, the lane's own keys in chunks of
+// kBinRankRows x 64.
 constexpr int kBinRankRows = 8;
-__device__ __forceinline__ void rank_segment(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
-    if (c <= 128u) {
-        const uint32_t a0 = lane < c ? idx[lane] : 0xFFFFFFFFu, a1 = 64u + lane < c ? idx[64u + lane] : 0xFFFFFFFFu;
-        const uint32_t n0 = min(c, 64u), n1 = c - n0;
-        uint32_t r0 = 0, r1 = 0;
-        // (lanes past the segment hold all-ones: never below a real index, so the steps run in fours without a remainder)
-        auto steps = [&](uint32_t src, uint32_t cnt) {
-            for (uint32_t j = 0; j < cnt; j += 4) {
-                const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)j), v1 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 1u));
-                const uint32_t v2 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 2u)), v3 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 3u));
-                r0 += (v0 < a0 ? 1u : 0u) + (v1 < a0 ? 1u : 0u) + (v2 < a0 ? 1u : 0u) + (v3 < a0 ? 1u : 0u);
-                r1 += (v0 < a1 ? 1u : 0u) + (v1 < a1 ? 1u : 0u) + (v2 < a1 ? 1u : 0u) + (v3 < a1 ? 1u : 0u);
+// element e of the sequence = register e >> 6, lane e & 63; runs ascend where (e & K) == 0 (K = the whole network: everywhere)
+template <int R, int K, int J>
+__device__ __forceinline__ void bitonic_step(uint32_t (&x)[R], uint32_t lane) {
+    if constexpr (J >= 64) {   // the partner is another register of the same lane
+        constexpr int jj = J / 64;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((r & jj) == 0) {
+                const bool up = K >= 64 * R ? true : ((r * 64) & K) == 0;
+                const uint32_t lo = min(x[r], x[r | jj]), hi = max(x[r], x[r | jj]);
+                x[r] = up ? lo : hi; x[r | jj] = up ? hi : lo;
             }
-        };
-        steps(a0, n0);
-        if (n1) steps(a1, n1);
-        if (lane < c) keys[r0] = hi | a0;
-        if (64u + lane < c) keys[r1] = hi | a1;
-        return;
+    } else {
+        const bool lower = (lane & (uint32_t)J) == 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool up = K >= 64 * R ? true : K < 64 ? (lane & (uint32_t)K) == 0u : ((r * 64) & K) == 0;
+            const uint32_t y = (uint32_t)__shfl_xor((int)x[r], J, 64);
+            x[r] = (lower == up) ? min(x[r], y) : max(x[r], y);
+        }
     }
+}
+template <int R, int K, int J>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&x)[R], uint32_t lane) {
+    bitonic_step<R, K, J>(x, lane);
+    if constexpr (J > 1) bitonic_merge<R, K, J / 2>(x, lane);
+}
+template <int R, int K = 2>
+__device__ __forceinline__ void bitonic_sort(uint32_t (&x)[R], uint32_t lane) {
+    bitonic_merge<R, K, K / 2>(x, lane);
+    if constexpr (K < 64 * R) bitonic_sort<R, K * 2>(x, lane);
+}
+template <int R>
+__device__ __forceinline__ void sort_segment_regs(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
+    uint32_t x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = (uint32_t)r * 64u + lane < c ? idx[(uint32_t)r * 64u + lane] : 0xFFFFFFFFu;
+    bitonic_sort<R>(x, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if ((uint32_t)r * 64u + lane < c) keys[(uint32_t)r * 64u + lane] = hi | x[r];
+}
+__device__ __forceinline__ void rank_segment(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
+    if (c <= 64u) { sort_segment_regs<1>(idx, c, hi, keys, lane); return; }
+    if (c <= 128u) { sort_segment_regs<2>(idx, c, hi, keys, lane); return; }
+    if (c <= 256u) { sort_segment_regs<4>(idx, c, hi, keys, lane); return; }
     for (uint32_t c0 = 0; c0 < c; c0 += (uint32_t)kBinRankRows * 64u) {
         uint32_t a[kBinRankRows], rank[kBinRankRows];
 #pragma unroll
