@@ -639,6 +639,19 @@ static hipError_t spin_wait(ffh_ctx *ctx, unsigned long long *out /* 16 words, n
     return hipSuccess;
 }
 
+template <typename T>
+static hipError_t grow_keep(DevBuf<T> &b, size_t used, size_t need, hipStream_t st) {  // like reserve, but the first `used` elements survive
+    if (need <= b.cap) return hipSuccess;
+    DevBuf<T> nb;
+    hipError_t e = nb.reserve(std::max(need, b.cap + b.cap / 2));
+    if (e != hipSuccess) return e;
+    if (used) e = hipMemcpyAsync(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { nb.release(); return e; }
+    b = std::move(nb);
+    return hipSuccess;
+}
+
 // =============================================================================================================
 // C ABI
 // =============================================================================================================
@@ -1090,6 +1103,76 @@ static int select_images(ffh_ctx *ctx, int max_mm) {
     return FFH_OK;
 }
 
+// ---- order n keys (guide << tbits | database index; `n_real` of them hits, the rest all-ones chunk padding) by (guide, index) and leave
+// every guide's segment in seg_begin / seg_end (cleared by the caller; indices relative to the ordered array) ----
+// keys = base of the n records; alt_buf + alt_off = a scratch range of the same length.  *sorted = where the ordered records are (keys
+// or the scratch range), *n_out = how many there are (the bin path drops the padding, the others sort it behind the hits).
+//   up to 4096 records          one block, bitonic network in LDS
+//   a moderate number of hits   (round 5) one unstable most-significant-digit pass into 2^B bins of a few thousand + one launch that orders
+//                               every bin inside LDS and leaves the segment bounds (ffh_prims.hpp: k_msd_*, k_binsort)
+//   > 256 hits per guide        the device-wide LSD sort over all key bits: segments of thousands of hits -- a 5-mismatch scan, guides
+//                               inside repeat families -- are what the device-wide passes are good at
+//   otherwise                   two device-wide passes over the guide bits, then one wave per guide orders its segment (k_segsort; guides
+//                               inside repeat families go to k_segsort_heavy)
+// FFH_SORT=lsd / seg / bin forces one (A/B runs, tests).
+static int order_hits(ffh_ctx *ctx, hipStream_t st, uint64_t *keys, DevBuf<uint64_t> &alt_buf, uint64_t alt_off, uint64_t n, uint64_t n_real, int gbits, uint32_t n_guides,
+                      uint32_t *seg_begin, uint32_t *seg_end, uint64_t **sorted, uint64_t *n_out) {
+    *sorted = keys; *n_out = n;
+    if (!n) return FFH_OK;
+    const bool full_lsd = ctx->sw.sort_mode == 1, force_seg = ctx->sw.sort_mode == 2, force_bin = ctx->sw.sort_mode == 3;
+    bool segments_done = false;
+    if (n <= kSmallSort) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, keys, (uint32_t)n);
+    else {
+        const uint32_t nbk = sort_nblocks(n);
+        FFH_HIP(alt_buf.reserve(std::max<size_t>(ctx->hits.cap, (size_t)(alt_off + n))));
+        uint64_t *alt = alt_buf.p + alt_off;
+        FFH_HIP(ctx->sort_table.reserve((size_t)kSortTableDigits * nbk + 1));
+        FFH_HIP(ctx->sort_offs.reserve((size_t)kSortTableDigits * nbk + 1));
+        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
+        SortScratch ss;
+        ss.alt = alt; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
+        const bool many = n > 256ull * std::max<uint32_t>(n_guides, 1u);
+        int B = 0;
+        while (B < std::min(gbits, (int)kMsdMaxBits) && (n >> B) > 4096) ++B;
+        const int sub_bits = gbits - B;
+        const bool bins_fit = sub_bits <= kBinMaxSubBits && (double)n / (double)(1u << B) <= 0.65 * kBinCap;
+        uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup: every call here follows a compare launch)
+        if (bins_fit && !full_lsd && !force_seg && (!many || force_bin)) {
+            const uint32_t nbins = 1u << B, nbm = msd_nblocks(n);
+            const int shift = ctx->tbits + gbits - B;
+            FFH_HIP(ctx->sort_table.reserve((size_t)nbins * nbm + 1));
+            FFH_HIP(ctx->sort_offs.reserve((size_t)nbins * nbm + 1));
+            FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)nbins * nbm)));
+            FFH_HIP(ctx->heavy_list.reserve((size_t)std::max<uint32_t>(n_guides, nbins) + 1));
+            hipLaunchKernelGGL(k_msd_hist, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)keys, n, shift, nbins, ctx->tbits, n_guides, ctx->sort_table.p, nbm);
+            exclusive_scan<uint32_t, uint32_t>(ctx->sort_table.p, (uint64_t)nbins * nbm, ctx->sort_offs.p, ctx->scan_tmp32.p, st);
+            hipLaunchKernelGGL(k_msd_scatter, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)keys, alt, n, shift, nbins, ctx->tbits, n_guides, (const uint32_t *)ctx->sort_offs.p, nbm);
+            // (the scatter dropped the chunk padding: from here on the array holds the n_real hits, contiguously)
+            hipLaunchKernelGGL(k_binsort, dim3(nbins), dim3(kMsdThreads), 0, st, alt, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, n_real, ctx->tbits, sub_bits, n_guides, seg_begin,
+                               seg_end, ctx->heavy_list.p, n_heavy);
+            hipLaunchKernelGGL(k_binsort_heavy, dim3(256), dim3(256), 0, st, alt, keys, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, n_real, (const uint32_t *)ctx->heavy_list.p,
+                               (const uint32_t *)n_heavy, ctx->tbits, sub_bits, n_guides, seg_begin, seg_end);
+            *sorted = alt; *n_out = n_real;
+            segments_done = true;
+        } else if (full_lsd || (many && !force_seg)) *sorted = radix_sort_u64(keys, n, 0, ctx->tbits + gbits, 64, 64, ss, st);
+        else {
+            FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
+            uint64_t *by_guide = radix_sort_u64(keys, n, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);
+            uint64_t *other = by_guide == keys ? alt : keys;
+            hipLaunchKernelGGL(k_segments, dim3(blocks_for(n, 256)), dim3(256), 0, st, by_guide, n, ctx->tbits, n_guides, seg_begin, seg_end);
+            hipLaunchKernelGGL(k_segsort, dim3(blocks_for(n_guides, 4)), dim3(256), 0, st, by_guide, (const uint32_t *)seg_begin, (const uint32_t *)seg_end, n_guides, ctx->tbits,
+                               ctx->heavy_list.p, n_heavy);
+            hipLaunchKernelGGL(k_segsort_heavy, dim3(512), dim3(256), 0, st, by_guide, other, (const uint32_t *)seg_begin, (const uint32_t *)seg_end, (const uint32_t *)ctx->heavy_list.p,
+                               (const uint32_t *)n_heavy, ctx->tbits);
+            *sorted = by_guide;
+            segments_done = true;
+        }
+    }
+    if (!segments_done) hipLaunchKernelGGL(k_segments, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const uint64_t *)*sorted, n, ctx->tbits, n_guides, seg_begin, seg_end);
+    FFH_HIP(hipGetLastError());
+    return FFH_OK;
+}
+
 // Address and capacity of every device buffer the candidate-list / work-list launches of a scan read or write (prepare_side, side_plan
 // and the SideArgs they fill), folded into one word: a captured sequence is replayed only while this is what it was when the sequence
 // was captured.  Per context: another context's allocations (another shard's thread, a finalize buffer that grows) do not touch it.
@@ -1388,6 +1471,10 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         }
         if (sl + 1 == slabs.size()) break;
         // ---- the slab's positions per guide -> who is still below the limit -> the packed guide set of the next slab ----
+        // (Round 5 tried ordering every slab completely as it ends -- k_segsort + k_segsort_heavy per slab, the target longs kept -- and
+        // concatenating the slabs' segments per guide instead of the final device-wide sort: 10.0 against 8.3 ms per step of the
+        // repeat-structured workload.  A wave per guide has a floor of ~0.22 ms per launch, paid six times, and the guides inside
+        // repeat families went through the block-level sort six times: profiles/r05/ab_log.txt 4.)
         const uint64_t n_new = cursor_before - slab_start;
         FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, (size_t)n_guides * 4, st));
         FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, (size_t)n_guides * 4, st));
@@ -1402,7 +1489,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
                 FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
                 SortScratch ss;
                 ss.alt = ctx->hits_alt.p + slab_start; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-                // by guide only (three passes instead of six): the totals do not depend on the order inside a guide's segment
+                // by guide only (two passes instead of five): the totals do not depend on the order inside a guide's segment
                 sp = radix_sort_u64(sp, n_new, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);   // (either buffer then holds a permutation of the slab's records)
             }
             hipLaunchKernelGGL(k_segments, dim3(blocks_for(n_new, 256)), dim3(256), 0, st, (const uint64_t *)sp, n_new, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
@@ -1423,75 +1510,17 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         ctx->tm.retired_guides = n_guides - still;
         act_guides = ctx->g_active.p; act_map = ctx->g_map.p; n_act = still;
     }
+    ctx->n_raw = cursor_before;
+    FFH_HIP(hipEventRecord(ctx->ev[5], st));
     if (bounded) {   // (k_guide_keys cleared nothing: the slabs' own segments are in the arrays)
         FFH_HIP(hipMemsetAsync(ctx->seg_begin.p, 0, (size_t)n_guides * 4, st));
         FFH_HIP(hipMemsetAsync(ctx->seg_end.p, 0, (size_t)n_guides * 4, st));
     }
-    ctx->n_raw = cursor_before;
-    FFH_HIP(hipEventRecord(ctx->ev[5], st));
     // ---- order the hits by (guide, database index) ----
-    // Two device-wide passes group them by guide, then one wave per guide orders its segment by ranking (ffh_prims.hpp: k_segsort;
-    // guides inside repeat families go to k_segsort_heavy).  FFH_SORT=lsd keeps the six-pass LSD sort over all key bits (A/B).
-    const bool full_lsd = ctx->sw.sort_mode == 1, force_seg = ctx->sw.sort_mode == 2;   // FFH_SORT: force one of the two (A/B runs, tests of the heavy-segment path)
-    ctx->hits_sorted = ctx->hits.p;
-    bool segments_done = false;
-    if (ctx->n_raw && ctx->n_raw <= kSmallSort) {
-        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, ctx->hits.p, (uint32_t)ctx->n_raw);
-    } else if (ctx->n_raw) {
-        const uint32_t nbk = sort_nblocks(ctx->n_raw);
-        FFH_HIP(ctx->hits_alt.reserve(ctx->hits.cap));
-        FFH_HIP(ctx->sort_table.reserve((size_t)kSortTableDigits * nbk + 1));
-        FFH_HIP(ctx->sort_offs.reserve((size_t)kSortTableDigits * nbk + 1));
-        FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)kSortTableDigits * nbk)));
-        SortScratch ss;
-        ss.alt = ctx->hits_alt.p; ss.table = ctx->sort_table.p; ss.offs = ctx->sort_offs.p; ss.scan_tmp = ctx->scan_tmp32.p;
-        // (segments of thousands of hits -- a 5-mismatch scan, guides inside repeat families -- are what the device-wide passes are
-        // good at: beyond 256 raw hits per guide on average the six-pass sort is taken)
-        const bool many = ctx->n_raw > 256ull * std::max<uint32_t>(n_guides, 1u);
-        // (round 5) a moderate number of hits -- a few thousand per bin of <= 2048 guides: one unstable most-significant-digit pass into
-        // 2^B bins + one launch that orders every bin inside LDS and leaves the segment bounds (ffh_prims.hpp: k_msd_*, k_binsort)
-        int B = 0;
-        while (B < std::min(gbits, (int)kMsdMaxBits) && (ctx->n_raw >> B) > 4096) ++B;
-        const int sub_bits = gbits - B;
-        const bool bins_fit = sub_bits <= kBinMaxSubBits && (double)ctx->n_raw / (double)(1u << B) <= 0.65 * kBinCap;
-        if (bins_fit && !full_lsd && !force_seg && (!many || ctx->sw.sort_mode == 3)) {
-            const uint32_t nbins = 1u << B, nbm = msd_nblocks(ctx->n_raw);
-            const int shift = ctx->tbits + gbits - B;
-            FFH_HIP(ctx->sort_table.reserve((size_t)nbins * nbm + 1));
-            FFH_HIP(ctx->sort_offs.reserve((size_t)nbins * nbm + 1));
-            FFH_HIP(ctx->scan_tmp32.reserve(scan_scratch_elems_safe((uint64_t)nbins * nbm)));
-            FFH_HIP(ctx->heavy_list.reserve((size_t)std::max<uint32_t>(n_guides, nbins) + 1));
-            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup)
-            hipLaunchKernelGGL(k_msd_hist, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)ctx->hits.p, ctx->n_raw, shift, nbins, ctx->tbits, n_guides, ctx->sort_table.p, nbm);
-            exclusive_scan<uint32_t, uint32_t>(ctx->sort_table.p, (uint64_t)nbins * nbm, ctx->sort_offs.p, ctx->scan_tmp32.p, st);
-            hipLaunchKernelGGL(k_msd_scatter, dim3(nbm), dim3(kMsdThreads), 0, st, (const uint64_t *)ctx->hits.p, ctx->hits_alt.p, ctx->n_raw, shift, nbins, ctx->tbits, n_guides,
-                               (const uint32_t *)ctx->sort_offs.p, nbm);
-            // (the scatter dropped the chunk padding: from here on the scan holds its n_real_hits real hits, contiguously)
-            hipLaunchKernelGGL(k_binsort, dim3(nbins), dim3(kMsdThreads), 0, st, ctx->hits_alt.p, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, (uint64_t)n_real_hits, ctx->tbits,
-                               sub_bits, n_guides, ctx->seg_begin.p, ctx->seg_end.p, ctx->heavy_list.p, n_heavy);
-            hipLaunchKernelGGL(k_binsort_heavy, dim3(256), dim3(256), 0, st, ctx->hits_alt.p, ctx->hits.p, (const uint32_t *)ctx->sort_offs.p, nbm, nbins, (uint64_t)n_real_hits,
-                               (const uint32_t *)ctx->heavy_list.p, (const uint32_t *)n_heavy, ctx->tbits, sub_bits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
-            ctx->hits_sorted = ctx->hits_alt.p;
-            ctx->n_raw = n_real_hits;
-            segments_done = true;
-        } else if (full_lsd || (many && !force_seg)) ctx->hits_sorted = radix_sort_u64(ctx->hits.p, ctx->n_raw, 0, ctx->tbits + gbits, 64, 64, ss, st);
-        else {
-            FFH_HIP(ctx->heavy_list.reserve((size_t)n_guides + 1));
-            uint32_t *n_heavy = (uint32_t *)(ctx->d_counters + 13);   // (cleared by k_compare_setup)
-            uint64_t *by_guide = radix_sort_u64(ctx->hits.p, ctx->n_raw, ctx->tbits, ctx->tbits + gbits, 64, 64, ss, st);
-            uint64_t *other = by_guide == ctx->hits.p ? ctx->hits_alt.p : ctx->hits.p;
-            hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, by_guide, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
-            hipLaunchKernelGGL(k_segsort, dim3(blocks_for(n_guides, 4)), dim3(256), 0, st, by_guide, (const uint32_t *)ctx->seg_begin.p, (const uint32_t *)ctx->seg_end.p, n_guides,
-                               ctx->tbits, ctx->heavy_list.p, n_heavy);
-            hipLaunchKernelGGL(k_segsort_heavy, dim3(512), dim3(256), 0, st, by_guide, other, (const uint32_t *)ctx->seg_begin.p, (const uint32_t *)ctx->seg_end.p,
-                               (const uint32_t *)ctx->heavy_list.p, (const uint32_t *)n_heavy, ctx->tbits);
-            ctx->hits_sorted = by_guide;
-            segments_done = true;
-        }
+    {
+        const int rc = order_hits(ctx, st, ctx->hits.p, ctx->hits_alt, 0, ctx->n_raw, n_real_hits, gbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p, &ctx->hits_sorted, &ctx->n_raw);
+        if (rc) return rc;
     }
-    // seg_begin / seg_end were cleared by the prefix-side k_guide_keys of every batch
-    if (ctx->n_raw && !segments_done)
-        hipLaunchKernelGGL(k_segments, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, n_guides, ctx->seg_begin.p, ctx->seg_end.p);
     ctx->hit_t_ready = false;  // the target longs of the hits are gathered on demand (gather_hit_targets)
     FFH_HIP(hipEventRecord(ctx->ev[6], st));
     FFH_HIP(hipGetLastError());
@@ -1945,19 +1974,6 @@ static void site_pattern(int enzyme, SitePattern &p) {  // fwdRegex / revRegex, 
         case 3: case 6: p.fwd[L - 2] = G; p.fwd[L - 1] = G; p.rev[0] = Cc; p.rev[1] = Cc; break;                  // NGG      /  CCN   (:148-150, :170-172)
         case 4: p.fwd[L - 2] = A; p.fwd[L - 1] = G; p.rev[0] = Cc; p.rev[1] = T; break;                            // NAG      /  CTN   (:192-194)
     }
-}
-
-template <typename T>
-static hipError_t grow_keep(DevBuf<T> &b, size_t used, size_t need, hipStream_t st) {  // like reserve, but the first `used` elements survive
-    if (need <= b.cap) return hipSuccess;
-    DevBuf<T> nb;
-    hipError_t e = nb.reserve(std::max(need, b.cap + b.cap / 2));
-    if (e != hipSuccess) return e;
-    if (used) e = hipMemcpyAsync(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { nb.release(); return e; }
-    b = std::move(nb);
-    return hipSuccess;
 }
 
 extern "C" {

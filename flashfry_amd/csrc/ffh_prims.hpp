@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ffh {
 
@@ -340,6 +341,39 @@ __global__ __launch_bounds__(1024) void k_sort_small(uint64_t *__restrict__ keys
 // and one write of the keys.  Segments beyond kSegWaveMax keys (guides inside repeat families) are listed and ordered by
 // k_segsort_heavy, one block each, with an LSD sort of its own over the segment.
 // ---------------------------------------------------------------------------------------------------------
+// ---- a bitonic network over R registers per lane of one wave (64 R elements) ----
+// element e of the sequence = register e >> 6, lane e & 63; runs ascend where (e & K) == 0 (K = the whole network: everywhere)
+template <int R, int K, int J>
+__device__ __forceinline__ void bitonic_step(uint32_t (&x)[R], uint32_t lane) {
+    if constexpr (J >= 64) {   // the partner is another register of the same lane
+        constexpr int jj = J / 64;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((r & jj) == 0) {
+                const bool up = K >= 64 * R ? true : ((r * 64) & K) == 0;
+                const uint32_t lo = min(x[r], x[r | jj]), hi = max(x[r], x[r | jj]);
+                x[r] = up ? lo : hi; x[r | jj] = up ? hi : lo;
+            }
+    } else {
+        const bool lower = (lane & (uint32_t)J) == 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool up = K >= 64 * R ? true : K < 64 ? (lane & (uint32_t)K) == 0u : ((r * 64) & K) == 0;
+            const uint32_t y = (uint32_t)__shfl_xor((int)x[r], J, 64);
+            x[r] = (lower == up) ? min(x[r], y) : max(x[r], y);
+        }
+    }
+}
+template <int R, int K, int J>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&x)[R], uint32_t lane) {
+    bitonic_step<R, K, J>(x, lane);
+    if constexpr (J > 1) bitonic_merge<R, K, J / 2>(x, lane);
+}
+template <int R, int K = 2>
+__device__ __forceinline__ void bitonic_sort(uint32_t (&x)[R], uint32_t lane) {
+    bitonic_merge<R, K, K / 2>(x, lane);
+    if constexpr (K < 64 * R) bitonic_sort<R, K * 2>(x, lane);
+}
 constexpr uint32_t kSegWaveMax = 1024;
 constexpr int kSegRows = kSegWaveMax / 64;
 
@@ -371,25 +405,25 @@ __global__ __launch_bounds__(256) void k_segsort(uint64_t *__restrict__ keys, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (K <= 2u) {
-        // the usual segment (<= 128 keys, two per lane): the other keys come through v_readlane, four per step -- no memory round trip
-        // in the loop (an LDS broadcast per key made the wave wait ~100 cycles 116 times: 370 us for the 100 000 guides of the
-        // hg38-scale step; one v_readlane per key 205 us)
-        const uint32_t a0 = (uint32_t)k[0] & mask, a1 = K > 1u ? (uint32_t)k[1] & mask : 0u;   // (a lane without a second key never writes rank[1])
-        const uint32_t n0 = min(n, 64u), n1 = n - n0;
-        uint32_t r0 = 0, r1 = 0;
-        // (lanes past the segment hold all-ones keys: never below a real key, so the steps run in fours without a remainder)
-        auto steps = [&](uint32_t src, uint32_t cnt) {
-            for (uint32_t j = 0; j < cnt; j += 4) {
-                const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)j), v1 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 1u));
-                const uint32_t v2 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 2u)), v3 = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(j + 3u));
-                r0 += (v0 < a0 ? 1u : 0u) + (v1 < a0 ? 1u : 0u) + (v2 < a0 ? 1u : 0u) + (v3 < a0 ? 1u : 0u);
-                r1 += (v0 < a1 ? 1u : 0u) + (v1 < a1 ? 1u : 0u) + (v2 < a1 ? 1u : 0u) + (v3 < a1 ? 1u : 0u);
-            }
+    if (K <= 4u) {
+        // the usual segment (<= 256 keys): a bitonic network over the keys' low words in registers -- no memory round trip, ~230
+        // instructions for 65 .. 128 keys (round 4 ranked every key against all others: four v_readlane + eight v_cmp per four keys)
+        const uint64_t hi = k[0] & ~(uint64_t)mask;   // (lane 0 always holds a key of the segment: n >= 2)
+        const uint64_t hi_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hi >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hi);
+        auto run = [&](auto rtag) {
+            constexpr int R = decltype(rtag)::value;
+            uint32_t x[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = (uint32_t)r * 64u + lane < n ? ((uint32_t)k[r] & mask) : 0xFFFFFFFFu;
+            bitonic_sort<R>(x, lane);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((uint32_t)r * 64u + lane < n) keys[b + (uint32_t)r * 64u + lane] = hi_u | x[r];
         };
-        steps(lane < n0 ? ((uint32_t)k[0] & mask) : 0xFFFFFFFFu, n0);
-        steps(lane < n1 ? ((uint32_t)k[1] & mask) : 0xFFFFFFFFu, n1);
-        rank[0] = r0; rank[1] = r1;
+        if (K <= 1u) run(std::integral_constant<int, 1>{});
+        else if (K <= 2u) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 4>{});
+        return;
     } else {
         // larger segments: the low words from LDS, four per (broadcast) read
         const uint32_t n4 = (n + 3u) & ~3u;
@@ -619,38 +653,6 @@ __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__r
 // Beyond 256 keys: ranking against the whole segment out of LDS, four keys per broadcast step, the lane's own keys in chunks of
 // kBinRankRows x 64.
 constexpr int kBinRankRows = 8;
-// element e of the sequence = register e >> 6, lane e & 63; runs ascend where (e & K) == 0 (K = the whole network: everywhere)
-template <int R, int K, int J>
-__device__ __forceinline__ void bitonic_step(uint32_t (&x)[R], uint32_t lane) {
-    if constexpr (J >= 64) {   // the partner is another register of the same lane
-        constexpr int jj = J / 64;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((r & jj) == 0) {
-                const bool up = K >= 64 * R ? true : ((r * 64) & K) == 0;
-                const uint32_t lo = min(x[r], x[r | jj]), hi = max(x[r], x[r | jj]);
-                x[r] = up ? lo : hi; x[r | jj] = up ? hi : lo;
-            }
-    } else {
-        const bool lower = (lane & (uint32_t)J) == 0u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool up = K >= 64 * R ? true : K < 64 ? (lane & (uint32_t)K) == 0u : ((r * 64) & K) == 0;
-            const uint32_t y = (uint32_t)__shfl_xor((int)x[r], J, 64);
-            x[r] = (lower == up) ? min(x[r], y) : max(x[r], y);
-        }
-    }
-}
-template <int R, int K, int J>
-__device__ __forceinline__ void bitonic_merge(uint32_t (&x)[R], uint32_t lane) {
-    bitonic_step<R, K, J>(x, lane);
-    if constexpr (J > 1) bitonic_merge<R, K, J / 2>(x, lane);
-}
-template <int R, int K = 2>
-__device__ __forceinline__ void bitonic_sort(uint32_t (&x)[R], uint32_t lane) {
-    bitonic_merge<R, K, K / 2>(x, lane);
-    if constexpr (K < 64 * R) bitonic_sort<R, K * 2>(x, lane);
-}
 template <int R>
 __device__ __forceinline__ void sort_segment_regs(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
     uint32_t x[R];
