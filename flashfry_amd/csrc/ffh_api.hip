@@ -280,7 +280,7 @@ struct ffh_ctx {
     // candidate binning and work list of one image
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
-    DevBuf<uint32_t> wl_count[2], wl_off[2];               // work entries per batch of buckets, their scan
+    DevBuf<uint32_t> wl_count[2];                             // work entries per batch of buckets + per block of 1024 batches
     DevBuf<WorkEntry> wl_list[2];                             // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint32_t> sort_table, sort_offs, heavy_list;
@@ -574,9 +574,8 @@ static int prepare_side(ffh_ctx *ctx, hipStream_t st, int which, const Image &im
     // those runs: no intermediate records (ffh_kernels.hpp: k_item_bin_direct)
     FFH_HIP(sc.gp_start.reserve((size_t)ig.n_part + 2));
     FFH_HIP(sc.by_part.reserve((size_t)ng + 1));
-    exclusive_scan<uint32_t, uint32_t>(sc.part_hist.p, ig.n_part, sc.gp_start.p, sc.scan_tmp.p, st);
     hipLaunchKernelGGL(k_guide_by_part, dim3(blocks_for(ng, 1024)), dim3(1024), 0, st, (const uint32_t *)gbucket.p, ng, ig.low_bits, ig.n_part,
-                       (const uint32_t *)sc.gp_start.p, part_fill, sc.by_part.p);
+                       (const uint32_t *)sc.part_hist.p, sc.gp_start.p, part_fill, sc.by_part.p);
     if (!filtered) hipLaunchKernelGGL(k_part_sizes, dim3(blocks_for(ig.n_part, 4)), dim3(256), 0, st, sc.part_hist.p, patterns.p, ig, part_bits, part_count);
     else hipLaunchKernelGGL((k_item_bin_direct<true, true>), dim3(ig.n_part), dim3(kPartThreads), 0, st, (const uint32_t *)sc.gp_start.p, (const uint32_t *)sc.by_part.p,
                             (const uint32_t *)patterns.p, ig, part_bits, (const uint32_t *)nullptr, part_count, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
@@ -703,7 +702,7 @@ ffh_ctx *ffh_create(int device_id, int enzyme_index) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_counters, kCounterWords * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_pub, 32 * sizeof(unsigned long long), hipHostMallocMapped);
     if (e == hipSuccess) { std::memset(ctx->h_pub, 0, 32 * sizeof(unsigned long long)); e = hipHostGetDevicePointer((void **)&ctx->d_pub, ctx->h_pub, 0); }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tab, sizeof(ScoreTables));
@@ -1121,7 +1120,15 @@ static int order_hits(ffh_ctx *ctx, hipStream_t st, uint64_t *keys, DevBuf<uint6
     if (!n) return FFH_OK;
     const bool full_lsd = ctx->sw.sort_mode == 1, force_seg = ctx->sw.sort_mode == 2, force_bin = ctx->sw.sort_mode == 3;
     bool segments_done = false;
-    if (n <= kSmallSort) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, keys, (uint32_t)n);
+    if (n <= kBinCap && gbits <= kBinMaxSubBits && !full_lsd && !force_seg) {
+        // a small scan (a chr22-scale call: a few thousand records, <= 2048 guides): k_binsort alone, one block, in place -- the records
+        // counted per guide in LDS, every guide's indices ordered by a wave, segment bounds left behind; the chunk padding is dropped
+        // (round 4: a 4096-key bitonic network in one block, 52 us, + k_segments)
+        hipLaunchKernelGGL(k_binsort, dim3(1), dim3(kMsdThreads), 0, st, keys, (const uint32_t *)nullptr, 0u, 1u, n, ctx->tbits, gbits, n_guides, seg_begin, seg_end,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr);
+        *n_out = n_real;
+        segments_done = true;
+    } else if (n <= kSmallSort) hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 0, st, keys, (uint32_t)n);
     else {
         const uint32_t nbk = sort_nblocks(n);
         FFH_HIP(alt_buf.reserve(std::max<size_t>(ctx->hits.cap, (size_t)(alt_off + n))));
@@ -1190,7 +1197,7 @@ static uint64_t prep_signature(const ffh_ctx *ctx, const Image &suffix) {
         const ffh_ctx::SideScratch &sc = ctx->side_scr[w];
         mix(sc.part_fill.p, sc.part_fill.cap); mix(sc.part_hist.p, sc.part_hist.cap); mix(sc.part_start.p, sc.part_start.cap);
         mix(sc.gp_start.p, sc.gp_start.cap); mix(sc.by_part.p, sc.by_part.cap); mix(sc.scan_tmp.p, sc.scan_tmp.cap);
-        mix(ctx->wl_count[w].p, ctx->wl_count[w].cap); mix(ctx->wl_off[w].p, ctx->wl_off[w].cap); mix(ctx->wl_list[w].p, ctx->wl_list[w].cap);
+        mix(ctx->wl_count[w].p, ctx->wl_count[w].cap); mix(ctx->wl_list[w].p, ctx->wl_list[w].cap);
         const Image &im = w == 0 ? ctx->img[0] : suffix;
         mix(im.bstart.p, im.bstart.cap); mix(im.gstart.p, im.gstart.cap); mix(im.gwords.p, im.gwords.cap); mix(im.tidx.p, im.tidx.cap); mix(im.live.p, im.live.cap);
     }
@@ -1267,20 +1274,20 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
         }
         // (what a guide set without pile-ups needs; one that needs more is noticed after the launch, which then runs again: below)
         const uint64_t max_entries = (uint64_t)n_bat + 2 * ((n_targets / 32 + S.nb) / S.split + 1) + (uint64_t)((double)ng * n_patterns) / kKC + 2;
-        FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + 1));
-        FFH_HIP(ctx->wl_off[which].reserve((size_t)n_bat + 2));
-        // (FFH_WORK_LIST_LIMIT: test aid -- a first list that small, so that the run-again path below is taken)
         FFH_HIP(ctx->wl_list[which].reserve(ctx->sw.work_list_limit > 0 ? std::min<size_t>((size_t)max_entries, (size_t)ctx->sw.work_list_limit) : (size_t)max_entries));
-        FFH_HIP(ctx->side_scr[which].scan_tmp.reserve(scan_scratch_elems_safe(n_bat)));
-        hipLaunchKernelGGL(k_work_count, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat,
-                           ctx->wl_count[which].p, (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u,
-                           ctx->d_counters + kStatPairs + which, rank_lo, rank_hi, (uint32_t)width);
-        exclusive_scan<uint32_t, uint32_t>(ctx->wl_count[which].p, n_bat, ctx->wl_off[which].p, ctx->side_scr[which].scan_tmp.p, st);
         S.list_cap = (uint32_t)std::min<size_t>(ctx->wl_list[which].cap, 0xFFFFFFF0u);
-        hipLaunchKernelGGL(k_work_fill, dim3(blocks_for(n_bat, 256)), dim3(256), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat, ctx->wl_off[which].p,
-                           ctx->wl_list[which].p, S.list_cap, ctx->d_counters + kStatEntries + which, rank_lo, rank_hi, (uint32_t)width);
+        // (FFH_WORK_LIST_LIMIT: test aid -- a first list that small, so that the run-again path below is taken)
+        const unsigned wblocks = blocks_for(n_bat, kWorkThreads);
+        FFH_HIP(ctx->wl_count[which].reserve((size_t)n_bat + wblocks + 64));   // [n_bat counts][wblocks block sums][.. the list's length]
+        uint32_t *counts = ctx->wl_count[which].p, *block_sums = counts + n_bat;
+        hipLaunchKernelGGL(k_work_count, dim3(wblocks), dim3(kWorkThreads), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat, counts, block_sums,
+                           (const unsigned long long *)ctx->part_pairs[which].p, count_pairs ? ctx->n_part[which] : 0u, ctx->d_counters + kStatPairs + which, rank_lo, rank_hi,
+                           (uint32_t)width);
+        hipLaunchKernelGGL(k_work_fill, dim3(wblocks), dim3(kWorkThreads), 0, st, im.gstart.p, ctx->istart[which].p, S.nb, S.NB, S.split, n_bat, (const uint32_t *)counts,
+                           (const uint32_t *)block_sums, ctx->wl_list[which].p, S.list_cap, ctx->d_counters + kStatEntries + which, block_sums + wblocks + 40, rank_lo, rank_hi,
+                           (uint32_t)width);
         S.list = ctx->wl_list[which].p;
-        S.n_list = ctx->wl_off[which].p + n_bat;
+        S.n_list = block_sums + wblocks + 40;   // (NOT the counter block: the compare launch's waves read this word while their atomics hammer that line)
         return FFH_OK;
     };
     FFH_HIP(hipEventRecord(ctx->ev[0], st));

@@ -58,7 +58,9 @@ constexpr int kGroupsPerLane = FFH_GPL;    // a candidate of a large bucket is s
 constexpr int kMaxParts = 16;             // jobs per candidate at most (park: fewer when a piece has many candidates)
 constexpr int kMinRest = 7, kMaxRest = 12;   // rest-key widths k_compare has a row form for (19-mers with a 12-base bucket key: 7)
 
-constexpr uint32_t kStatPairs = 4, kStatEntries = 6, kQueue = 32, kQueues = 16;   // cursor[32 + 16 side + k]: the side's k-th work queue (chunks drawn so far)
+constexpr uint32_t kStatPairs = 4, kStatEntries = 6, kQueue = 64, kQueues = 16, kQueueStride = 16;   // cursor[64 + 16 (16 side + k)]: the side's k-th work queue (chunks drawn
+// so far), every queue in a 128-byte line of its own (round 5: atomics on different words of ONE line queue behind each other like atomics on one word)
+constexpr uint32_t kCounterWords = kQueue + 2 * kQueues * kQueueStride;   // size of a context's counter block
 // cursor[4 + side]: executed pair tests, cursor[6 + side]: work entries of this launch
 constexpr uint32_t kQueueChunkLong = 16, kQueueChunkMedium = 4;   // work entries a wave draws from its queue at a time (long lists: 8: 1.07, 16 / 32: 1.06 ms per launch;
                                                                   // the medium-length lists of a bounded scan's slabs: 4)
@@ -106,7 +108,7 @@ __global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int fir
     if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
     if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
     if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
-    if (threadIdx.x >= kQueue && threadIdx.x < kQueue + 2 * kQueues) cursor[threadIdx.x] = 0ull;  // the two images' work queues (k_compare)
+    if (threadIdx.x < 2 * kQueues) cursor[kQueue + threadIdx.x * kQueueStride] = 0ull;  // the two images' work queues (k_compare)
     if (FFH_TRIP_STATS && threadIdx.x >= 16 && threadIdx.x < 30) cursor[threadIdx.x] = 0ull;
 }
 
@@ -368,14 +370,10 @@ __device__ __forceinline__ void scan_row(RowCtx &c, uint32_t rest, uint32_t d, u
 
 // ---------------------------------------------------------------------------------------------------------
 // The work list of one image for one compare launch, built from the bucket boundaries and the candidate CSR offsets:
-//   k_work_count  per batch of NB consecutive buckets: 0 entries if it has no candidate or no target, else ceil(groups / split) x
-//                 ceil(candidates / kKC) -- an entry never holds more than the wave's strip and candidate table take (a repeat family's
-//                 bucket with thousands of candidate guides used to be ONE entry per 51 groups, worked off piece by piece by one wave
-//                 while the launch waited for it);
-//                 the launch also adds up the executed-pair statistic (targets x candidates of every bucket) from the partial
-//                 sums k_item_bin left per partition
-//   (scan)
-//   k_work_fill   the entries.  A call with a handful of guides lists a few hundred batches instead of making every wave walk all
+//   k_work_fill   per batch of NB consecutive buckets: no entry if it has no candidate or no target, else ceil(groups / split) x
+//                 ceil(candidates / kKC) of them -- an entry never holds more than the wave's strip and candidate table take (a repeat
+//                 family's bucket with thousands of candidate guides used to be ONE entry per 51 groups, worked off piece by piece by
+//                 one wave while the launch waited for it).  A call with a handful of guides lists a few hundred batches instead of making every wave walk all
 //                 4^11 buckets' boundaries; a bucket of 1e5 targets becomes ~100 entries dealt to ~100 waves.
 // ---------------------------------------------------------------------------------------------------------
 // One slab of a bounded scan on the prefix image, whose candidate CSR is built ONCE for all slabs: the batch's buckets that belong to
@@ -407,27 +405,51 @@ __device__ __forceinline__ WorkSplit work_split(uint32_t ngr, uint32_t nc, uint3
     w.n_c = (nc + cs_n - 1u) / cs_n;
     return w;
 }
-__global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
-                                                    uint32_t n_bat, uint32_t *__restrict__ counts, const unsigned long long *__restrict__ part_pairs,
-                                                    uint32_t n_part, unsigned long long *__restrict__ pairs_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
-    __shared__ unsigned long long red[4];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// (Round 5: two launches per image instead of four.  k_work_count leaves, besides every batch's number of entries, the sum of each block
+// of 1024 batches; a block of k_work_fill adds up the sums of the blocks before it (a few hundred values) and scans its own 1024 counts:
+// the device-wide scan between the two -- two launches -- is gone and the list keeps its bucket order, which the compare launch is
+// sensitive to: handing the blocks their ranges through an atomic, in order of arrival, cost 5 % of the compare launch at hg38 scale
+// and 40 % on the repeat-structured workload, profiles/r05/ab_log.txt 5.)
+constexpr int kWorkThreads = 1024;
+__global__ __launch_bounds__(kWorkThreads) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
+                                                             uint32_t n_bat, uint32_t *__restrict__ counts, uint32_t *__restrict__ block_sums,
+                                                             const unsigned long long *__restrict__ part_pairs, uint32_t n_part, unsigned long long *__restrict__ pairs_out,
+                                                             uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+    __shared__ uint32_t wsum[kWorkThreads / 64];
+    __shared__ unsigned long long red[kWorkThreads / 64];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    uint32_t n = 0;
     if (t < n_bat) {
         uint32_t s0, s1;
         slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
         const uint32_t ngr = gstart[s1] - gstart[s0], nc = istart[s1] - istart[s0];
         const WorkSplit w = work_split(ngr, nc, split, s1 - s0 == 1u);
-        counts[t] = (ngr && nc) ? w.n_g * w.n_c : 0u;
+        n = (ngr && nc) ? w.n_g * w.n_c : 0u;
+        counts[t] = n;
     }
-    if (blockIdx.x != 0) return;
+    uint32_t sum = n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < kWorkThreads / 64; ++k) tot += wsum[k];
+        block_sums[blockIdx.x] = tot;
+    }
+    if (blockIdx.x != 0 || !n_part) return;
     // the executed-pair statistic (targets x candidates of every bucket): k_item_bin left one partial sum per partition
     unsigned long long pairs = 0;
     for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) pairs += part_pairs[d];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) pairs += __shfl_xor(pairs, d, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pairs;
+    if (lane == 0) red[threadIdx.x >> 6] = pairs;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(pairs_out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < kWorkThreads / 64; ++k) tot += red[k];
+        atomicAdd(pairs_out, tot);
+    }
 }
 // A work entry, 32 bytes: what a wave needs to fetch the batch -- first bucket, buckets, groups [g0, g1), candidates [c0, c1) (absolute
 // indices into gwords / gids) -- worked out HERE, once, from the bucket boundaries.  (Round 3's 16-byte entries held {first bucket,
@@ -436,16 +458,41 @@ __global__ __launch_bounds__(256) void k_work_count(const uint32_t *__restrict__
 struct WorkEntry { uint32_t b0, nbv, g0, g1, c0, c1, pad0, pad1; };
 static_assert(sizeof(WorkEntry) == 32, "two 16-byte stores");
 // A thread per batch; a batch with many entries (a repeat family's bucket: hundreds) is written by its whole wave.
-__global__ __launch_bounds__(256) void k_work_fill(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
-                                                   uint32_t n_bat, const uint32_t *__restrict__ offs, WorkEntry *__restrict__ list, uint32_t list_cap,
-                                                   unsigned long long *__restrict__ n_out, uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+__global__ __launch_bounds__(kWorkThreads) void k_work_fill(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
+                                                            uint32_t n_bat, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ block_sums,
+                                                            WorkEntry *__restrict__ list, uint32_t list_cap, unsigned long long *__restrict__ n_out,
+                                                            uint32_t *__restrict__ n_list /* the same number where the compare launch reads it: a line of its own */,
+                                                            uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+    __shared__ uint32_t scan_lds[16];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-    uint32_t o = 0, n = 0, s0 = 0, s1 = 0, gs = 0, ge = 0, is0 = 0, is1 = 0;
-    WorkSplit w{1u, 1u, 0u};
-    if (t < n_bat) {
-        o = offs[t]; n = offs[t + 1] - o;
-        if (t == n_bat - 1) *n_out = offs[n_bat];
+    uint32_t o = 0, n = t < n_bat ? counts[t] : 0u, s0 = 0, s1 = 0, gs = 0, ge = 0, is0 = 0, is1 = 0;
+    {   // entries before this block (the sums of the blocks before it) + before this batch inside the block
+        uint32_t before = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kWorkThreads) before += block_sums[b];
+        uint32_t incl = n, binc = before;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) binc += __shfl_xor(binc, d, 64);
+        if (lane == 63) scan_lds[threadIdx.x >> 6] = incl;
+        __shared__ uint32_t before_lds[kWorkThreads / 64];
+        if (lane == 0) before_lds[threadIdx.x >> 6] = binc;
+        __syncthreads();
+        uint32_t wave_off = 0, tot = 0, base = 0;
+#pragma unroll
+        for (int k = 0; k < kWorkThreads / 64; ++k) {
+            const uint32_t v = scan_lds[k];
+            if ((uint32_t)k < (threadIdx.x >> 6)) wave_off += v;
+            tot += v;
+            base += before_lds[k];
+        }
+        o = base + wave_off + incl - n;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = base + tot; *n_list = base + tot; }
     }
+    WorkSplit w{1u, 1u, 0u};
     if (n) {
         slab_run(t * NB, min(nb, t * NB + NB), rank_lo, rank_hi, width, s0, s1);
         gs = gstart[s0]; ge = gstart[s1];
@@ -525,7 +572,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
             if constexpr (QC == 0) { const uint32_t r = stride_q < n_total ? stride_q : kEnd; stride_q += n_waves; return r; }
             if (chunk_j == chunk_len) {
                 uint32_t t = 0;
-                if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(cursor + kQueue + side * kQueues + my_queue, 1ull);
+                if (chunk < n_chunks && lane == 0) t = (uint32_t)atomicAdd(cursor + kQueue + (side * kQueues + my_queue) * kQueueStride, 1ull);
                 chunk = chunk < n_chunks ? n_waves + my_queue + n_queues * uni(t) : chunk;
                 chunk_j = 0;
             }

@@ -324,11 +324,28 @@ __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__
 // guides grouped by partition: by_part[gp_start[part] + k] = (low bucket bits << kGidBits) | guide.  A block of 1024 guides counts
 // its guides per partition in LDS and reserves one run per partition it touches (an image with few partitions -- the suffix side --
 // put ~400 same-address global atomics on every counter: 47 us; this way a few per block)
+// (round 5: the exclusive scan of the partition histogram -- <= 4096 counters -- is done by every block for itself in LDS instead of in
+// two launches of its own; block 0 leaves it in gp_start for k_item_bin_direct)
 __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
-                                                        const uint32_t *__restrict__ gp_start, uint32_t *__restrict__ gp_fill /* zeroed */,
-                                                        uint32_t *__restrict__ by_part) {
+                                                        const uint32_t *__restrict__ part_hist, uint32_t *__restrict__ gp_start /* [n_part + 1] out */,
+                                                        uint32_t *__restrict__ gp_fill /* zeroed */, uint32_t *__restrict__ by_part) {
     __shared__ uint32_t cnt[1 << kMaxPartBits];
-    for (uint32_t q = threadIdx.x; q < n_part; q += blockDim.x) cnt[q] = 0;
+    __shared__ uint32_t start[1 << kMaxPartBits];
+    __shared__ uint32_t scan_lds[16];
+    {   // start[q] = guides in the partitions before q: four counters per thread
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t q = 4u * threadIdx.x + (uint32_t)k; c[k] = q < n_part ? part_hist[q] : 0u; sum += c[k]; }
+        uint32_t tot;
+        uint32_t off = block_exclusive_scan_1024(sum, scan_lds, tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t q = 4u * threadIdx.x + (uint32_t)k;
+            if (q < n_part) { start[q] = off; cnt[q] = 0; if (blockIdx.x == 0) gp_start[q] = off; }
+            off += c[k];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) gp_start[n_part] = tot;
+    }
     __syncthreads();
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = 0, part = 0, local = 0;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restri
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < n_part; q += blockDim.x) {
         const uint32_t c = cnt[q];
-        if (c) cnt[q] = gp_start[q] + atomicAdd(&gp_fill[q], c);
+        if (c) cnt[q] = start[q] + atomicAdd(&gp_fill[q], c);
     }
     __syncthreads();
     if (g < n_guides) by_part[cnt[part] + local] = ((b & ((1u << low_bits) - 1u)) << kGidBits) | g;

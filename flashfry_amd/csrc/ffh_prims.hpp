@@ -695,7 +695,9 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
     __shared__ uint32_t cnt[(1 << kBinMaxSubBits) + 2], start[(1 << kBinMaxSubBits) + 2];
     __shared__ uint32_t scan_lds[16];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), bin = blockIdx.x;
-    const uint32_t b0 = offs[(uint64_t)bin * nblocks], b1 = bin + 1u < nbins ? offs[(uint64_t)(bin + 1u) * nblocks] : (uint32_t)n_total, n = b1 - b0;
+    // offs == nullptr: ONE bin = all n_total records as the compare launch left them, chunk padding included (a small scan: this launch
+    // is the whole ordering); the padding is dropped as the records are read
+    const uint32_t b0 = offs ? offs[(uint64_t)bin * nblocks] : 0u, b1 = !offs || bin + 1u >= nbins ? (uint32_t)n_total : offs[(uint64_t)(bin + 1u) * nblocks], n = b1 - b0;
     if (n == 0u) return;
     if (n > kBinCap) {
         if (t == 0) heavy_list[atomicAdd(n_heavy, 1u)] = bin;
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
     __syncthreads();
     uint64_t kreg[kBinRows];
     uint16_t rk[kBinRows];
-    auto sub_of = [&](uint64_t key) { return (uint32_t)(key >> tbits) & (nsub - 1u); };
+    auto sub_of = [&](uint64_t key) { const uint32_t g = (uint32_t)(key >> tbits); return g >= n_guides ? nsub : g & (nsub - 1u); };   // (nsub: chunk padding, dropped)
 #pragma unroll
     for (int r = 0; r < kBinRows; ++r) {
         const uint32_t i = (uint32_t)r * kMsdThreads + t;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
 #pragma unroll
     for (int r = 0; r < kBinRows; ++r) {
         const uint32_t i = (uint32_t)r * kMsdThreads + t;
-        if (i < n) idx[start[sub_of(kreg[r])] + rk[r]] = (uint32_t)kreg[r] & mask;
+        if (i < n) idx[start[sub_of(kreg[r])] + rk[r]] = (uint32_t)kreg[r] & mask;   // (padding: behind the last guide's indices, never read)
     }
     __syncthreads();
     // every wave takes guides of the bin; all of the bin's keys are in registers / LDS by now, so writing in place is safe

@@ -102,6 +102,19 @@ def test_compare_kernel_spills_no_registers():
         assert int(re.search(r"waves/SIMD (\d+)", l).group(1)) >= 4, l
 
 
+def test_ordering_kernels_spill_no_registers():
+    """the kernels of the hit ordering (round 5: k_msd_hist, k_msd_scatter, k_binsort, k_binsort_heavy; k_segsort) as hipcc compiles them:
+    no spills, no scratch -- a variant of k_binsort that tested for padding keys in a loop of its own spilled 1216 registers and ran
+    12 x slower (profiles/r05/ab_log.txt 6)"""
+    import re
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kres.sh"), "k_binsort|k_msd_|k_segsort"], capture_output=True, text=True, timeout=600).stdout
+    rows = [l for l in out.splitlines() if "ffh::k_" in l]
+    assert len(rows) >= 6, out
+    for l in rows:
+        assert [int(x) for x in re.findall(r"spilled +(\d+)", l)] == [0, 0], l
+        assert int(re.search(r"scratch +(\d+)", l).group(1)) == 0, l
+
+
 def test_a_box_without_rccl_gets_an_error_not_a_crash():
     """when librccl cannot be opened the communicator entry points return FFH_E_STATE with a message (dlerror() used to be
     called twice -- the second call returns NULL -- and the std::string built from it crashed).  In a process of its own: the
