@@ -301,7 +301,8 @@ struct ffh_ctx {
     DevBuf<uint64_t> ret_off, pos_base, out_target, out_posoff, out_pos;
     DevBuf<uint8_t> out_mm;
     DevBuf<double> out_cfd, out_hsu, out_jost;
-    DevBuf<GuideSummary> summ;
+    DevBuf<GuideSummary> summ, summ_stage;   // (summ_stage / ret_off_stage: what the copy stream reads of a pipelined call's first part)
+    DevBuf<uint64_t> ret_off_stage;
     ScoreTables *d_tab = nullptr;
 
     // The candidate-list / work-list kernels of a scan (~26 launches of a few microseconds each: the host cannot issue them as fast
@@ -314,7 +315,8 @@ struct ffh_ctx {
         SideArgs side[2];
         double expect[2] = {0, 0};
         uint32_t n_part[2] = {0, 0};
-    } pg;
+    } pg_slots[2];        // [1]: the second part of a pipelined ffh_discover (another guide pointer and count: a sequence of its own)
+    int pg_slot = 0;
     hipEvent_t ev[8] = {};
     ffh_timings tm{};
     std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
@@ -728,7 +730,7 @@ void ffh_destroy(ffh_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->st);
-    if (ctx->pg.exec) (void)hipGraphExecDestroy(ctx->pg.exec);
+    for (auto &g : ctx->pg_slots) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
@@ -1352,7 +1354,7 @@ static int scan_impl(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, in
             };
             {
                 const bool graphs_on = ctx->sw.graph;
-                ffh_ctx::PrepGraph &pg = ctx->pg;
+                ffh_ctx::PrepGraph &pg = ctx->pg_slots[ctx->pg_slot];
                 const bool eligible = graphs_on && !bounded && !ctx->borrowed && g0 == 0 && ng == n_guides && first_launch;
                 // (pattern_gen: the captured kernels read ctx->patterns[side], which prepare_side overwrites IN PLACE -- no reallocation, no
                 // epoch change -- when a scan with another (width, radius) comes in between: ADVICE r4.  A plain run that uploads moves
@@ -1647,6 +1649,159 @@ static hipError_t copy_out(ffh_ctx *, void *host, const void *dev, size_t bytes,
     return bytes ? hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
 }
 
+// ---- the list-delivering half of ffh_finalize ------------------------------------------------------------------------------------
+// One call delivers the lists of the guides of the CURRENT scan into `lp.r`.  Alone (ffh_finalize): the result is allocated here, exactly,
+// and the call returns when everything has arrived.  As a part of a pipelined ffh_discover (discover_pipelined, round 5): the guide set
+// is scanned in two halves; the first half's per-hit arrays are still crossing the link (~55 GB/s, ~1 ms per half at hg38 scale) while
+// the second half is scanned -- a device-to-host copy next to the latency-bound compare launch slows neither
+// (profiles/r05/overlap_probe.json: 1.82 ms step + 1.84 ms copy = 2.05 ms together).  The halves write one result: per-guide arrays at
+// g_base, per-hit arrays at h_base, positions at p_base, on the device and on the host; the first half sizes the block for both from
+// its own counts, and a second half that does not fit abandons the pipeline (the caller then runs the unsplit call).
+struct ListPipe {
+    ffh_result *r = nullptr;
+    uint32_t G_total = 0, g_base = 0;
+    uint64_t h_base = 0, p_base = 0, h_cap = 0, p_cap = 0;
+    bool pipelined = false, last = true;
+    uint64_t Hr = 0, Pr = 0;   // this part's counts (out)
+    bool overflow = false;     // out: the second half did not fit the block the first one sized
+};
+static int finalize_lists(ffh_ctx *ctx, const uint32_t *d_prior, int max_offtargets, unsigned flags, ListPipe &lp) {
+    hipStream_t st = ctx->st;
+    const uint32_t G = ctx->n_guides;
+    if (lp.pipelined) {   // (ffh_finalize did this already for a call of its own)
+        FFH_HIP(hipEventRecord(ctx->ev[7], st));
+        FFH_HIP(ctx->n_ret.reserve((size_t)G + 1)); FFH_HIP(ctx->ot_count.reserve((size_t)G + 1)); FFH_HIP(ctx->full.reserve((size_t)G + 1));
+        FFH_HIP(ctx->ret_off.reserve((size_t)G + 2)); FFH_HIP(ctx->summ.reserve((size_t)G + 1));
+        FFH_HIP(ctx->scan_tmp64.reserve(scan_scratch_elems_safe(std::max<uint64_t>(G, ctx->n_raw) + 1)));
+    }
+    { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
+    const bool want_pos = !(flags & FFH_FINALIZE_NO_POSITIONS), want_cfd = !(flags & FFH_FINALIZE_NO_HIT_SCORES);
+    // ordered cut-off; with positions wanted it also leaves, per kept hit, the number of the guide's kept positions before it, so that
+    // every hit's slot in the position array follows from one scan over the guides (no scan over the hits, no second round trip)
+    if (want_pos) { FFH_HIP(ctx->hit_pre.reserve(ctx->n_raw + 1)); FFH_HIP(ctx->pos_base.reserve((size_t)G + 2)); }
+    if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
+                              ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr, want_pos ? ctx->hit_pre.p : (uint32_t *)nullptr);
+    exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
+    uint64_t Hr = 0, Pr = 0;
+    FFH_HIP(hipMemcpyAsync(&Hr, ctx->ret_off.p + G, 8, hipMemcpyDeviceToHost, st));
+    if (want_pos) {
+        exclusive_scan<uint32_t, uint64_t>(ctx->ot_count.p, G, ctx->pos_base.p, ctx->scan_tmp64.p, st);
+        FFH_HIP(hipMemcpyAsync(&Pr, ctx->pos_base.p + G, 8, hipMemcpyDeviceToHost, st));
+    }
+    FFH_HIP(hipStreamSynchronize(st));
+    lp.Hr = Hr; lp.Pr = Pr;
+    const uint64_t hb = lp.h_base, pb = lp.p_base;
+    if (!lp.r) {   // the only part, or the first: the result block (and the device arrays) for everything
+        uint64_t hc = Hr, pc = Pr;
+        if (lp.pipelined) {   // room for the other half: this half's counts scaled to the whole guide set, + 30 %
+            const double f = 1.3 * (double)lp.G_total / (double)std::max<uint32_t>(G, 1u);
+            hc = (uint64_t)((double)Hr * f) + 4096; pc = (uint64_t)((double)Pr * f) + 4096;
+        }
+        lp.h_cap = hc; lp.p_cap = pc;
+        ffh_result *r = new (std::nothrow) ffh_result();
+        if (!r || !r->allocate(ctx->pool, lp.G_total, hc, true, want_cfd, want_pos) || (want_pos && !r->allocate_positions(pc))) {
+            delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM;
+        }
+        r->scores_valid = ctx->geo.cas9_23;
+        r->pos_offsets_pending = want_pos;  // never copied: hit h owns (hit_targets[h] >> 48) positions (settle_pos_offsets)
+        lp.r = r;
+    } else if (hb + Hr > lp.h_cap || pb + Pr > lp.p_cap) { lp.overflow = true; return FFH_OK; }
+    ffh_result *r = lp.r;
+    FFH_HIP(ctx->out_target.reserve(lp.h_cap + 2));
+    FFH_HIP(ctx->out_mm.reserve(lp.h_cap + 16));
+    FFH_HIP(ctx->out_cnt.reserve(std::max<uint64_t>(lp.h_cap, ctx->T) + 1));
+    FFH_HIP(ctx->out_tidx.reserve(lp.h_cap + 1));
+    FFH_HIP(ctx->out_cfd.reserve(lp.h_cap + 2));
+    FFH_HIP(ctx->out_hsu.reserve(lp.h_cap + 1));
+    double *d_jost = nullptr;  // the CRISPRi aggregates are computed on request only: they cost a third per-hit array
+    if (flags & FFH_FINALIZE_JOST) { FFH_HIP(ctx->out_jost.reserve(lp.h_cap + 1)); d_jost = ctx->out_jost.p + hb; }
+    if (want_pos) { FFH_HIP(ctx->out_posoff.reserve(lp.h_cap + 2)); FFH_HIP(ctx->out_pos.reserve(lp.p_cap + 2)); }
+    if (ctx->n_raw)
+        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, G, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
+                           ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p + hb, ctx->out_mm.p + hb, ctx->out_cnt.p + hb, ctx->out_tidx.p + hb, ctx->out_cfd.p + hb,
+                           ctx->out_hsu.p + hb, d_jost, want_pos ? (const uint32_t *)ctx->hit_pre.p : (const uint32_t *)nullptr,
+                           want_pos ? (const uint64_t *)ctx->pos_base.p : (const uint64_t *)nullptr, want_pos ? ctx->out_posoff.p + hb : (uint64_t *)nullptr);
+    auto fail = [&](const char *what, hipError_t e) {
+        (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamSynchronize(st);
+        ctx->err = std::string(what) + hipGetErrorString(e); delete lp.r; lp.r = nullptr;
+        return FFH_E_HIP;
+    };
+    auto after_main = [&]() {   // the copy stream goes on when the main stream has come this far
+        hipError_t e = hipEventRecord(ctx->copy_ev, st);
+        return e == hipSuccess ? hipStreamWaitEvent(ctx->copy_st, ctx->copy_ev, 0) : e;
+    };
+    auto copy_hits = [&]() {
+        hipError_t e = hipSuccess;
+        if (Hr) e = copy_out(ctx, r->hit_targets + hb, ctx->out_target.p + hb, Hr * 8, ctx->copy_st);
+        if (Hr && e == hipSuccess) e = copy_out(ctx, r->hit_mm + hb, ctx->out_mm.p + hb, Hr, ctx->copy_st);
+        if (Hr && want_cfd && e == hipSuccess) e = copy_out(ctx, r->hit_cfd + hb, ctx->out_cfd.p + hb, Hr * 8, ctx->copy_st);
+        return e;
+    };
+    auto gather_positions = [&]() {
+        if (want_pos && Hr) hipLaunchKernelGGL(k_gather_positions, dim3(blocks_for(Hr, 256)), dim3(256), 0, st, ctx->out_tidx.p + hb, ctx->out_cnt.p + hb, ctx->out_posoff.p + hb, Hr,
+                                               ctx->pos_off.p, ctx->positions.p, ctx->out_pos.p + pb);
+    };
+    auto aggregate = [&]() {
+        if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p + hb,
+                                  ctx->out_cnt.p + hb, ctx->out_cfd.p + hb, ctx->out_hsu.p + hb, (const double *)d_jost, G, ctx->summ.p);
+    };
+    hipError_t e = hipSuccess;
+    if (lp.last) {
+        // The link (~55 GB/s) is what a list-delivering call waits for: the per-hit arrays leave on the copy stream as soon as
+        // k_score_hits has written them; the positions are gathered beside that transfer and queue behind it; the aggregation and the
+        // small per-guide copies run on the main stream meanwhile (both kernels run 5-10 x slower beside the runtime's copy kernel
+        // than alone, and are still done before it is).
+        e = after_main();
+        if (e == hipSuccess) e = copy_hits();
+        if (e != hipSuccess) return fail("result copy: ", e);
+        gather_positions();
+        if (want_pos) {
+            e = after_main();
+            if (Pr && e == hipSuccess) e = copy_out(ctx, r->positions + pb, ctx->out_pos.p + pb, Pr * 8, ctx->copy_st);
+        }
+        aggregate();
+    } else {
+        // a half that another half follows: its kernels first, ALONE (behind them waits the next half's scan, and beside the copy kernel
+        // they would take 1.0-1.3 ms each instead of 0.1-0.25), then all its copies, which the next half's scan runs beside at no cost
+        gather_positions();
+        aggregate();
+        // (the per-guide arrays leave on the copy stream too, from device copies made HERE: the next half's kernels overwrite summ /
+        // ret_off, a copy of them on the main stream would queue for the link in front of the next half's scan, and even a
+        // device-to-device copy started beside the transfers below takes 0.65 ms instead of a few microseconds)
+        FFH_HIP(ctx->summ_stage.reserve((size_t)G + 1)); FFH_HIP(ctx->ret_off_stage.reserve((size_t)G + 2));
+        if (G) e = hipMemcpyAsync(ctx->summ_stage.p, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->ret_off_stage.p, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], st);
+        if (e == hipSuccess) e = after_main();
+        if (e == hipSuccess) e = copy_hits();
+        if (want_pos && Pr && e == hipSuccess) e = copy_out(ctx, r->positions + pb, ctx->out_pos.p + pb, Pr * 8, ctx->copy_st);
+        if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries + lp.g_base, ctx->summ_stage.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, ctx->copy_st);
+        // (G entries, not G + 1: the next part writes entry g_base + G itself, and this copy may land after that one)
+        if (G && e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets + lp.g_base, ctx->ret_off_stage.p, (size_t)G * 8, hipMemcpyDeviceToHost, ctx->copy_st);
+    }
+    if (e != hipSuccess) return fail("result copy: ", e);
+    if (lp.last) {
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], st);
+        if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries + lp.g_base, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets + lp.g_base, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail("result copy: ", e);
+    if (!lp.last) return FFH_OK;   // (the next half's scan goes on behind these launches; its finalize_lists waits for everything)
+    e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_st);
+    if (e != hipSuccess) return fail("result copy: ", e);
+    if (hb)   // the second half's offsets count from its own first hit
+        for (uint32_t g = 0; g <= G; ++g) r->guide_offsets[lp.g_base + g] += hb;
+    r->n_hits = hb + Hr;
+    r->n_positions = want_pos ? pb + Pr : 0;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
+    ctx->tm.finalize_ms = ms;
+    finish_scan_timings(ctx);
+    return FFH_OK;
+}
+
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets, unsigned flags, ffh_result **out) {
     if (!ctx || !out || max_offtargets < 0) { if (ctx) ctx->err = "bad argument"; return FFH_E_ARG; }
     if (!ctx->scanned) { ctx->err = "ffh_scan has not run"; return FFH_E_STATE; }
@@ -1698,72 +1853,11 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals, int max_offtargets,
         *out = r;
         return FFH_OK;
     }
-    { const int rc = gather_hit_targets(ctx); if (rc) return rc; }
-    const bool want_pos = !(flags & FFH_FINALIZE_NO_POSITIONS), want_cfd = !(flags & FFH_FINALIZE_NO_HIT_SCORES);
-    // ordered cut-off; with positions wanted it also leaves, per kept hit, the number of the guide's kept positions before it, so that
-    // every hit's slot in the position array follows from one scan over the guides (no scan over the hits, no second round trip)
-    if (want_pos) { FFH_HIP(ctx->hit_pre.reserve(ctx->n_raw + 1)); FFH_HIP(ctx->pos_base.reserve((size_t)G + 2)); }
-    if (G) hipLaunchKernelGGL(k_cutoff, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->seg_begin.p, ctx->seg_end.p, ctx->hit_t.p, d_prior, G, (uint32_t)max_offtargets,
-                              ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, (uint32_t *)nullptr, want_pos ? ctx->hit_pre.p : (uint32_t *)nullptr);
-    exclusive_scan<uint32_t, uint64_t>(ctx->n_ret.p, G, ctx->ret_off.p, ctx->scan_tmp64.p, st);
-    uint64_t Hr = 0, Pr = 0;
-    FFH_HIP(hipMemcpyAsync(&Hr, ctx->ret_off.p + G, 8, hipMemcpyDeviceToHost, st));
-    if (want_pos) {
-        exclusive_scan<uint32_t, uint64_t>(ctx->ot_count.p, G, ctx->pos_base.p, ctx->scan_tmp64.p, st);
-        FFH_HIP(hipMemcpyAsync(&Pr, ctx->pos_base.p + G, 8, hipMemcpyDeviceToHost, st));
-    }
-    FFH_HIP(hipStreamSynchronize(st));
-    FFH_HIP(ctx->out_target.reserve(Hr + 2));
-    FFH_HIP(ctx->out_mm.reserve(Hr + 16));
-    FFH_HIP(ctx->out_cnt.reserve(std::max<uint64_t>(Hr, ctx->T) + 1));
-    FFH_HIP(ctx->out_tidx.reserve(Hr + 1));
-    FFH_HIP(ctx->out_cfd.reserve(Hr + 2));
-    FFH_HIP(ctx->out_hsu.reserve(Hr + 1));
-    double *d_jost = nullptr;  // the CRISPRi aggregates are computed on request only: they cost a third per-hit array
-    if (flags & FFH_FINALIZE_JOST) { FFH_HIP(ctx->out_jost.reserve(Hr + 1)); d_jost = ctx->out_jost.p; }
-    if (want_pos) { FFH_HIP(ctx->out_posoff.reserve(Hr + 2)); FFH_HIP(ctx->out_pos.reserve(Pr + 2)); }
-    ffh_result *r = new (std::nothrow) ffh_result();
-    if (!r || !r->allocate(ctx->pool, G, Hr, true, want_cfd, want_pos) || (want_pos && !r->allocate_positions(Pr))) {
-        delete r; ctx->err = "out of (pinned) host memory"; return FFH_E_NOMEM;
-    }
-    r->scores_valid = ctx->geo.cas9_23;
-    r->pos_offsets_pending = want_pos;  // never copied: hit h owns (hit_targets[h] >> 48) positions (settle_pos_offsets)
-    if (ctx->n_raw)
-        hipLaunchKernelGGL(k_score_hits, dim3(blocks_for(ctx->n_raw, 256)), dim3(256), 0, st, ctx->hits_sorted, ctx->n_raw, ctx->tbits, G, ctx->seg_begin.p, ctx->n_ret.p, ctx->ret_off.p,
-                           ctx->hit_t.p, ctx->guides.p, ctx->geo, ctx->d_tab, ctx->out_target.p, ctx->out_mm.p, ctx->out_cnt.p, ctx->out_tidx.p, ctx->out_cfd.p,
-                           ctx->out_hsu.p, d_jost, want_pos ? (const uint32_t *)ctx->hit_pre.p : (const uint32_t *)nullptr,
-                           want_pos ? (const uint64_t *)ctx->pos_base.p : (const uint64_t *)nullptr, want_pos ? ctx->out_posoff.p : (uint64_t *)nullptr);
-    // The link (~55 GB/s) is what a list-delivering call waits for: the per-hit arrays leave on the copy stream as soon as
-    // k_score_hits has written them; the positions are gathered beside that transfer and queue behind it; the aggregation and the
-    // small per-guide copies run on the main stream meanwhile.
-    hipError_t e = hipEventRecord(ctx->copy_ev, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_st, ctx->copy_ev, 0);
-    if (Hr && e == hipSuccess) e = copy_out(ctx, r->hit_targets, ctx->out_target.p, Hr * 8, ctx->copy_st);
-    if (Hr && e == hipSuccess) e = copy_out(ctx, r->hit_mm, ctx->out_mm.p, Hr, ctx->copy_st);
-    if (Hr && want_cfd && e == hipSuccess) e = copy_out(ctx, r->hit_cfd, ctx->out_cfd.p, Hr * 8, ctx->copy_st);
-    auto fail = [&](const char *what) { (void)hipStreamSynchronize(ctx->copy_st); (void)hipStreamSynchronize(st); ctx->err = std::string(what) + hipGetErrorString(e); delete r; return FFH_E_HIP; };
-    if (e != hipSuccess) return fail("result copy: ");
-    if (want_pos) {
-        if (Hr) hipLaunchKernelGGL(k_gather_positions, dim3(blocks_for(Hr, 256)), dim3(256), 0, st, ctx->out_tidx.p, ctx->out_cnt.p, ctx->out_posoff.p, Hr, ctx->pos_off.p,
-                                   ctx->positions.p, ctx->out_pos.p);
-        e = hipEventRecord(ctx->copy_ev, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_st, ctx->copy_ev, 0);
-        if (Pr && e == hipSuccess) e = copy_out(ctx, r->positions, ctx->out_pos.p, Pr * 8, ctx->copy_st);
-    }
-    if (G) hipLaunchKernelGGL(k_guide_aggregate, dim3(blocks_for(G, 4)), dim3(256), 0, st, ctx->ret_off.p, ctx->n_ret.p, ctx->ot_count.p, ctx->full.p, ctx->out_mm.p,
-                              ctx->out_cnt.p, ctx->out_cfd.p, ctx->out_hsu.p, (const double *)d_jost, G, ctx->summ.p);
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], st);
-    if (G && e == hipSuccess) e = hipMemcpyAsync(r->summaries, ctx->summ.p, (size_t)G * sizeof(ffh_guide_summary), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(r->guide_offsets, ctx->ret_off.p, ((size_t)G + 1) * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_st);
-    if (e != hipSuccess) return fail("result copy: ");
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ctx->ev[7], ctx->ev[1]);
-    ctx->tm.finalize_ms = ms;
-    finish_scan_timings(ctx);
-    *out = r;
+    ListPipe lp;
+    lp.G_total = G;
+    const int rc = finalize_lists(ctx, d_prior, max_offtargets, flags, lp);
+    if (rc) return rc;
+    *out = lp.r;
     return FFH_OK;
 }
 
@@ -1808,7 +1902,36 @@ static ffh_result *merge_results(ffh_ctx *ctx, const ffh_result *a, const ffh_re
     }
     return r;
 }
+// The list-delivering discover of a large guide set against a large database, in two halves: the first half's lists cross the link while
+// the second half is scanned (finalize_lists).  Returns 1 when the pipeline was abandoned (a scan that must be split further, a second
+// half that does not fit the block the first one sized): nothing is left in flight and the caller runs the unsplit call.
+static int discover_pipelined(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
+    // (60 : 40 -- the second part's scan should take about as long as the first part's lists need on the link, and a scan of
+    // fewer guides costs more per guide: profiles/r05/ab_log.txt 7)
+    const uint32_t ga = (uint32_t)((uint64_t)n_guides * 3 / 5);
+    ListPipe lp;
+    lp.G_total = n_guides; lp.pipelined = true; lp.last = false;
+    auto abandon = [&]() { (void)hipStreamSynchronize(ctx->st); (void)hipStreamSynchronize(ctx->copy_st); delete lp.r; lp.r = nullptr; return 1; };
+    int rc = scan_retry_bounded(ctx, guides, ga, max_mismatch, max_offtargets);
+    if (rc) return ctx->too_many_hits ? 1 : rc;
+    rc = finalize_lists(ctx, nullptr, max_offtargets, flags, lp);
+    if (rc) { (void)abandon(); return rc; }
+    lp.g_base = ga; lp.h_base = lp.Hr; lp.p_base = lp.Pr; lp.last = true;
+    ctx->pg_slot = 1;
+    rc = scan_retry_bounded(ctx, guides + ga, n_guides - ga, max_mismatch, max_offtargets);
+    ctx->pg_slot = 0;
+    if (rc) { const bool again = ctx->too_many_hits; (void)abandon(); return again ? 1 : rc; }
+    rc = finalize_lists(ctx, nullptr, max_offtargets, flags, lp);
+    if (rc) { (void)abandon(); return rc; }
+    if (lp.overflow) return abandon();
+    *out = lp.r;
+    return FFH_OK;
+}
 static int discover_split(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_result **out) {
+    if (ctx && !(flags & FFH_FINALIZE_SUMMARIES_ONLY) && n_guides >= 2 && ctx->sw.pipeline) {   // (FFH_PIPELINE=1 only: see ffh_debug.hpp)
+        const int rc = discover_pipelined(ctx, guides, n_guides, max_mismatch, max_offtargets, flags, out);
+        if (rc <= 0) return rc;   // (1: abandoned, go on unsplit)
+    }
     int rc = scan_retry_bounded(ctx, guides, n_guides, max_mismatch, max_offtargets);
     if (!rc) return ffh_finalize(ctx, nullptr, max_offtargets, flags, out);
     if (!ctx || !ctx->too_many_hits || n_guides < 2) return rc;

@@ -343,14 +343,15 @@ __global__ __launch_bounds__(1024) void k_sort_small(uint64_t *__restrict__ keys
 // ---------------------------------------------------------------------------------------------------------
 // ---- a bitonic network over R registers per lane of one wave (64 R elements) ----
 // element e of the sequence = register e >> 6, lane e & 63; runs ascend where (e & K) == 0 (K = the whole network: everywhere)
-template <int R, int K, int J>
+// N: elements the network orders (a power of two <= 64 R; the elements from N on are left alone -- all-ones sentinels in every use)
+template <int R, int K, int J, int N = 64 * R>
 __device__ __forceinline__ void bitonic_step(uint32_t (&x)[R], uint32_t lane) {
     if constexpr (J >= 64) {   // the partner is another register of the same lane
         constexpr int jj = J / 64;
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if ((r & jj) == 0) {
-                const bool up = K >= 64 * R ? true : ((r * 64) & K) == 0;
+                const bool up = K >= N ? true : ((r * 64) & K) == 0;
                 const uint32_t lo = min(x[r], x[r | jj]), hi = max(x[r], x[r | jj]);
                 x[r] = up ? lo : hi; x[r | jj] = up ? hi : lo;
             }
@@ -358,21 +359,21 @@ __device__ __forceinline__ void bitonic_step(uint32_t (&x)[R], uint32_t lane) {
         const bool lower = (lane & (uint32_t)J) == 0u;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool up = K >= 64 * R ? true : K < 64 ? (lane & (uint32_t)K) == 0u : ((r * 64) & K) == 0;
+            const bool up = K >= N ? true : K < 64 ? (lane & (uint32_t)K) == 0u : ((r * 64) & K) == 0;
             const uint32_t y = (uint32_t)__shfl_xor((int)x[r], J, 64);
             x[r] = (lower == up) ? min(x[r], y) : max(x[r], y);
         }
     }
 }
-template <int R, int K, int J>
+template <int R, int K, int J, int N = 64 * R>
 __device__ __forceinline__ void bitonic_merge(uint32_t (&x)[R], uint32_t lane) {
-    bitonic_step<R, K, J>(x, lane);
-    if constexpr (J > 1) bitonic_merge<R, K, J / 2>(x, lane);
+    bitonic_step<R, K, J, N>(x, lane);
+    if constexpr (J > 1) bitonic_merge<R, K, J / 2, N>(x, lane);
 }
-template <int R, int K = 2>
+template <int R, int K = 2, int N = 64 * R>
 __device__ __forceinline__ void bitonic_sort(uint32_t (&x)[R], uint32_t lane) {
-    bitonic_merge<R, K, K / 2>(x, lane);
-    if constexpr (K < 64 * R) bitonic_sort<R, K * 2>(x, lane);
+    bitonic_merge<R, K, K / 2, N>(x, lane);
+    if constexpr (K < N) bitonic_sort<R, K * 2, N>(x, lane);
 }
 constexpr uint32_t kSegWaveMax = 1024;
 constexpr int kSegRows = kSegWaveMax / 64;
@@ -658,12 +659,20 @@ __device__ __forceinline__ void sort_segment_regs(const uint32_t *__restrict__ i
     uint32_t x[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) x[r] = (uint32_t)r * 64u + lane < c ? idx[(uint32_t)r * 64u + lane] : 0xFFFFFFFFu;
-    bitonic_sort<R>(x, lane);
+    if constexpr (R == 1) {   // (a guide with a handful of hits -- a chr22-scale call has 1.7 per guide: a network of its size, not of 64)
+        if (c <= 2u) bitonic_sort<1, 2, 2>(x, lane);
+        else if (c <= 4u) bitonic_sort<1, 2, 4>(x, lane);
+        else if (c <= 8u) bitonic_sort<1, 2, 8>(x, lane);
+        else if (c <= 16u) bitonic_sort<1, 2, 16>(x, lane);
+        else if (c <= 32u) bitonic_sort<1, 2, 32>(x, lane);
+        else bitonic_sort<1>(x, lane);
+    } else bitonic_sort<R>(x, lane);
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if ((uint32_t)r * 64u + lane < c) keys[(uint32_t)r * 64u + lane] = hi | x[r];
 }
 __device__ __forceinline__ void rank_segment(const uint32_t *__restrict__ idx, uint32_t c, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
+    if (c == 1u) { if (lane == 0) keys[0] = hi | idx[0]; return; }
     if (c <= 64u) { sort_segment_regs<1>(idx, c, hi, keys, lane); return; }
     if (c <= 128u) { sort_segment_regs<2>(idx, c, hi, keys, lane); return; }
     if (c <= 256u) { sort_segment_regs<4>(idx, c, hi, keys, lane); return; }

@@ -256,3 +256,28 @@ def test_hit_ordering_by_segments_and_by_six_passes_agree_with_the_oracle(capi, 
     assert per_guide.max() > 1024 and (per_guide <= 128).sum() > 50 and ((per_guide > 128) & (per_guide <= 1024)).sum() > 5, (per_guide.max(), tm.n_raw_hits)
     assert_same_hits(gpu, odb.discover(g, 4, 2 ** 31 - 1))
     assert_same_hits(cut, odb.discover(g, 5, 300))
+
+
+def test_two_part_pipelined_discover_delivers_the_same_result(capi, oracle, monkeypatch):
+    """FFH_PIPELINE=1 (off by default: slower on this stack, profiles/r05/ab_log.txt 7): a list-delivering ffh_discover scans 60 % of
+    the guides, leaves their lists on the copy stream, scans the rest and delivers both parts in ONE result block.  Every array must be
+    what the unsplit call delivers, with and without positions / per-hit scores, cut-off far and biting."""
+    from tests.test_gpu_parity import dense_case
+    odb, t, p, g = dense_case(oracle, n_random=150_000, n_guides=600, n_dense=50, variants=150, seed=61)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        plain = {(mo, kw): ctx.discover(g, 4, mo, jost=True, **dict(kw)) for mo in (2000, 30) for kw in ((), (("positions", False), ("hit_scores", False)))}
+    monkeypatch.setenv("FFH_PIPELINE", "1")
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        for (mo, kw), want in plain.items():
+            got = ctx.discover(g, 4, mo, jost=True, **dict(kw))
+            assert got.n_hits == want.n_hits and got.n_positions == want.n_positions
+            assert got.summaries.tobytes() == want.summaries.tobytes()
+            for name in ("guide_offsets", "hit_targets", "hit_mismatches"):
+                assert np.array_equal(getattr(got, name), getattr(want, name)), name
+            if not kw:
+                assert np.array_equal(got.positions, want.positions) and np.array_equal(got.pos_offsets, want.pos_offsets)
+                assert np.array_equal(np.isnan(got.hit_cfd), np.isnan(want.hit_cfd)) and np.array_equal(np.nan_to_num(got.hit_cfd), np.nan_to_num(want.hit_cfd))
+        assert_same_hits(ctx.discover(g, 4, 2000), odb.discover(g, 4, 2000))
+    monkeypatch.delenv("FFH_PIPELINE")
