@@ -1,7 +1,7 @@
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, KiB) and issue counters of the kernels around the compare launch during bench.py: candidate
 # binning, the radix-sort passes, segments, the epilogue.  One --pmc set per run, --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
-RX="k_item_bin_direct|k_guide_by_part|k_sort_hist|k_sort_scatter|k_segments|k_segsort|k_guide_epilogue|k_work_count|k_hit_targets"
+RX="k_item_bin_direct|k_guide_by_part|k_msd_hist|k_msd_scatter|k_binsort|k_sort_hist|k_sort_scatter|k_segments|k_segsort|k_guide_epilogue|k_work_count|k_work_fill|k_hit_targets"
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS"; do
   N=$(echo $P | cut -d" " -f1)
   rm -rf /tmp/pmco_$N
