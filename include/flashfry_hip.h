@@ -204,6 +204,13 @@ int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t cla
 int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shard */, int max_offtargets,
                  unsigned flags, ffh_result **out);
 
+/* ffh_scan_bounded + ffh_finalize in one call -- what Traverser.scan(...) binds (reference/traverser/Traverser.scala:53-60).
+ * ONE scan holds fewer than 2^32 raw hits (its segment arithmetic is 32-bit).  A guide set that collects more (<= 5-6 mismatches on a
+ * repeat-rich genome) is not refused: the call first bounds the scan (as if ffh_set_bounding(1)), and if that is not enough halves the
+ * guide set as often as needed and concatenates the parts' results -- guides are independent of each other everywhere on the path, the
+ * reference is slow on such a set, not wrong (reference/binary/blocks/BlockManager.scala:212-254).  ffh_discover_sharded and
+ * ffh_discover_bulge do the same; the two-step ffh_scan / ffh_finalize report FFH_E_ARG ("more than 2^32 raw hits") and leave the
+ * split to their caller.  After a split call the context holds the scan of the LAST part only. */
 int ffh_discover(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets,
                  unsigned flags, ffh_result **out);
 

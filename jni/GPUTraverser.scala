@@ -69,7 +69,12 @@ object GPUTraverser extends Traverser with LazyLogging {
   /** the devices of a run: -Dflashfry.gpu.devices=0,1,2,3,4,5,6,7 (a device may be named twice: two bin shards on it), else the one of
     * -Dflashfry.gpu.device (default 0) */
   def devices: Array[Int] = Option(System.getProperty("flashfry.gpu.devices")) match {
-    case Some(s) if s.trim.nonEmpty => s.split(",").map(_.trim.toInt)
+    case Some(s) if s.trim.nonEmpty =>
+      val ids = s.split(",").map(_.trim)
+      ids.foreach { t =>
+        if (t.isEmpty || !t.forall(_.isDigit)) throw new IllegalArgumentException("flashfry.gpu.devices: '" + s + "' is not a comma-separated list of device numbers")
+      }
+      ids.map(_.toInt)
     case _ => Array(Integer.getInteger("flashfry.gpu.device", 0).intValue)
   }
 
@@ -119,25 +124,38 @@ object GPUTraverser extends Traverser with LazyLogging {
            bitCoder: BitEncoding,
            posCoder: BitPosition) {
 
-    val devs = devices
+    var devs = devices
     val enzyme = ParameterPack.parameterPackToIndex(configuration)
     val path = binaryFile.getAbsolutePath // the body file; the library reads <path>.header itself (BinaryHeader.scala:115-160)
-    val ctxs = new Array[Long](devs.length)
+    var ctxs = new Array[Long](devs.length)
     var comm = 0L
     try {
-      devs.indices.foreach { i =>
+      ctxs(0) = create(devs(0), enzyme)
+      if (ctxs(0) == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
+      // one GPU: the whole database; several: shard i holds the bins [cut(i), cut(i + 1)) (static, contiguous, balanced by payload)
+      var cut = Array(0, 0)
+      if (devs.length > 1) {
+        if (dbOpenHeader(ctxs(0), path) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
+        val all = binCuts(Array.tabulate(dbBins(ctxs(0)))(b => dbBinBytes(ctxs(0), b)), devs.length)
+        // more devices than bins with a payload (a small database, an empty one): the shards that would be empty are dropped -- an empty
+        // bin range is not a database (ADVICE r4); the devices behind them stay idle
+        val keep = devs.indices.filter(i => all(i + 1) > all(i))
+        if (keep.length <= 1) devs = devs.take(1)
+        else { cut = (keep.map(all(_)) :+ all.last).toArray; devs = keep.map(devs(_)).toArray }   // (dropped ranges are empty: the kept ones stay contiguous)
+        ctxs = ctxs(0) +: new Array[Long](devs.length - 1)
+      }
+      (1 until devs.length).foreach { i =>
         ctxs(i) = create(devs(i), enzyme)
         if (ctxs(i) == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
       }
-      // one GPU: the whole database; several: shard i holds the bins [cut(i), cut(i + 1)) (static, contiguous, balanced by payload)
       if (devs.length == 1) {
         if (dbOpen(ctxs(0), path, 0, 0) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
       } else {
-        if (dbOpenHeader(ctxs(0), path) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
-        val cut = binCuts(Array.tabulate(dbBins(ctxs(0)))(b => dbBinBytes(ctxs(0), b)), devs.length)
-        devs.indices.par.foreach { i => // (the loads are independent: one host thread per device)
-          if (dbOpen(ctxs(i), path, cut(i), cut(i + 1)) != 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(i)))
-        }
+        // the loads are independent: one host thread per device; every load runs to its end, then ONE exception names what failed
+        val failed = devs.indices.par.map { i =>
+          if (dbOpen(ctxs(i), path, cut(i), cut(i + 1)) != 0) Some("device " + devs(i) + " (bins " + cut(i) + " .. " + cut(i + 1) + "): " + lastError(ctxs(i))) else None
+        }.seq.flatten
+        if (failed.nonEmpty) throw new IllegalStateException("GPUTraverser: " + failed.mkString("; "))
         comm = createLocalComm(ctxs)
         if (comm == 0) throw new IllegalStateException("GPUTraverser: " + lastError(0))
       }
