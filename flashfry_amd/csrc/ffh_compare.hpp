@@ -841,6 +841,9 @@ template <int R0, int R1>
 inline void launch_compare_pair(const CompareArgs &ca, unsigned long long *cursor, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((k_compare<R0, R1, -1, 0>), dim3(grid), dim3(kCmpThreads), 0, st, ca, cursor);
 }
+// Every pair of rest widths build_image_into accepts has an instance: prefix + suffix width = 20 compared bases -> (8,12) (9,11) (10,10)
+// (11,9) (12,8); 19 compared bases -> (7,12) (8,11) (9,10) (10,9) (11,8) (12,7); a one-image plan takes the instance whose prefix form is
+// its own.  The per-pair instances deal their work entries with a fixed stride whatever `chunk` / FFH_WORK_QUEUE say.
 // chunk: the queue chunk both images' expected list lengths allow (work_list_chunk: two chunks per wave at least), 0 = fixed stride.
 // Returns false for a pair of rest widths no instance exists for (the host refuses such images when they are built).
 // generic_only / queue_env: the context's FFH_GENERIC_COMPARE / FFH_WORK_QUEUE switches (ffh_debug.hpp; tests: the per-pair instances for

@@ -255,6 +255,7 @@ struct ffh_ctx {
     DevBuf<WorkEntry> wl_list[2];                             // the compare kernel's work list, per image
     DevBuf<uint64_t> scan_tmp64;
     DevBuf<uint32_t> sort_table, sort_offs, heavy_list;
+    DevBuf<unsigned long long> sort_status;   // look-back words of the one-sweep radix passes (ffh_prims.hpp)
     std::map<std::pair<int, int>, std::vector<uint32_t>> pattern_cache;
 
     // finalize scratch

@@ -29,8 +29,12 @@ struct Switches {
     bool summary_copy = false;       // FFH_SUMMARY_COPY=1: the summaries leave in a copy after the epilogue instead of under it
     bool generic_compare = false;    // FFH_GENERIC_COMPARE=1: the per-width-pair instances of k_compare for every plan
     int work_queue = -1;             // FFH_WORK_QUEUE=0 / 1 / 16 / 4: how the compare launch deals its work entries (-1: by list length)
+                                     // (the three tuned instances only: the per-width-pair instances of other plans -- 19-mers, Cpf1,
+                                     // <= 2 or >= 6 mismatches -- always deal with a fixed stride, launch_compare_pair)
     bool pipeline = false;           // FFH_PIPELINE=1: a list-delivering ffh_discover scans its guide set in two parts, the first part's lists crossing the
                                      // link under the second part's scan.  OFF: measured slower on this stack (profiles/r05/ab_log.txt 7); kept for tests / A-B
+    bool one_sweep = false;          // FFH_ONESWEEP=1: the device-wide LSD sort with decoupled look-back instead of a histogram launch + scan per pass.
+                                     // OFF: slower on this part (3.27 against 2.45 ms for 4.7e7 keys, profiles/r05/ab_log.txt 8); kept for tests / A-B
     int nb_force[2] = {0, 0};        // FFH_NB_PREFIX / FFH_NB_SUFFIX: buckets per work entry of the image (A/B; 0: side_plan's rule)
     uint64_t raw_hit_limit = (1ull << 32) - 64;   // FFH_RAW_HIT_LIMIT: raw hits one scan may collect before the guide set is split (tests: 2^20)
 
@@ -53,6 +57,7 @@ struct Switches {
         s.generic_compare = num("FFH_GENERIC_COMPARE", 0) == 1;
         s.work_queue = (int)num("FFH_WORK_QUEUE", -1);
         s.pipeline = num("FFH_PIPELINE", 0) == 1;
+        s.one_sweep = num("FFH_ONESWEEP", 0) == 1;
         s.nb_force[0] = (int)num("FFH_NB_PREFIX", 0); s.nb_force[1] = (int)num("FFH_NB_SUFFIX", 0);
         { const long v = num("FFH_RAW_HIT_LIMIT", 0); if (v > 0) s.raw_hit_limit = (uint64_t)v; }
         return s;

@@ -778,6 +778,7 @@ struct SortScratch {
     uint32_t *table = nullptr;   // 512*nblocks + 1
     uint32_t *offs = nullptr;    // 512*nblocks + 1
     uint32_t *scan_tmp = nullptr;
+    unsigned long long *status = nullptr;   // 512 x nblocks words: the one-sweep passes' look-back words (radix_sort_u64; null: the three-launch passes)
 };
 constexpr uint32_t kSortTableDigits = 1u << kSortMaxBits;   // table / offs hold this many digits x nblocks (+ 1)
 
@@ -802,12 +803,191 @@ inline void radix_pass(const uint64_t *src, uint64_t *dst, const uint64_t *vsrc,
 inline int radix_passes(int len) { return len <= 0 ? 0 : (len + kSortMaxBits - 1) / kSortMaxBits; }
 inline int radix_width(int len, int k) { const int p = radix_passes(len); return len / p + (k < len % p ? 1 : 0); }
 
+// ---------------------------------------------------------------------------------------------------------
+// (round 5) The LSD sort without its histogram passes ("one sweep").  A pass of the sort above reads the keys twice -- k_sort_hist for the
+// per-block digit counts, a device-wide scan of the 512 x nblocks table, then k_sort_scatter -- although the keys' digits of ALL passes
+// are known before the first one.  Here ONE launch counts every pass's digits over the whole array (k_os_hist -> k_os_bases: where each
+// digit's run begins, per pass), and a pass is a single launch: a block counts its own 4096 keys per digit, publishes the counts, and
+// learns how many keys of each digit the blocks before it hold by looking BACK through their published words (decoupled look-back:
+// a word is either a block's own count or already the inclusive sum up to that block, so the walk is short).  Blocks are dispatched in
+// index order, so a block only ever waits for blocks that are resident or done.  Same stable ranking inside the block as
+// k_sort_scatter; 1 + P launches and P + 1 reads of the keys instead of 4 P launches and 2 P reads.
+// Status word: [63:48] pass tag (a word of another pass, or of the memset, is "not there yet"), [33:32] 1 = count, 2 = inclusive sum,
+// [31:0] the value.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kOsMaxPasses = 8;
+constexpr int kOsHistBlocks = 256;
+constexpr size_t kOsPartialWords = (size_t)kOsHistBlocks * kOsMaxPasses * 512;   // what SortScratch::table has to hold for k_os_hist (offs: kOsMaxPasses x 512)
+struct OsPlan { int n_passes; int shift[kOsMaxPasses]; int bits[kOsMaxPasses]; };
+
+__global__ __launch_bounds__(1024) void k_os_hist(const uint64_t *__restrict__ keys, uint64_t n, OsPlan plan, uint32_t *__restrict__ partial /* [blocks][passes][512] */) {
+    __shared__ uint32_t h[kOsMaxPasses][512];
+    for (uint32_t d = threadIdx.x; d < (uint32_t)plan.n_passes * 512u; d += 1024) (&h[0][0])[d] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < plan.n_passes; ++p) atomicAdd(&h[p][(uint32_t)(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < (uint32_t)plan.n_passes * 512u; d += 1024) partial[(size_t)blockIdx.x * plan.n_passes * 512u + d] = (&h[0][0])[d];
+}
+// one block per pass: base[pass][d] = keys with a smaller digit in that pass
+__global__ __launch_bounds__(512) void k_os_bases(const uint32_t *__restrict__ partial, uint32_t n_blocks, int n_passes, uint32_t *__restrict__ base /* [passes][512] */) {
+    __shared__ uint32_t wsum[8];
+    const uint32_t p = blockIdx.x, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) c += partial[((size_t)b * n_passes + p) * 512u + d];
+    uint32_t incl = c;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        const uint32_t o = __shfl_up(incl, k, 64);
+        if (lane >= (uint32_t)k) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+    base[p * 512u + d] = off + incl - c;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kSortThreads) void k_os_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift, const uint32_t *__restrict__ base /* [512] of this pass */,
+                                                              unsigned long long *__restrict__ status /* [nblocks][512] */, uint32_t tag) {
+    constexpr uint32_t DIG = 1u << BITS, PER = DIG / kSortThreads;
+    static_assert(BITS >= 8 && BITS <= kSortMaxBits, "256 or 512 digits per pass");
+    __shared__ uint64_t staged[kSortChunk];
+    __shared__ uint32_t wave_cnt[4][DIG];
+    __shared__ uint32_t dig_start[DIG];
+    __shared__ uint32_t dig_goff[DIG];
+    __shared__ uint32_t scan_lds[8];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * kSortChunk;
+    const uint32_t here = (uint32_t)min((uint64_t)kSortChunk, n - chunk0);
+    uint64_t kreg[kSortRows];
+#pragma unroll
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        kreg[r] = i < here ? keys[chunk0 + i] : 0;
+    }
+    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wave_cnt[w][d] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        if (i < here) atomicAdd(&wave_cnt[wave][(uint32_t)(kreg[r] >> shift) & (DIG - 1u)], 1u);
+    }
+    __syncthreads();
+    {
+        uint32_t c[PER][4], tot_d[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            tot_d[k] = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { c[k][w] = wave_cnt[w][PER * threadIdx.x + k]; tot_d[k] += c[k][w]; }
+            sum += tot_d[k];
+        }
+        // publish this block's digit counts (block 0: they already are inclusive sums), then look back
+        const unsigned long long tagw = (unsigned long long)tag << 48;
+        unsigned long long *mine = status + (size_t)blockIdx.x * DIG;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k)
+            __hip_atomic_store(mine + PER * threadIdx.x + k, tagw | ((blockIdx.x == 0 ? 2ull : 1ull) << 32) | tot_d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t tot;
+        uint32_t start = block_exclusive_scan<uint32_t>(sum, scan_lds, tot);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t d = PER * threadIdx.x + k;
+            uint32_t before = 0;   // keys of digit d in the blocks before this one
+            // (four predecessors' words requested together: the walk is a chain of memory round trips)
+            for (int64_t b = (int64_t)blockIdx.x - 1; b >= 0;) {
+                unsigned long long v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = b - k >= 0 ? __hip_atomic_load(status + (size_t)(b - k) * DIG + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tagw | (2ull << 32));
+                bool done = false;
+                int used = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (done || (v[k] >> 48) != tag) break;
+                    before += (uint32_t)v[k];
+                    ++used;
+                    if (((v[k] >> 32) & 3ull) == 2ull) done = true;
+                }
+                if (done) break;
+                b -= used;
+            }
+            if (blockIdx.x) __hip_atomic_store(mine + d, tagw | (2ull << 32) | (unsigned long long)(before + tot_d[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dig_goff[d] = base[d] + before;
+            dig_start[d] = start;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { wave_cnt[w][d] = start; start += c[k][w]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRows; ++r) {
+        const uint32_t i = wave * (kSortRows * 64) + r * 64 + lane;
+        const bool valid = i < here;
+        const uint32_t d = (uint32_t)(kreg[r] >> shift) & (DIG - 1u);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const uint32_t rank = mbcnt(peers);
+        uint32_t pos = 0;
+        if (valid) pos = wave_cnt[wave][d] + rank;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == (uint32_t)__popcll(peers) - 1) wave_cnt[wave][d] = pos + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) staged[pos] = kreg[r];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < here; i += kSortThreads) {
+        const uint64_t key = staged[i];
+        const uint32_t d = (uint32_t)(key >> shift) & (DIG - 1u);
+        out[(uint64_t)dig_goff[d] + (i - dig_start[d])] = key;
+    }
+}
+
 // sorts keys[0..n) ascending considering only bits [lo_a, hi_a) and [lo_b, hi_b) (lo_b >= hi_a); returns the
 // pointer (keys or scratch.alt) that holds the sorted result.
 inline uint64_t *radix_sort_u64(uint64_t *keys, uint64_t n, int lo_a, int hi_a, int lo_b, int hi_b, SortScratch &s, hipStream_t st) {
     if (n == 0) return keys;
     uint64_t *src = keys, *dst = s.alt;
     int ranges[2][2] = {{lo_a, hi_a}, {lo_b, hi_b}};
+    if (s.status && n < (1ull << 32)) {   // one sweep: all passes' digit counts in one launch, one launch per pass
+        OsPlan plan{};
+        for (int rg = 0; rg < 2; ++rg) {
+            const int len = ranges[rg][1] - ranges[rg][0];
+            int shift = ranges[rg][0];
+            for (int k = 0; k < radix_passes(len); ++k) {
+                const int w = radix_width(len, k);
+                plan.shift[plan.n_passes] = shift; plan.bits[plan.n_passes] = std::max(w, 8); ++plan.n_passes;
+                shift += w;
+            }
+        }
+        if (plan.n_passes <= kOsMaxPasses) {
+            const uint32_t nb = sort_nblocks(n), hb = (uint32_t)std::min<uint64_t>(kOsHistBlocks, (n + 1023) / 1024);
+            uint32_t *partial = s.table, *base = s.offs;   // (both hold >= 512 x nblocks words)
+            (void)hipMemsetAsync(s.status, 0, (size_t)nb * 512 * sizeof(unsigned long long), st);
+            hipLaunchKernelGGL(k_os_hist, dim3(hb), dim3(1024), 0, st, (const uint64_t *)keys, n, plan, partial);
+            hipLaunchKernelGGL(k_os_bases, dim3(plan.n_passes), dim3(512), 0, st, (const uint32_t *)partial, hb, plan.n_passes, base);
+            for (int p = 0; p < plan.n_passes; ++p) {
+                if (plan.bits[p] > 8) hipLaunchKernelGGL(k_os_scatter<9>, dim3(nb), dim3(kSortThreads), 0, st, (const uint64_t *)src, dst, n, plan.shift[p], (const uint32_t *)base + p * 512, s.status, (uint32_t)p + 1u);
+                else hipLaunchKernelGGL(k_os_scatter<8>, dim3(nb), dim3(kSortThreads), 0, st, (const uint64_t *)src, dst, n, plan.shift[p], (const uint32_t *)base + p * 512, s.status, (uint32_t)p + 1u);
+                uint64_t *t = src; src = dst; dst = t;
+            }
+            return src;
+        }
+    }
     for (int rg = 0; rg < 2; ++rg) {
         const int len = ranges[rg][1] - ranges[rg][0];
         int shift = ranges[rg][0];

@@ -234,14 +234,16 @@ def test_bounded_scan_with_guide_batches_and_other_enzymes(capi, oracle, monkeyp
         assert gpu.n_hits > 0
 
 
-@pytest.mark.parametrize("sort", ["seg", "lsd", "bin"])
+@pytest.mark.parametrize("sort", ["seg", "lsd", "bin", "lsd-onesweep"])
 def test_hit_ordering_by_segments_and_by_six_passes_agree_with_the_oracle(capi, oracle, monkeypatch, sort):
     """the hits are ordered by two device-wide passes over the guide bits + one wave per guide ranking its segment (k_segsort), guides
     with more than 1024 raw hits by a block-level sort of their own (k_segsort_heavy); scans with many hits per guide take the
     six-pass LSD sort; a moderate number of hits takes one most-significant-digit pass + one in-LDS launch per bin of guides (round 5:
     k_msd_scatter, k_binsort; bins that outgrow LDS go through k_binsort_heavy).  FFH_SORT forces each: all must give the oracle's lists on a genome whose repeat families put thousands of
     raw hits on some guides and a handful on others."""
-    monkeypatch.setenv("FFH_SORT", sort)
+    monkeypatch.setenv("FFH_SORT", sort.split("-")[0])
+    if sort.endswith("onesweep"):
+        monkeypatch.setenv("FFH_ONESWEEP", "1")       # the LSD passes with decoupled look-back (off by default: profiles/r05/ab_log.txt 8)
     db = synth.make_repeat_database(900_000, seed=synth.DB_SEED + 21)
     g = synth.as_u64(synth.make_guides_from_database(db, 500, seed=synth.GUIDE_SEED + 21))
     t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
