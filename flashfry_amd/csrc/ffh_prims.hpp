@@ -558,7 +558,9 @@ constexpr uint32_t kBinCap = 12288;                         // keys of a bin k_b
 constexpr int kBinRows = kBinCap / kMsdThreads;
 constexpr int kBinMaxSubBits = 11;                          // guides per bin <= 2048
 
-inline uint32_t msd_nblocks(uint64_t n) { return (uint32_t)((n + kMsdChunk - 1) / kMsdChunk); }
+constexpr int kMsdRowsSmall = 4;
+inline int msd_rows(uint64_t n) { return n >= (uint64_t)128 * kMsdChunk ? kMsdRows : kMsdRowsSmall; }   // (below 2.1e6 keys: <= 512 bins, a 4 096-key block still writes runs of ~8 keys)
+inline uint32_t msd_nblocks(uint64_t n) { const uint64_t chunk = (uint64_t)msd_rows(n) * kMsdThreads; return (uint32_t)((n + chunk - 1) / chunk); }
 
 // exclusive scan over the 1024 threads of a block
 __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds /* >= 16 */, uint32_t &total) {
@@ -585,28 +587,33 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds /*
 
 // (keys whose guide field is >= n_guides are the all-ones padding of the compare waves' last chunks: counted nowhere and dropped by the
 // scatter, so the bins hold hits only and their total is the scan's number of real hits)
+// ROWS: keys per thread = 16 (16 384 per block) for the large scans, 4 for the mid-size ones (1e6 keys in 71 blocks left most of the part idle)
+template <int ROWS>
 __global__ __launch_bounds__(kMsdThreads) void k_msd_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift, uint32_t nbins, int tbits, uint32_t n_guides,
                                                            uint32_t *__restrict__ table /* [nbins][nblocks] */, uint32_t nblocks) {
     __shared__ uint32_t h[1 << kMsdMaxBits];
     for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) h[d] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * kMsdChunk;
-    uint64_t kreg[kMsdRows];
+    const uint64_t base = (uint64_t)blockIdx.x * (ROWS * kMsdThreads);
+    uint64_t kreg[ROWS];
 #pragma unroll
-    for (int r = 0; r < kMsdRows; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         const uint64_t i = base + (uint64_t)r * kMsdThreads + threadIdx.x;
         kreg[r] = i < n ? keys[i] : ~0ull;
     }
 #pragma unroll
-    for (int r = 0; r < kMsdRows; ++r)
+    for (int r = 0; r < ROWS; ++r)
         if ((kreg[r] >> tbits) < n_guides) atomicAdd(&h[(uint32_t)(kreg[r] >> shift) & (nbins - 1u)], 1u);
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) table[(uint64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
+template <int ROWS>
 __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift, uint32_t nbins, int tbits,
                                                               uint32_t n_guides, const uint32_t *__restrict__ offs /* scanned [nbins][nblocks] */, uint32_t nblocks) {
-    __shared__ uint64_t staged[kMsdChunk];                  // the chunk, digit-ordered (128 KB)
+    constexpr int kMsdRows = ROWS;
+    constexpr uint32_t kMsdChunk = (uint32_t)ROWS * kMsdThreads;
+    __shared__ uint64_t staged[kMsdChunk];                  // the chunk, digit-ordered (128 KB at 16 rows)
     __shared__ uint32_t cnt[1 << kMsdMaxBits], dig_start[1 << kMsdMaxBits], dig_goff[1 << kMsdMaxBits];
     __shared__ uint32_t scan_lds[16];
     const uint32_t t = threadIdx.x;
@@ -676,34 +683,44 @@ __device__ __forceinline__ void rank_segment(const uint32_t *__restrict__ idx, u
     if (c <= 64u) { sort_segment_regs<1>(idx, c, hi, keys, lane); return; }
     if (c <= 128u) { sort_segment_regs<2>(idx, c, hi, keys, lane); return; }
     if (c <= 256u) { sort_segment_regs<4>(idx, c, hi, keys, lane); return; }
-    for (uint32_t c0 = 0; c0 < c; c0 += (uint32_t)kBinRankRows * 64u) {
-        uint32_t a[kBinRankRows], rank[kBinRankRows];
+}
+// keys [c0, c0 + 64 ROWS) of a segment of c > 256 indices ranked against the whole segment out of LDS, four per broadcast step (the
+// rare large guide of a dense scan, by the wave that owns it; k_binsort<true> has the form for scans MADE of large guides)
+template <int ROWS>
+__device__ __forceinline__ void rank_unit(const uint32_t *__restrict__ idx, uint32_t c, uint32_t c0, uint64_t hi, uint64_t *__restrict__ keys, uint32_t lane) {
+    uint32_t a[ROWS], rank[ROWS];
 #pragma unroll
-        for (int r = 0; r < kBinRankRows; ++r) {
-            const uint32_t i = c0 + (uint32_t)r * 64u + lane;
-            a[r] = i < c ? idx[i] : 0xFFFFFFFFu;
-            rank[r] = 0;
-        }
-        for (uint32_t j = 0; j < c; j += 4) {   // (uniform addresses: LDS broadcasts)
-            const uint32_t v0 = idx[j], v1 = j + 1u < c ? idx[j + 1u] : 0xFFFFFFFFu, v2 = j + 2u < c ? idx[j + 2u] : 0xFFFFFFFFu, v3 = j + 3u < c ? idx[j + 3u] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < kBinRankRows; ++r) rank[r] += (v0 < a[r] ? 1u : 0u) + (v1 < a[r] ? 1u : 0u) + (v2 < a[r] ? 1u : 0u) + (v3 < a[r] ? 1u : 0u);
-        }
-#pragma unroll
-        for (int r = 0; r < kBinRankRows; ++r)
-            if (c0 + (uint32_t)r * 64u + lane < c) keys[rank[r]] = hi | a[r];
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t i = c0 + (uint32_t)r * 64u + lane;
+        a[r] = i < c ? idx[i] : 0xFFFFFFFFu;
+        rank[r] = 0;
     }
+    for (uint32_t j = 0; j < c; j += 4) {   // (uniform addresses: LDS broadcasts)
+        const uint32_t v0 = idx[j], v1 = j + 1u < c ? idx[j + 1u] : 0xFFFFFFFFu, v2 = j + 2u < c ? idx[j + 2u] : 0xFFFFFFFFu, v3 = j + 3u < c ? idx[j + 3u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) rank[r] += (v0 < a[r] ? 1u : 0u) + (v1 < a[r] ? 1u : 0u) + (v2 < a[r] ? 1u : 0u) + (v3 < a[r] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+        if (c0 + (uint32_t)r * 64u + lane < c) keys[rank[r]] = hi | a[r];
 }
 
 // bin d = keys [offs[d * nblocks], offs[(d + 1) * nblocks]) of `keys` (the digit-major table k_msd_scatter used: block 0's offset of a
 // digit is where the digit's run begins); in place.
+// COOP: guides with more than 256 hits are set aside and ordered by all 16 waves together after the rest -- the form for scans whose
+// guides are few and large (ten guides of 1 140 hits each: one wave per guide left fifteen idle for 0.25 ms); without it each wave ranks
+// its own guides whatever their size and leaves as soon as it is done (the hg38-scale scan: 116 hits a guide; the barrier and the second
+// phase cost 20 of 122 us there, profiles/r05/ab_log.txt item 9)
+template <bool COOP>
 __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ keys, const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t nbins, uint64_t n_total,
                                                           int tbits, int sub_bits, uint32_t n_guides, uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_end,
                                                           uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ n_heavy) {
     __shared__ uint32_t idx[kBinCap];
     __shared__ uint32_t cnt[(1 << kBinMaxSubBits) + 2], start[(1 << kBinMaxSubBits) + 2];
     __shared__ uint32_t scan_lds[16];
+    __shared__ uint32_t big[COOP ? kBinCap / 256 + 2 : 1], n_big;   // the bin's guides with more than 256 hits: ranked by all waves together (below)
     const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), bin = blockIdx.x;
+    if (COOP && t == 0) n_big = 0;
     // offs == nullptr: ONE bin = all n_total records as the compare launch left them, chunk padding included (a small scan: this launch
     // is the whole ordering); the padding is dropped as the records are read
     const uint32_t b0 = offs ? offs[(uint64_t)bin * nblocks] : 0u, b1 = !offs || bin + 1u >= nbins ? (uint32_t)n_total : offs[(uint64_t)(bin + 1u) * nblocks], n = b1 - b0;
@@ -747,8 +764,70 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
         if (c == 0u) continue;
         const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[s]), guide = (bin << sub_bits) | s;
         if (lane == 0) { seg_begin[guide] = b0 + st; seg_end[guide] = b0 + st + c; }
-        rank_segment(idx + st, c, (uint64_t)guide << tbits, keys + b0 + st, lane);
+        if (c <= 256u) rank_segment(idx + st, c, (uint64_t)guide << tbits, keys + b0 + st, lane);
+        else if (COOP) { if (lane == 0) big[atomicAdd(&n_big, 1u)] = s; }
+        else for (uint32_t c0 = 0; c0 < c; c0 += 512u) rank_unit<8>(idx + st, c, c0, (uint64_t)guide << tbits, keys + b0 + st, lane);
     }
+    if (!COOP) return;
+    __syncthreads();
+    // the large guides, in chunks of 256 indices dealt round-robin to the 16 waves: every chunk ordered in registers and put back (1),
+    // then every index ranked = its place in its own chunk + the number of smaller indices in each other chunk of the guide, found by
+    // bisection (2): 9 LDS reads per other chunk and index -- ranking against every index of the guide, four per broadcast step, cost
+    // 285 steps of 8 reads for a guide of 1 140 hits, 0.28 ms for ten of them in one block
+    const uint32_t nb = n_big;
+    auto for_chunks = [&](auto &&fn) {
+        uint32_t i = 0, first = 0;   // chunks of big[0 .. i) = first
+        for (uint32_t u = wave; i < nb; u += kMsdThreads / 64) {
+            uint32_t c = 0, s = 0;
+            for (; i < nb; ++i) {
+                s = big[i]; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[s]);
+                const uint32_t units = (c + 255u) / 256u;
+                if (u < first + units) break;
+                first += units;
+            }
+            if (i >= nb) break;
+            fn(s, c, (uint32_t)__builtin_amdgcn_readfirstlane((int)start[s]), (u - first) * 256u);
+        }
+    };
+    for_chunks([&](uint32_t, uint32_t c, uint32_t st, uint32_t c0) {
+        uint32_t x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = c0 + (uint32_t)r * 64u + lane < c ? idx[st + c0 + (uint32_t)r * 64u + lane] : 0xFFFFFFFFu;
+        bitonic_sort<4>(x, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c0 + (uint32_t)r * 64u + lane < c) idx[st + c0 + (uint32_t)r * 64u + lane] = x[r];
+    });
+    __syncthreads();
+    for_chunks([&](uint32_t s, uint32_t c, uint32_t st, uint32_t c0) {
+        uint32_t x[4], rank[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t e = c0 + (uint32_t)r * 64u + lane;
+            x[r] = e < c ? idx[st + e] : 0xFFFFFFFFu;
+            rank[r] = (uint32_t)r * 64u + lane;
+        }
+        for (uint32_t q0 = 0; q0 < c; q0 += 256u) {
+            if (q0 == c0) continue;
+            const uint32_t *__restrict__ other = idx + st + q0;
+            const uint32_t lq = min(256u, c - q0);
+            uint32_t pos[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t step = 256u; step; step >>= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t p = pos[r] + step;
+                    if (p <= lq && other[p - 1u] < x[r]) pos[r] = p;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rank[r] += pos[r];
+        }
+        const uint64_t hi = (uint64_t)((bin << sub_bits) | s) << tbits;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c0 + (uint32_t)r * 64u + lane < c) keys[b0 + st + rank[r]] = hi | x[r];
+    });
 }
 
 // the bins k_binsort listed: sorted through memory by their low tbits + sub_bits bits, then the guides' segments found in the sorted run

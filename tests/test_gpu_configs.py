@@ -260,6 +260,26 @@ def test_hit_ordering_by_segments_and_by_six_passes_agree_with_the_oracle(capi, 
     assert_same_hits(cut, odb.discover(g, 5, 300))
 
 
+@pytest.mark.parametrize("n_guides,variants", [(1, 1500), (9, 1100), (9, 3000), (40, 1200), (300, 600)])
+def test_scans_made_of_a_few_large_guides(capi, oracle, n_guides, variants):
+    """a handful of guides with a thousand hits each (a five-mismatch look-up of ten guides): one block of k_binsort<true> holds the
+    whole scan (<= 12 288 records) or a bin of it, and its 16 waves share every guide -- chunks of 256 indices ordered in registers,
+    then ranked against the guide's other chunks by bisection.  9 x 1 100 fits the single block, 9 x 3 000 and 40 x 1 200 take the
+    digit pass first (a few guides per bin), 300 x 600 mixes guides above and below the 256-hit network.  No cut-off: every hit is
+    delivered, so the order of every segment is checked."""
+    from tests.test_gpu_parity import dense_case
+    odb, t, p, g = dense_case(oracle, n_random=40_000, n_guides=n_guides, n_dense=n_guides, variants=variants, seed=70 + n_guides)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(t, p)
+        ctx.set_bounding(0)
+        gpu = ctx.discover(g, 4, 2 ** 31 - 1, jost=True)
+        cut = ctx.discover(g, 3, 50)
+    per_guide = np.diff(gpu.guide_offsets.astype(np.int64))
+    assert per_guide.max() > 256 and per_guide.mean() > 256, per_guide
+    assert_same_hits(gpu, odb.discover(g, 4, 2 ** 31 - 1))
+    assert_same_hits(cut, odb.discover(g, 3, 50))
+
+
 def test_two_part_pipelined_discover_delivers_the_same_result(capi, oracle, monkeypatch):
     """FFH_PIPELINE=1 (off by default: slower on this stack, profiles/r05/ab_log.txt 7): a list-delivering ffh_discover scans 60 % of
     the guides, leaves their lists on the copy stream, scans the rest and delivers both parts in ONE result block.  Every array must be
