@@ -169,9 +169,55 @@ inline uint64_t scan_scratch_elems_safe(uint64_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Count tables of the radix passes: BLOCK-major, table[block][digit] -- a block leaves its counts as one contiguous run and reads its
+// offsets the same way.  (Digit-major until round 5: 512 four-byte writes per block into lines shared with the neighbouring blocks cost
+// a histogram pass over 4.7e7 keys 54 of its 128 us, tools/probes/bw_probe.hip; block-major costs 8.)  The offsets a pass needs are the
+// exclusive scan of the counts in digit-major order: offs[b][d] = sum of all counts of digits < d + counts of digit d in blocks < b.
+//   k_tab_colsum   per group of T blocks, the digit's count over the group  -> partial[digit][group]   (coalesced reads across digits)
+//   exclusive_scan of partial (digits x groups, a few 1e5 entries)
+//   k_tab_apply    per group: the running offset of every digit walked down the group's blocks      -> offs[block][digit]
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kTabThreads = 256, kTabGroupMin = 8;
+inline uint32_t tab_group(uint32_t nblocks) { uint32_t t = kTabGroupMin; while ((nblocks + t - 1) / t > 512u) t *= 2u; return t; }
+// elements a table buffer must hold for `nblocks` blocks of `digits` counts: the table, then partial, then its scan
+inline size_t tab_elems(uint32_t nblocks, uint32_t digits) { return (size_t)digits * nblocks + 2 * ((size_t)digits * (nblocks / kTabGroupMin + 2) + 8) + 8; }
+
+__global__ __launch_bounds__(kTabThreads) void k_tab_colsum(const uint32_t *__restrict__ table, uint32_t digits, uint32_t nblocks, uint32_t T, uint32_t ngroups,
+                                                            uint32_t *__restrict__ partial) {
+    const uint32_t g = blockIdx.x, b0 = g * T, b1 = min(nblocks, b0 + T);
+    for (uint32_t d = threadIdx.x; d < digits; d += kTabThreads) {
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (uint32_t b = b0; b < b1; ++b) sum += table[(uint64_t)b * digits + d];
+        partial[(uint64_t)d * ngroups + g] = sum;
+    }
+}
+__global__ __launch_bounds__(kTabThreads) void k_tab_apply(const uint32_t *__restrict__ table, uint32_t digits, uint32_t nblocks, uint32_t T, uint32_t ngroups,
+                                                           const uint32_t *__restrict__ pscan, uint32_t *__restrict__ offs) {
+    const uint32_t g = blockIdx.x, b0 = g * T, b1 = min(nblocks, b0 + T);
+    for (uint32_t d = threadIdx.x; d < digits; d += kTabThreads) {
+        uint32_t run = pscan[(uint64_t)d * ngroups + g];
+#pragma unroll 8
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t v = table[(uint64_t)b * digits + d];
+            offs[(uint64_t)b * digits + d] = run;
+            run += v;
+        }
+    }
+}
+// table: tab_elems(nblocks, digits) elements, the counts in front; offs: digits x nblocks; scan_tmp: scan_scratch_elems_safe(digits x nblocks) or more
+inline void tab_scan(uint32_t *table, uint32_t digits, uint32_t nblocks, uint32_t *offs, uint32_t *scan_tmp, hipStream_t st) {
+    const uint32_t T = tab_group(nblocks), ng = (nblocks + T - 1) / T;
+    uint32_t *partial = table + (((size_t)digits * nblocks + 7) & ~(size_t)7), *pscan = partial + (((size_t)digits * ng + 8) & ~(size_t)7);
+    hipLaunchKernelGGL(k_tab_colsum, dim3(ng), dim3(kTabThreads), 0, st, (const uint32_t *)table, digits, nblocks, T, ng, partial);
+    exclusive_scan<uint32_t, uint32_t>(partial, (uint64_t)digits * ng, pscan, scan_tmp, st);
+    hipLaunchKernelGGL(k_tab_apply, dim3(ng), dim3(kTabThreads), 0, st, (const uint32_t *)table, digits, nblocks, T, ng, (const uint32_t *)pscan, offs);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LSD radix sort of u64 keys, BITS (8 or 9) bits per pass, only over the caller-given bit ranges.
-// A 256-thread block owns a contiguous chunk of 4096 keys.  Per pass: histogram -> scan of the digit-major
-// (2^BITS x nblocks) table -> scatter.  The scatter ranks the chunk stably (wave w owns rows w*16..w*16+15, ranked row
+// A 256-thread block owns a contiguous chunk of 4096 keys.  Per pass: histogram -> scan of the (nblocks x 2^BITS)
+// count table (tab_scan) -> scatter.  The scatter ranks the chunk stably (wave w owns rows w*16..w*16+15, ranked row
 // by row with ballots), stages it digit-ordered in LDS and writes every digit's run contiguously, so the global
 // stores are coalesced runs instead of 8-byte scatters.
 // ---------------------------------------------------------------------------------------------------------
@@ -182,7 +228,7 @@ constexpr int kSortMaxBits = 9;
 
 template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift,
-                                                             uint32_t *__restrict__ table /* [2^BITS][nblocks] */, uint32_t nblocks) {
+                                                             uint32_t *__restrict__ table /* [nblocks][2^BITS] */, uint32_t nblocks) {
     constexpr uint32_t DIG = 1u << BITS;
     __shared__ uint32_t h[DIG];
     for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) h[d] = 0;
@@ -194,13 +240,13 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__re
         if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (DIG - 1u)], 1u);
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) table[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+    for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) table[(uint64_t)blockIdx.x * DIG + d] = h[d];
 }
 
 // VALS: a u64 payload travels with every key (same stable permutation), staged through the same LDS buffer after the keys
 template <bool VALS, int BITS>
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift,
-                                                                const uint32_t *__restrict__ offs /* scanned [2^BITS][nblocks] */, uint32_t nblocks,
+                                                                const uint32_t *__restrict__ offs /* scanned [nblocks][2^BITS] */, uint32_t nblocks,
                                                                 const uint64_t *__restrict__ vals, uint64_t *__restrict__ vout) {
     constexpr uint32_t DIG = 1u << BITS, PER = DIG / kSortThreads;   // digits owned by a thread: 2t .. 2t + PER - 1
     static_assert(BITS >= 8 && BITS <= kSortMaxBits, "256 or 512 digits per pass");
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
     for (uint32_t d = threadIdx.x; d < DIG; d += kSortThreads) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) wave_cnt[w][d] = 0;
-        dig_goff[d] = offs[(uint64_t)d * nblocks + blockIdx.x];
+        dig_goff[d] = offs[(uint64_t)blockIdx.x * DIG + d];
     }
     __syncthreads();
     // pass 1: per-wave digit counts
@@ -590,7 +636,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *lds /*
 // ROWS: keys per thread = 16 (16 384 per block) for the large scans, 4 for the mid-size ones (1e6 keys in 71 blocks left most of the part idle)
 template <int ROWS>
 __global__ __launch_bounds__(kMsdThreads) void k_msd_hist(const uint64_t *__restrict__ keys, uint64_t n, int shift, uint32_t nbins, int tbits, uint32_t n_guides,
-                                                           uint32_t *__restrict__ table /* [nbins][nblocks] */, uint32_t nblocks) {
+                                                           uint32_t *__restrict__ table /* [nblocks][nbins] */, uint32_t nblocks) {
     __shared__ uint32_t h[1 << kMsdMaxBits];
     for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) h[d] = 0;
     __syncthreads();
@@ -605,12 +651,12 @@ __global__ __launch_bounds__(kMsdThreads) void k_msd_hist(const uint64_t *__rest
     for (int r = 0; r < ROWS; ++r)
         if ((kreg[r] >> tbits) < n_guides) atomicAdd(&h[(uint32_t)(kreg[r] >> shift) & (nbins - 1u)], 1u);
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) table[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+    for (uint32_t d = threadIdx.x; d < nbins; d += kMsdThreads) table[(uint64_t)blockIdx.x * nbins + d] = h[d];
 }
 
 template <int ROWS>
 __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, uint64_t n, int shift, uint32_t nbins, int tbits,
-                                                              uint32_t n_guides, const uint32_t *__restrict__ offs /* scanned [nbins][nblocks] */, uint32_t nblocks) {
+                                                              uint32_t n_guides, const uint32_t *__restrict__ offs /* scanned [nblocks][nbins] */, uint32_t nblocks) {
     constexpr int kMsdRows = ROWS;
     constexpr uint32_t kMsdChunk = (uint32_t)ROWS * kMsdThreads;
     __shared__ uint64_t staged[kMsdChunk];                  // the chunk, digit-ordered (128 KB at 16 rows)
@@ -626,7 +672,7 @@ __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__r
         const uint32_t i = (uint32_t)r * kMsdThreads + t;
         kreg[r] = i < here ? keys[base + i] : ~0ull;
     }
-    for (uint32_t d = t; d < nbins; d += kMsdThreads) { cnt[d] = 0; dig_goff[d] = offs[(uint64_t)d * nblocks + blockIdx.x]; }
+    for (uint32_t d = t; d < nbins; d += kMsdThreads) { cnt[d] = 0; dig_goff[d] = offs[(uint64_t)blockIdx.x * nbins + d]; }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kMsdRows; ++r) {
@@ -705,8 +751,8 @@ __device__ __forceinline__ void rank_unit(const uint32_t *__restrict__ idx, uint
         if (c0 + (uint32_t)r * 64u + lane < c) keys[rank[r]] = hi | a[r];
 }
 
-// bin d = keys [offs[d * nblocks], offs[(d + 1) * nblocks]) of `keys` (the digit-major table k_msd_scatter used: block 0's offset of a
-// digit is where the digit's run begins); in place.
+// bin d = keys [offs[d], offs[d + 1]) of `keys` (row 0 of the table k_msd_scatter used: block 0's offset of a digit is where the
+// digit's run begins); in place.
 // COOP: guides with more than 256 hits are set aside and ordered by all 16 waves together after the rest -- the form for scans whose
 // guides are few and large (ten guides of 1 140 hits each: one wave per guide left fifteen idle for 0.25 ms); without it each wave ranks
 // its own guides whatever their size and leaves as soon as it is done (the hg38-scale scan: 116 hits a guide; the barrier and the second
@@ -723,7 +769,7 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
     if (COOP && t == 0) n_big = 0;
     // offs == nullptr: ONE bin = all n_total records as the compare launch left them, chunk padding included (a small scan: this launch
     // is the whole ordering); the padding is dropped as the records are read
-    const uint32_t b0 = offs ? offs[(uint64_t)bin * nblocks] : 0u, b1 = !offs || bin + 1u >= nbins ? (uint32_t)n_total : offs[(uint64_t)(bin + 1u) * nblocks], n = b1 - b0;
+    const uint32_t b0 = offs ? offs[bin] : 0u, b1 = !offs || bin + 1u >= nbins ? (uint32_t)n_total : offs[bin + 1u], n = b1 - b0;
     if (n == 0u) return;
     if (n > kBinCap) {
         if (t == 0) heavy_list[atomicAdd(n_heavy, 1u)] = bin;
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(256) void k_binsort_heavy(uint64_t *__restrict__ ke
     const uint32_t nh = *n_heavy;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t bin = heavy_list[h];
-        const uint32_t b0 = offs[(uint64_t)bin * nblocks], b1 = bin + 1u < nbins ? offs[(uint64_t)(bin + 1u) * nblocks] : (uint32_t)n_total, n = b1 - b0;
+        const uint32_t b0 = offs[bin], b1 = bin + 1u < nbins ? offs[bin + 1u] : (uint32_t)n_total, n = b1 - b0;
         uint64_t *k = keys + b0;
         block_lsd_sort(k, alt + b0, n, tbits + sub_bits, L);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -869,11 +915,11 @@ inline void radix_pass(const uint64_t *src, uint64_t *dst, const uint64_t *vsrc,
     const uint32_t nb = sort_nblocks(n);
     if (bits > 8) {
         hipLaunchKernelGGL(k_sort_hist<9>, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
-        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)512 * nb, s.offs, s.scan_tmp, st);
+        tab_scan(s.table, 512u, nb, s.offs, s.scan_tmp, st);
         hipLaunchKernelGGL((k_sort_scatter<VALS, 9>), dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, vsrc, vdst);
     } else {
         hipLaunchKernelGGL(k_sort_hist<8>, dim3(nb), dim3(kSortThreads), 0, st, src, n, shift, s.table, nb);
-        exclusive_scan<uint32_t, uint32_t>(s.table, (uint64_t)256 * nb, s.offs, s.scan_tmp, st);
+        tab_scan(s.table, 256u, nb, s.offs, s.scan_tmp, st);
         hipLaunchKernelGGL((k_sort_scatter<VALS, 8>), dim3(nb), dim3(kSortThreads), 0, st, src, dst, n, shift, s.offs, nb, vsrc, vdst);
     }
 }
