@@ -22,6 +22,7 @@ struct Switches {
     bool no_spin = false;            // FFH_NO_SPIN=1: hipStreamSynchronize instead of polling the published counters
     uint32_t max_guide_batch = 0;    // FFH_MAX_GUIDE_BATCH: guides per compare launch at most (0: what the candidate list allows)
     bool inflate_host = false;       // FFH_INFLATE=host: BGZF members inflated on host threads instead of on the device
+    bool inflate_device = false;     // FFH_INFLATE=device: on the device even for a small body (default there: host threads + one copy)
     long work_list_limit = 0;        // FFH_WORK_LIST_LIMIT: first size of the compare launch's work list (forces the run-again path)
     bool slab_prefix_per_slab = false;   // FFH_SLAB_PREFIX=per-slab: a bounded scan bins the prefix candidates per slab
     bool graph = true;               // FFH_GRAPH=0: never replay the candidate-list launches as a captured graph
@@ -33,6 +34,7 @@ struct Switches {
                                      // <= 2 or >= 6 mismatches -- always deal with a fixed stride, launch_compare_pair)
     bool pipeline = false;           // FFH_PIPELINE=1: a list-delivering ffh_discover scans its guide set in two parts, the first part's lists crossing the
                                      // link under the second part's scan.  OFF: measured slower on this stack (profiles/r05/ab_log.txt 7); kept for tests / A-B
+    bool load_pipeline = false;      // FFH_LOAD_PIPELINE=1: ffh_db_open moves even a small body through the threaded page-locked pipeline (A/B)
     bool one_sweep = false;          // FFH_ONESWEEP=1: the device-wide LSD sort with decoupled look-back instead of a histogram launch + scan per pass.
                                      // OFF: slower on this part (3.27 against 2.45 ms for 4.7e7 keys, profiles/r05/ab_log.txt 8); kept for tests / A-B
     int nb_force[2] = {0, 0};        // FFH_NB_PREFIX / FFH_NB_SUFFIX: buckets per work entry of the image (A/B; 0: side_plan's rule)
@@ -49,6 +51,7 @@ struct Switches {
         s.no_spin = num("FFH_NO_SPIN", 0) == 1;
         { const long v = num("FFH_MAX_GUIDE_BATCH", 0); s.max_guide_batch = v > 0 ? (uint32_t)v : 0u; }
         s.inflate_host = is("FFH_INFLATE", "host");
+        s.inflate_device = is("FFH_INFLATE", "device");
         { const long v = num("FFH_WORK_LIST_LIMIT", 0); s.work_list_limit = v > 0 ? v : 0; }
         s.slab_prefix_per_slab = is("FFH_SLAB_PREFIX", "per-slab");
         s.graph = num("FFH_GRAPH", 1) != 0;
@@ -58,6 +61,7 @@ struct Switches {
         s.work_queue = (int)num("FFH_WORK_QUEUE", -1);
         s.pipeline = num("FFH_PIPELINE", 0) == 1;
         s.one_sweep = num("FFH_ONESWEEP", 0) == 1;
+        s.load_pipeline = num("FFH_LOAD_PIPELINE", 0) == 1;
         s.nb_force[0] = (int)num("FFH_NB_PREFIX", 0); s.nb_force[1] = (int)num("FFH_NB_SUFFIX", 0);
         { const long v = num("FFH_RAW_HIT_LIMIT", 0); if (v > 0) s.raw_hit_limit = (uint64_t)v; }
         return s;

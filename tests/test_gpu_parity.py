@@ -374,8 +374,9 @@ def _rewrite_bgzf(src, dst, member_bytes, level, strategy):
 @pytest.mark.parametrize("member_bytes,level,strategy", [(65280, 5, "default"), (65000, 0, "default"), (4096, 9, "default"), (32768, 6, "fixed"),
                                                          (65280, 6, "huffman_only"), (8192, 1, "rle"), (65280, 9, "filtered")])
 def test_device_inflate_handles_every_deflate_block_type(capi, oracle, tmp_path, monkeypatch, member_bytes, level, strategy):
-    """the BGZF members are inflated on the device (ffh_inflate.hpp): stored, fixed-Huffman and dynamic-Huffman blocks, short and
-    long matches, small and full-size members; the host-thread inflate (FFH_INFLATE=host) must give the same database"""
+    """the BGZF members are inflated on the device (ffh_inflate.hpp; FFH_INFLATE=device forces it for a body this small, which the
+    host threads take by default since round 5): stored, fixed-Huffman and dynamic-Huffman blocks, short and long matches, small and
+    full-size members; the host-thread inflate (FFH_INFLATE=host, and the default here) must give the same database"""
     import zlib
     odb, t, p, g = make_case(oracle, 40000, 60, enzyme=3, seed=77, max_linear=500)
     src, dst = str(tmp_path / "src_db"), str(tmp_path / "re_db")
@@ -383,12 +384,17 @@ def test_device_inflate_handles_every_deflate_block_type(capi, oracle, tmp_path,
     strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED, "huffman_only": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE, "filtered": zlib.Z_FILTERED}[strategy]
     _rewrite_bgzf(src, dst, member_bytes, level, strat)
     ora = odb.discover(g, 4, 2000)
-    for where in ("device", "host"):
-        monkeypatch.setenv("FFH_INFLATE", where)
+    for where in ("device", "host", "default", "pipeline"):
+        monkeypatch.delenv("FFH_INFLATE", raising=False)
+        monkeypatch.delenv("FFH_LOAD_PIPELINE", raising=False)
+        if where in ("device", "host"):
+            monkeypatch.setenv("FFH_INFLATE", where)
+        if where == "pipeline":
+            monkeypatch.setenv("FFH_LOAD_PIPELINE", "1")        # the large-body path (page-locked arena, copy streams, device inflate)
         with capi.Context(3) as ctx:
             ctx.open(dst)
             st = ctx.load_stats()
-            assert (st.device_inflate_ms > 0) == (where == "device")
+            assert (st.device_inflate_ms > 0) == (where in ("device", "pipeline"))
             assert (ctx.info().n_targets, ctx.info().n_positions) == (len(t), len(p))
             assert_same_hits(ctx.discover(g, 4, 2000), ora)
             c2 = capi.Context(3)
@@ -396,14 +402,19 @@ def test_device_inflate_handles_every_deflate_block_type(capi, oracle, tmp_path,
             n_mid = c2.info().n_targets
             c2.close()
         assert 0 < n_mid < len(t)
-    # a flipped payload bit must be caught by the CRC check on the device
-    monkeypatch.setenv("FFH_INFLATE", "device")
+    # a flipped payload bit must be caught by the CRC check, on the device and on the host threads
+    monkeypatch.delenv("FFH_LOAD_PIPELINE", raising=False)
     blob = bytearray(open(dst, "rb").read())
     blob[len(blob) // 2] ^= 0x10
     open(dst, "wb").write(bytes(blob))
-    with capi.Context(3) as ctx:
-        with pytest.raises(capi.FlashFryHipError, match="inflate / crc failure|BGZF"):
-            ctx.open(dst)
+    for where in ("device", None):
+        if where:
+            monkeypatch.setenv("FFH_INFLATE", where)
+        else:
+            monkeypatch.delenv("FFH_INFLATE", raising=False)
+        with capi.Context(3) as ctx:
+            with pytest.raises(capi.FlashFryHipError, match="inflate / crc failure|BGZF"):
+                ctx.open(dst)
 
 
 def test_device_resident_exchange_entry_points(capi, oracle):

@@ -58,7 +58,7 @@ def timed(cmd, key="comparisons"):
     dt = time.perf_counter() - t0
     if p.returncode:
         raise SystemExit("FAILED %s\n%s" % (" ".join(cmd), p.stderr[-2000:]))
-    detail = [l for l in p.stderr.splitlines() if key in l or "Database load" in l or "Host stages" in l]
+    detail = [l for l in p.stderr.splitlines() if key in l or "Database load" in l or "Host stages" in l or "[ffh ingest]" in l]
     return dt, " | ".join(detail)
 
 
