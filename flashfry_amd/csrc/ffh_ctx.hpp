@@ -249,7 +249,7 @@ struct ffh_ctx {
     uint64_t pattern_gen = 0;   // moves on with every pattern upload: a captured launch sequence reads patterns[side] and must not outlive its content
     DevBuf<uint32_t> icount, ifill, item_gid, scan_tmp32;
     // candidate binning and work list of one image
-    struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, part_start, gp_start, by_part, scan_tmp; } side_scr[2];
+    struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, gp_start, by_part; } side_scr[2];
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2];                             // work entries per batch of buckets + per block of 1024 batches
     DevBuf<WorkEntry> wl_list[2];                             // the compare kernel's work list, per image

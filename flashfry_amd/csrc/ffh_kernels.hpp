@@ -212,7 +212,7 @@ __global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Ge
 // capacity guess, so skewed guide sets (tiling libraries, repeats) cost nothing extra -- and without per-entry global
 // atomics (device-scope atomics on random addresses run at ~1.3e10/s on MI355X: 4 ms for the 5.6e7 entries of the
 // hg38-scale workload):
-//   A k_guide_part_hist + k_part_sizes : the partition (= high bits of the bucket id) sizes, computed without touching
+//   A k_guide_part_hist + the size blocks of k_guide_by_part's launch (k_part_sizes until round 5): the partition (= high bits of the bucket id) sizes, computed without touching
 //                           the entries (XOR convolution of two histograms);  exclusive scan of the <= 4096 sizes;
 //   B k_guide_by_part + k_item_bin_direct : the guides grouped by partition, then one block per partition enumerates its own
 //                           entries from those runs, counts them per bucket in LDS, scans the counts, writes the CSR offsets of
@@ -237,7 +237,7 @@ struct ItemGeom {
     // one slab of a bounded scan (prefix image only): keep the entries whose bucket's first three bases, read as a number 0..63 in
     // sequence order, lie in [rank_lo, rank_hi].  The bucket id holds the planes apart (all high bits, then all low bits), so a
     // slab of the database order is not a range of bucket ids; {0, 63} = everything, and the partition sizes then still come from
-    // k_part_sizes.
+    // the size blocks of k_guide_by_part's launch.
     uint32_t rank_lo, rank_hi, width;
 };
 
@@ -311,18 +311,8 @@ __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__rest
         if (c) atomicAdd(&ghist[d], c);
     }
 }
-// one wave per partition, the lanes stride over the patterns (a thread per partition left 4096 threads walking 529 patterns each: 36 us)
-__global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__ ghist, const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits,
-                                                    uint32_t *__restrict__ part_count) {
-    const uint32_t q = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (q >= ig.n_part) return;
-    uint32_t n = 0;
-    for (uint32_t p = lane; p < ig.n_pat; p += 64) n += ghist[q ^ (patterns[p] >> ig.low_bits)];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
-    const bool live = part_live_wave(ig, q, part_bits, lane);
-    if (lane == 0) part_count[q] = live ? n : 0u;   // partitions without a target take no entries
-}
+// (the partitions' entry counts: a wave per partition, the lanes striding over the patterns -- a thread per partition left 4096 threads
+// walking 529 patterns each: 36 us --, in the blocks behind the sorting ones of k_guide_by_part's launch)
 
 // ---------------------------------------------------------------------------------------------------------
 // The CSR is built without intermediate records (round 3; round 2 wrote every entry as a 4-byte record into one of 4096 runs first and
@@ -337,12 +327,27 @@ __global__ __launch_bounds__(256) void k_part_sizes(const uint32_t *__restrict__
 // put ~400 same-address global atomics on every counter: 47 us; this way a few per block)
 // (round 5: the exclusive scan of the partition histogram -- <= 4096 counters -- is done by every block for itself in LDS instead of in
 // two launches of its own; block 0 leaves it in gp_start for k_item_bin_direct)
+// (... and the partitions' entry counts, which need the same histogram and nothing else, are computed by the blocks from `sort_blocks` on
+// of the same launch -- k_part_sizes' work, a wave per partition: one launch less per image and step.  patterns == nullptr: not wanted,
+// a slab of a bounded scan counts its entries with k_item_bin_direct<true, true>.)
 __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
                                                         const uint32_t *__restrict__ part_hist, uint32_t *__restrict__ gp_start /* [n_part + 1] out */,
-                                                        uint32_t *__restrict__ gp_fill /* zeroed */, uint32_t *__restrict__ by_part) {
+                                                        uint32_t *__restrict__ gp_fill /* zeroed */, uint32_t *__restrict__ by_part, uint32_t sort_blocks,
+                                                        const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, uint32_t *__restrict__ part_count) {
     __shared__ uint32_t cnt[1 << kMaxPartBits];
     __shared__ uint32_t start[1 << kMaxPartBits];
     __shared__ uint32_t scan_lds[16];
+    if (blockIdx.x >= sort_blocks) {
+        const uint32_t q = (blockIdx.x - sort_blocks) * 16u + wave_uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (q >= ig.n_part) return;
+        uint32_t n = 0;
+        for (uint32_t p = lane; p < ig.n_pat; p += 64) n += part_hist[q ^ (patterns[p] >> ig.low_bits)];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+        const bool live = part_live_wave(ig, q, part_bits, lane);
+        if (lane == 0) part_count[q] = live ? n : 0u;   // partitions without a target take no entries
+        return;
+    }
     {   // start[q] = guides in the partitions before q: four counters per thread
         uint32_t c[4], sum = 0;
 #pragma unroll
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restri
 // its rank filter looks at the low bucket bits, so the XOR convolution of k_part_sizes does not apply) -> part_count[d].
 template <bool COUNT, bool SLAB>
 __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint32_t *__restrict__ gp_start, const uint32_t *__restrict__ by_part,
-                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, const uint32_t *__restrict__ part_start,
+                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, const uint32_t *__restrict__ part_size /* entries per partition (placing) */,
                                                                   uint32_t *__restrict__ part_count, uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid,
                                                                   const uint32_t *__restrict__ bstart, unsigned long long *__restrict__ part_pairs) {
     __shared__ uint32_t cnt[1 << kMaxLowBits];
@@ -427,7 +432,15 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint3
         if (threadIdx.x == 0) part_count[d] = tot;
         return;
     }
-    const uint32_t p0 = part_start[d], n = part_start[d + 1] - p0;
+    // the entries of the partitions before this one: every block adds up its own prefix of the <= 4096 sizes (an exclusive scan in one
+    // or two launches of its own until round 5)
+    uint32_t p0 = 0;
+    {
+        uint32_t before = 0;
+        for (uint32_t q = threadIdx.x; q < d; q += kPartThreads) before += part_size[q];
+        (void)block_exclusive_scan_1024(before, scan_lds, p0);
+    }
+    const uint32_t n = part_size[d];
     const uint32_t gbase = ig.item_base + p0;  // the entries of partition d occupy CSR slots [item_base + p0, + n)
     {   // exclusive scan of the nlow counters: CSR offsets out, counters become placement cursors; the executed-pair statistic
         uint32_t mine = 0;
