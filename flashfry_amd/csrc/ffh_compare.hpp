@@ -411,10 +411,22 @@ __device__ __forceinline__ WorkSplit work_split(uint32_t ngr, uint32_t nc, uint3
 // sensitive to: handing the blocks their ranges through an atomic, in order of arrival, cost 5 % of the compare launch at hg38 scale
 // and 40 % on the repeat-structured workload, profiles/r05/ab_log.txt 5.)
 constexpr int kWorkThreads = 1024;
-__global__ __launch_bounds__(kWorkThreads) void k_work_count(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
-                                                             uint32_t n_bat, uint32_t *__restrict__ counts, uint32_t *__restrict__ block_sums,
-                                                             const unsigned long long *__restrict__ part_pairs, uint32_t n_part, unsigned long long *__restrict__ pairs_out,
-                                                             uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+// (both images' lists in one launch: blockIdx.y picks the image, see k_guide_keys)
+struct WorkEntry;
+struct WorkArgs {
+    const uint32_t *gstart, *istart; uint32_t nb, NB, split, n_bat; uint32_t *counts, *block_sums;
+    const unsigned long long *part_pairs; uint32_t n_part; unsigned long long *pairs_out;
+    WorkEntry *list; uint32_t list_cap; unsigned long long *n_out; uint32_t *n_list /* the same number where the compare launch reads it: a line of its own */;
+    uint32_t rank_lo, rank_hi, width, grid;
+};
+__global__ __launch_bounds__(kWorkThreads) void k_work_count(WorkArgs a0, WorkArgs a1) {
+    const WorkArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
+    const uint32_t *__restrict__ gstart = A.gstart, *__restrict__ istart = A.istart;
+    uint32_t *__restrict__ counts = A.counts, *__restrict__ block_sums = A.block_sums;
+    const unsigned long long *__restrict__ part_pairs = A.part_pairs;
+    unsigned long long *__restrict__ pairs_out = A.pairs_out;
+    const uint32_t nb = A.nb, NB = A.NB, split = A.split, n_bat = A.n_bat, n_part = A.n_part, rank_lo = A.rank_lo, rank_hi = A.rank_hi, width = A.width;
     __shared__ uint32_t wsum[kWorkThreads / 64];
     __shared__ unsigned long long red[kWorkThreads / 64];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -458,11 +470,14 @@ __global__ __launch_bounds__(kWorkThreads) void k_work_count(const uint32_t *__r
 struct WorkEntry { uint32_t b0, nbv, g0, g1, c0, c1, pad0, pad1; };
 static_assert(sizeof(WorkEntry) == 32, "two 16-byte stores");
 // A thread per batch; a batch with many entries (a repeat family's bucket: hundreds) is written by its whole wave.
-__global__ __launch_bounds__(kWorkThreads) void k_work_fill(const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ istart, uint32_t nb, uint32_t NB, uint32_t split,
-                                                            uint32_t n_bat, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ block_sums,
-                                                            WorkEntry *__restrict__ list, uint32_t list_cap, unsigned long long *__restrict__ n_out,
-                                                            uint32_t *__restrict__ n_list /* the same number where the compare launch reads it: a line of its own */,
-                                                            uint32_t rank_lo, uint32_t rank_hi, uint32_t width) {
+__global__ __launch_bounds__(kWorkThreads) void k_work_fill(WorkArgs a0, WorkArgs a1) {
+    const WorkArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
+    const uint32_t *__restrict__ gstart = A.gstart, *__restrict__ istart = A.istart, *__restrict__ counts = A.counts, *__restrict__ block_sums = A.block_sums;
+    WorkEntry *__restrict__ list = A.list;
+    unsigned long long *__restrict__ n_out = A.n_out;
+    uint32_t *__restrict__ n_list = A.n_list;
+    const uint32_t nb = A.nb, NB = A.NB, split = A.split, n_bat = A.n_bat, list_cap = A.list_cap, rank_lo = A.rank_lo, rank_hi = A.rank_hi, width = A.width;
     __shared__ uint32_t scan_lds[16];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     uint32_t o = 0, n = t < n_bat ? counts[t] : 0u, s0 = 0, s1 = 0, gs = 0, ge = 0, is0 = 0, is1 = 0;
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(kWorkThreads) void k_work_fill(const uint32_t *__re
             base += before_lds[k];
         }
         o = base + wave_off + incl - n;
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = base + tot; *n_list = base + tot; }
+        if (blockIdx.x == A.grid - 1 && threadIdx.x == 0) { *n_out = base + tot; *n_list = base + tot; }
     }
     WorkSplit w{1u, 1u, 0u};
     if (n) {

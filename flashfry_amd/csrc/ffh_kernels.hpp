@@ -192,18 +192,25 @@ __global__ __launch_bounds__(256) void k_group_build(const uint32_t *__restrict_
 // ---------------------------------------------------------------------------------------------------------
 // candidate lists: every guide visits the buckets inside its Hamming ball (key ^ pattern)
 // ---------------------------------------------------------------------------------------------------------
-template <bool SUFFIX>
-__global__ void k_guide_keys(const uint64_t *__restrict__ guides, uint32_t n, Geometry geo, int width, uint2 *__restrict__ gtab,
-                             uint32_t *__restrict__ gbucket, uint32_t *__restrict__ seg_begin /* nullable */, uint32_t *__restrict__ seg_end,
-                             uint32_t *__restrict__ zero_buf, uint32_t n_zero) {
+// The kernels that build the candidate lists take the arguments of BOTH images (round 5): blockIdx.y picks the image, blocks beyond the
+// image's own grid leave at once.  The two images' lists do not depend on each other and most of these launches sit on the launch floor
+// (~4.7 us each behind its predecessor), so the pair costs what one cost: 7 launches per step where there were 13.  (Two streams, tried
+// in round 3, did not overlap on this stack.)  A single image -- a slab of a bounded scan, a one-image plan -- is launched with grid.y = 1.
+struct GuideKeysArgs {
+    const uint64_t *guides; uint32_t n; Geometry geo; int width; uint2 *gtab; uint32_t *gbucket;
+    uint32_t *seg_begin /* nullable */, *seg_end, *zero_buf; uint32_t n_zero; uint32_t suffix; uint32_t grid;
+};
+__global__ void k_guide_keys(GuideKeysArgs a0, GuideKeysArgs a1) {
+    const GuideKeysArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t d = g; d < n_zero; d += gridDim.x * blockDim.x) zero_buf[d] = 0u;  // the partition histogram k_guide_part_hist adds into
-    if (g >= n) return;
-    if (seg_begin) { seg_begin[g] = 0u; seg_end[g] = 0u; }  // the hit segment of a guide without hits (k_segments only visits the others)
-    const uint64_t pk = planar_key(guides[g], geo.c0, geo.lc);
-    const uint32_t b = SUFFIX ? suffix_bucket(pk, width) : prefix_bucket(pk, geo.lc, width);
-    gbucket[g] = b;
-    gtab[g] = make_uint2(SUFFIX ? suffix_rest_key(pk, width) : prefix_rest_key(pk, geo.lc, width), b);  // what the compare kernel gathers per candidate
+    for (uint32_t d = g; d < A.n_zero; d += A.grid * blockDim.x) A.zero_buf[d] = 0u;  // the partition histogram k_guide_part_hist adds into
+    if (g >= A.n) return;
+    if (A.seg_begin) { A.seg_begin[g] = 0u; A.seg_end[g] = 0u; }  // the hit segment of a guide without hits (k_segments only visits the others)
+    const uint64_t pk = planar_key(A.guides[g], A.geo.c0, A.geo.lc);
+    const uint32_t b = A.suffix ? suffix_bucket(pk, A.width) : prefix_bucket(pk, A.geo.lc, A.width);
+    A.gbucket[g] = b;
+    A.gtab[g] = make_uint2(A.suffix ? suffix_rest_key(pk, A.width) : prefix_rest_key(pk, A.geo.lc, A.width), b);  // what the compare kernel gathers per candidate
 }
 
 // Candidate lists in CSR form: for every bucket the ids of the guides whose Hamming ball reaches it (the guides' {rest key,
@@ -296,19 +303,21 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t x) { return x ^ ((x >> 5) 
 // device-scope atomics on 2048 counters took 47 us; one block walking all guides took 30 us; eight blocks take a few).  ghist was
 // cleared by k_guide_keys.
 constexpr int kPartHistBlocks = 8;
-__global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
-                                                          uint32_t *__restrict__ ghist, uint32_t *__restrict__ part_fill, uint32_t n_fill) {
+struct PartHistArgs { const uint32_t *gbucket; uint32_t n_guides, low_bits, n_part; uint32_t *ghist, *part_fill; uint32_t n_fill, grid; };
+__global__ __launch_bounds__(1024) void k_guide_part_hist(PartHistArgs a0, PartHistArgs a1) {
+    const PartHistArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
     __shared__ uint32_t h[1 << kMaxPartBits];
     if (blockIdx.x == 0)
-        for (uint32_t d = threadIdx.x; d < n_fill; d += blockDim.x) part_fill[d] = 0;  // the counters of the passes that follow (saves a fill launch)
-    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) h[d] = 0;
+        for (uint32_t d = threadIdx.x; d < A.n_fill; d += blockDim.x) A.part_fill[d] = 0;  // the counters of the passes that follow (saves a fill launch)
+    for (uint32_t d = threadIdx.x; d < A.n_part; d += blockDim.x) h[d] = 0;
     __syncthreads();
-    const uint32_t per = (n_guides + gridDim.x - 1) / gridDim.x, g_end = min(n_guides, (blockIdx.x + 1) * per);
-    for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) atomicAdd(&h[lds_slot(gbucket[g] >> low_bits)], 1u);
+    const uint32_t per = (A.n_guides + A.grid - 1) / A.grid, g_end = min(A.n_guides, (blockIdx.x + 1) * per);
+    for (uint32_t g = blockIdx.x * per + threadIdx.x; g < g_end; g += blockDim.x) atomicAdd(&h[lds_slot(A.gbucket[g] >> A.low_bits)], 1u);
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < n_part; d += blockDim.x) {
+    for (uint32_t d = threadIdx.x; d < A.n_part; d += blockDim.x) {
         const uint32_t c = h[lds_slot(d)];
-        if (c) atomicAdd(&ghist[d], c);
+        if (c) atomicAdd(&A.ghist[d], c);
     }
 }
 // (the partitions' entry counts: a wave per partition, the lanes striding over the patterns -- a thread per partition left 4096 threads
@@ -330,10 +339,17 @@ __global__ __launch_bounds__(1024) void k_guide_part_hist(const uint32_t *__rest
 // (... and the partitions' entry counts, which need the same histogram and nothing else, are computed by the blocks from `sort_blocks` on
 // of the same launch -- k_part_sizes' work, a wave per partition: one launch less per image and step.  patterns == nullptr: not wanted,
 // a slab of a bounded scan counts its entries with k_item_bin_direct<true, true>.)
-__global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restrict__ gbucket, uint32_t n_guides, uint32_t low_bits, uint32_t n_part,
-                                                        const uint32_t *__restrict__ part_hist, uint32_t *__restrict__ gp_start /* [n_part + 1] out */,
-                                                        uint32_t *__restrict__ gp_fill /* zeroed */, uint32_t *__restrict__ by_part, uint32_t sort_blocks,
-                                                        const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, uint32_t *__restrict__ part_count) {
+struct ByPartArgs {
+    const uint32_t *gbucket; uint32_t n_guides, low_bits, n_part; const uint32_t *part_hist; uint32_t *gp_start /* [n_part + 1] out */, *gp_fill /* zeroed */, *by_part;
+    uint32_t sort_blocks; const uint32_t *patterns; ItemGeom ig; uint32_t part_bits; uint32_t *part_count; uint32_t grid;
+};
+__global__ __launch_bounds__(1024) void k_guide_by_part(ByPartArgs a0, ByPartArgs a1) {
+    const ByPartArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
+    const uint32_t *__restrict__ gbucket = A.gbucket, *__restrict__ part_hist = A.part_hist, *__restrict__ patterns = A.patterns;
+    uint32_t *__restrict__ gp_start = A.gp_start, *__restrict__ gp_fill = A.gp_fill, *__restrict__ by_part = A.by_part, *__restrict__ part_count = A.part_count;
+    const uint32_t n_guides = A.n_guides, low_bits = A.low_bits, n_part = A.n_part, sort_blocks = A.sort_blocks, part_bits = A.part_bits;
+    const ItemGeom &ig = A.ig;
     __shared__ uint32_t cnt[1 << kMaxPartBits];
     __shared__ uint32_t start[1 << kMaxPartBits];
     __shared__ uint32_t scan_lds[16];
@@ -377,11 +393,20 @@ __global__ __launch_bounds__(1024) void k_guide_by_part(const uint32_t *__restri
 
 // One block per partition.  COUNT: only the number of entries the partition keeps (the exact sizes a slab of a bounded scan needs:
 // its rank filter looks at the low bucket bits, so the XOR convolution of k_part_sizes does not apply) -> part_count[d].
+struct ItemBinArgs {
+    const uint32_t *gp_start, *by_part, *patterns; ItemGeom ig; uint32_t part_bits; const uint32_t *part_size /* entries per partition (placing) */;
+    uint32_t *part_count, *istart, *item_gid; const uint32_t *bstart; unsigned long long *part_pairs; uint32_t grid;
+};
 template <bool COUNT, bool SLAB>
-__global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint32_t *__restrict__ gp_start, const uint32_t *__restrict__ by_part,
-                                                                  const uint32_t *__restrict__ patterns, ItemGeom ig, uint32_t part_bits, const uint32_t *__restrict__ part_size /* entries per partition (placing) */,
-                                                                  uint32_t *__restrict__ part_count, uint32_t *__restrict__ istart, uint32_t *__restrict__ item_gid,
-                                                                  const uint32_t *__restrict__ bstart, unsigned long long *__restrict__ part_pairs) {
+__global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(ItemBinArgs a0, ItemBinArgs a1) {
+    const ItemBinArgs &A = blockIdx.y ? a1 : a0;
+    if (blockIdx.x >= A.grid) return;
+    const uint32_t *__restrict__ gp_start = A.gp_start, *__restrict__ by_part = A.by_part, *__restrict__ patterns = A.patterns, *__restrict__ part_size = A.part_size,
+                   *__restrict__ bstart = A.bstart;
+    uint32_t *__restrict__ part_count = A.part_count, *__restrict__ istart = A.istart, *__restrict__ item_gid = A.item_gid;
+    unsigned long long *__restrict__ part_pairs = A.part_pairs;
+    const ItemGeom &ig = A.ig;
+    const uint32_t part_bits = A.part_bits;
     __shared__ uint32_t cnt[1 << kMaxLowBits];
     __shared__ uint32_t stage[COUNT ? 1 : kBinStage];
     __shared__ uint32_t scan_lds[16];
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(kPartThreads, 8) void k_item_bin_direct(const uint3
                 off += c;
                 if (c) pairs += (unsigned long long)c * (bstart[bucket + 1] - bstart[bucket]);
             }
-        if (d == gridDim.x - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
+        if (d == A.grid - 1 && threadIdx.x == kPartThreads - 1) istart[(uint64_t)ig.n_part << ig.low_bits] = gbase + n;
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) pairs += __shfl_xor(pairs, sft, 64);
         if ((threadIdx.x & 63) == 0) pair_lds[threadIdx.x >> 6] = pairs;
