@@ -103,13 +103,14 @@ struct CompareArgs {
                               // image on all guides with the retired ones made unreachable); null = guide_base + position
 };
 
-// before every compare launch: clears the per-launch statistics words (one launch in place of a memset)
-__global__ void k_compare_setup(unsigned long long *__restrict__ cursor, int first_batch) {
-    if (first_batch && threadIdx.x < 4) cursor[threadIdx.x] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
-    if (threadIdx.x >= 4 && threadIdx.x < 8) cursor[threadIdx.x] = 0ull;  // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
-    if (threadIdx.x == 13) cursor[13] = 0ull;                              // the list of heavy segments of the hit ordering (k_segsort)
-    if (threadIdx.x < 2 * kQueues) cursor[kQueue + threadIdx.x * kQueueStride] = 0ull;  // the two images' work queues (k_compare)
-    if (FFH_TRIP_STATS && threadIdx.x >= 16 && threadIdx.x < 30) cursor[threadIdx.x] = 0ull;
+// before every compare launch: clears the per-launch statistics words -- 64 threads of the first k_guide_keys launch of the candidate lists
+// (the first launch of the sequence the compare launch ends; a launch of its own, k_compare_setup, until round 5)
+__device__ void compare_setup_words(unsigned long long *__restrict__ cursor, int first_batch, uint32_t t) {
+    if (first_batch && t < 4) cursor[t] = 0ull;  // [0] hit cursor, [1] real hits: once per scan, they run across guide batches
+    if (t >= 4 && t < 8) cursor[t] = 0ull;       // [4], [5] executed pairs, [6], [7] work entries of the two images: per launch
+    if (t == 13) cursor[13] = 0ull;              // the list of heavy segments of the hit ordering (k_segsort)
+    if (t < 2 * kQueues) cursor[kQueue + t * kQueueStride] = 0ull;  // the two images' work queues (k_compare)
+    if (FFH_TRIP_STATS && t >= 16 && t < 30) cursor[t] = 0ull;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

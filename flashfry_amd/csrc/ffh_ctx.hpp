@@ -249,6 +249,7 @@ struct ffh_ctx {
     uint64_t pattern_gen = 0;   // moves on with every pattern upload: a captured launch sequence reads patterns[side] and must not outlive its content
     DevBuf<uint32_t> icount, ifill, item_gid, scan_tmp32;
     // candidate binning and work list of one image
+    int pending_setup = 0;   // scan_impl -> prepare_side: 1 = the next k_guide_keys launch clears the compare launch's per-launch counters, 2 = and the per-scan ones
     struct SideScratch { DevBuf<uint32_t> part_fill, part_hist, gp_start, by_part; } side_scr[2];
     DevBuf<uint32_t> tmp_keys, tmp_tidx;                    // build_image's temporaries
     DevBuf<uint32_t> wl_count[2];                             // work entries per batch of buckets + per block of 1024 batches

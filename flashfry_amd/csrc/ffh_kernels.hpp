@@ -199,10 +199,13 @@ __global__ __launch_bounds__(256) void k_group_build(const uint32_t *__restrict_
 struct GuideKeysArgs {
     const uint64_t *guides; uint32_t n; Geometry geo; int width; uint2 *gtab; uint32_t *gbucket;
     uint32_t *seg_begin /* nullable */, *seg_end, *zero_buf; uint32_t n_zero; uint32_t suffix; uint32_t grid;
+    unsigned long long *setup_cursor /* nullable */; int first_batch;   // the compare launch's counters, cleared here (compare_setup_words: a launch of its own until round 5)
 };
+__device__ void compare_setup_words(unsigned long long *__restrict__ cursor, int first_batch, uint32_t t);   // (ffh_compare.hpp)
 __global__ void k_guide_keys(GuideKeysArgs a0, GuideKeysArgs a1) {
     const GuideKeysArgs &A = blockIdx.y ? a1 : a0;
     if (blockIdx.x >= A.grid) return;
+    if (A.setup_cursor && blockIdx.x == 0 && threadIdx.x < 64) compare_setup_words(A.setup_cursor, A.first_batch, threadIdx.x);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t d = g; d < A.n_zero; d += A.grid * blockDim.x) A.zero_buf[d] = 0u;  // the partition histogram k_guide_part_hist adds into
     if (g >= A.n) return;

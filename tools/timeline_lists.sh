@@ -27,7 +27,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 for r in csv.DictReader(open(sys.argv[2])):
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY %s" % r.get("Direction", "?")))
 ev.sort()
-setups = [i for i, e in enumerate(ev) if "k_compare_setup" in e[2]]
+setups = [i for i, e in enumerate(ev) if "k_guide_keys" in e[2]]
 first = setups[-2] if len(setups) >= 2 and ev[setups[-1]][0] - ev[setups[-2]][0] < 4000000 else setups[-1]   # (a pipelined call scans twice)
 seq = ev[first - 1:]
 t0 = seq[0][0]
