@@ -261,6 +261,7 @@ struct ffh_ctx {
 
     // finalize scratch
     DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals, hit_pre;
+    DevBuf<unsigned long long> totals64;   // a bounded scan: the positions the slab just scanned adds to every guide (k_slab_totals)
     // bounded scan (ffh_scan_bounded): the suffix images of the slabs, the slabs' first targets, their prefix-bucket ranges, the
     // guides' running totals and the packed set of guides still active
     std::vector<std::unique_ptr<Image>> slab_img;

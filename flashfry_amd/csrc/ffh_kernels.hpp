@@ -935,14 +935,54 @@ __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint
 // the COMPLEMENT of its bucket id there: against every bucket of its candidate list (its own id with <= r1 bases changed) the key
 // then differs in >= width - r1 bases, more than any maxMismatch a two-image plan runs with, so the compare kernel gives its jobs
 // no steps -- without a test of its own in the hot loop.
-__global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, uint32_t n, uint32_t limit, uint32_t *__restrict__ flag,
-                               uint2 *__restrict__ gtab0, uint32_t key_mask) {
+// (slab_total64: the slab's totals as k_slab_totals leaves them, unsaturated sums; else slab_total, k_cutoff's)
+__global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, const unsigned long long *__restrict__ slab_total64, uint32_t n,
+                               uint32_t limit, uint32_t *__restrict__ flag, uint2 *__restrict__ gtab0, uint32_t key_mask) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    const uint32_t before = total[g], t = min(limit, before + min(limit, slab_total[g]));
+    const uint32_t slab = slab_total64 ? (uint32_t)min(slab_total64[g], (unsigned long long)limit) : min(limit, slab_total[g]);
+    const uint32_t before = total[g], t = min(limit, before + slab);
     total[g] = t;
     flag[g] = t < limit ? 1u : 0u;
     if (gtab0 && before < limit && t >= limit) gtab0[g].y = ~gtab0[g].y & key_mask;
+}
+// The positions a slab's raw hits add to every guide, from the records AS THE COMPARE LAUNCH LEFT THEM (any order, chunk padding
+// included): the hit's target long is gathered for its count (the same random line k_hit_targets fetched) and the counts are added up per
+// guide in an LDS table of the block -- a repeat family's hits arrive together, work entry by work entry, so most of a block's 16 384
+// records share a few hundred guides -- and the table's sums leave with one 64-bit atomic per guide and block.  A record that finds no
+// slot within eight probes adds its count directly.  (Until round 5 the slab's records were ordered by guide first -- two passes of the
+// device-wide sort, k_segments, k_hit_targets, k_cutoff: 0.85 of the repeat-structured workload's 8.05 ms, profiles/r05/ab_log.txt 14.)
+constexpr uint32_t kTotThreads = 1024, kTotRows = 16, kTotSlots = 8192, kTotProbes = 8;
+__global__ __launch_bounds__(kTotThreads) void k_slab_totals(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t n_guides, const uint64_t *__restrict__ targets,
+                                                             unsigned long long *__restrict__ totals /* zeroed */) {
+    __shared__ uint32_t tag[kTotSlots], sum[kTotSlots];
+    for (uint32_t i = threadIdx.x; i < kTotSlots; i += kTotThreads) { tag[i] = 0xFFFFFFFFu; sum[i] = 0u; }
+    const uint64_t base = (uint64_t)blockIdx.x * (kTotThreads * kTotRows), mask = (1ull << tbits) - 1ull;
+    uint64_t key[kTotRows];
+    uint32_t cnt[kTotRows];
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * kTotThreads + threadIdx.x;
+        key[r] = i < n ? hits[i] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) cnt[r] = (key[r] >> tbits) < n_guides ? (uint32_t)(targets[key[r] & mask] >> 48) : 0u;   // (16 gathers in flight per lane)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint32_t g = (uint32_t)(key[r] >> tbits);
+        if (g >= n_guides) continue;
+        uint32_t s = (g * 2654435761u) >> 19;   // 13 bits
+        bool placed = false;
+        for (uint32_t k = 0; k < kTotProbes && !placed; ++k, s = (s + 1u) & (kTotSlots - 1u)) {
+            const uint32_t old = atomicCAS(&tag[s], 0xFFFFFFFFu, g);
+            if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&sum[s], cnt[r]); placed = true; }
+        }
+        if (!placed) atomicAdd(&totals[g], (unsigned long long)cnt[r]);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kTotSlots; i += kTotThreads)
+        if (tag[i] != 0xFFFFFFFFu && sum[i]) atomicAdd(&totals[tag[i]], (unsigned long long)sum[i]);
 }
 // the guides still active, packed: their longs and their numbers in the caller's guide array
 __global__ void k_bound_compact(const uint64_t *__restrict__ guides, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,
