@@ -261,6 +261,10 @@ struct ffh_ctx {
 
     // finalize scratch
     DevBuf<uint32_t> n_ret, ot_count, full, prior, out_cnt, out_tidx, totals, hit_pre;
+    DevBuf<unsigned long long> sub_hist, kept_ctr;   // ... and what stops a guide inside a slab (ffh_kernels.hpp: k_slab_subhist)
+    DevBuf<uint16_t> hit_cnt;
+    DevBuf<uint32_t> g_allow;
+    DevBuf<uint8_t> g_thr;
     DevBuf<unsigned long long> totals64;   // a bounded scan: the positions the slab just scanned adds to every guide (k_slab_totals)
     // bounded scan (ffh_scan_bounded): the suffix images of the slabs, the slabs' first targets, their prefix-bucket ranges, the
     // guides' running totals and the packed set of guides still active

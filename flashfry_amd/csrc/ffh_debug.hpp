@@ -36,6 +36,7 @@ struct Switches {
                                      // link under the second part's scan.  OFF: measured slower on this stack (profiles/r05/ab_log.txt 7); kept for tests / A-B
     bool load_pipeline = false;      // FFH_LOAD_PIPELINE=1: ffh_db_open moves even a small body through the threaded page-locked pipeline (A/B)
     bool slab_totals_sorted = false; // FFH_SLAB_TOTALS=sort: a bounded scan adds up a slab's positions per guide from the records ordered by guide (round 4) instead of k_slab_totals
+    bool slab_filter = true;         // FFH_SLAB_FILTER=0: a bounded scan keeps every record of the slab in which a guide reaches the limit (round 4)
     bool one_sweep = false;          // FFH_ONESWEEP=1: the device-wide LSD sort with decoupled look-back instead of a histogram launch + scan per pass.
                                      // OFF: slower on this part (3.27 against 2.45 ms for 4.7e7 keys, profiles/r05/ab_log.txt 8); kept for tests / A-B
     int nb_force[2] = {0, 0};        // FFH_NB_PREFIX / FFH_NB_SUFFIX: buckets per work entry of the image (A/B; 0: side_plan's rule)
@@ -62,6 +63,7 @@ struct Switches {
         s.work_queue = (int)num("FFH_WORK_QUEUE", -1);
         s.pipeline = num("FFH_PIPELINE", 0) == 1;
         s.one_sweep = num("FFH_ONESWEEP", 0) == 1;
+        s.slab_filter = num("FFH_SLAB_FILTER", 1) != 0;
         s.slab_totals_sorted = is("FFH_SLAB_TOTALS", "sort");
         s.load_pipeline = num("FFH_LOAD_PIPELINE", 0) == 1;
         s.nb_force[0] = (int)num("FFH_NB_PREFIX", 0); s.nb_force[1] = (int)num("FFH_NB_SUFFIX", 0);

@@ -936,12 +936,14 @@ __global__ void k_gather_positions(const uint32_t *__restrict__ tidx, const uint
 // then differs in >= width - r1 bases, more than any maxMismatch a two-image plan runs with, so the compare kernel gives its jobs
 // no steps -- without a test of its own in the hot loop.
 // (slab_total64: the slab's totals as k_slab_totals leaves them, unsaturated sums; else slab_total, k_cutoff's)
+// allow (nullable): for a guide that reaches the limit IN this slab, the positions it still had to go when the slab began (0: any other)
 __global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__restrict__ slab_total, const unsigned long long *__restrict__ slab_total64, uint32_t n,
-                               uint32_t limit, uint32_t *__restrict__ flag, uint2 *__restrict__ gtab0, uint32_t key_mask) {
+                               uint32_t limit, uint32_t *__restrict__ flag, uint2 *__restrict__ gtab0, uint32_t key_mask, uint32_t *__restrict__ allow) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
     const uint32_t slab = slab_total64 ? (uint32_t)min(slab_total64[g], (unsigned long long)limit) : min(limit, slab_total[g]);
     const uint32_t before = total[g], t = min(limit, before + slab);
+    if (allow) allow[g] = before < limit && t >= limit ? limit - before : 0u;
     total[g] = t;
     flag[g] = t < limit ? 1u : 0u;
     if (gtab0 && before < limit && t >= limit) gtab0[g].y = ~gtab0[g].y & key_mask;
@@ -952,12 +954,35 @@ __global__ void k_bound_update(uint32_t *__restrict__ total, const uint32_t *__r
 // records share a few hundred guides -- and the table's sums leave with one 64-bit atomic per guide and block.  A record that finds no
 // slot within eight probes adds its count directly.  (Until round 5 the slab's records were ordered by guide first -- two passes of the
 // device-wide sort, k_segments, k_hit_targets, k_cutoff: 0.85 of the repeat-structured workload's 8.05 ms, profiles/r05/ab_log.txt 14.)
-constexpr uint32_t kTotThreads = 1024, kTotRows = 16, kTotSlots = 8192, kTotProbes = 8;
+constexpr uint32_t kTotThreads = 1024, kTotRows = 16, kTotSlots = 8192, kTotProbes = 8, kTotChunk = kTotThreads * kTotRows;
+// sums per 32-bit key in the LDS of a block (one chunk of 16 384 records), flushed to 64-bit global counters
+// (Tried on the repeat-structured workload, none of it measurable: blocks that keep their table over a run of chunks; the equal keys of
+// neighbouring lanes added up before the table is touched.  The sums of the second pass below are dominated by keys that occur once
+// or twice per chunk -- a guide's hits from the suffix image arrive in no order of the index -- i.e. by the flush's ~7e6 global atomics.)
+template <uint32_t SLOTS>
+struct LdsSums {
+    uint32_t tag[SLOTS], sum[SLOTS];
+    __device__ __forceinline__ void clear() {
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += blockDim.x) { tag[i] = 0xFFFFFFFFu; sum[i] = 0u; }
+    }
+    __device__ __forceinline__ void add(uint32_t key, uint32_t v, unsigned long long *__restrict__ global) {
+        uint32_t s = (key * 2654435761u) >> (32 - __builtin_ctz(SLOTS));
+        for (uint32_t k = 0; k < kTotProbes; ++k, s = (s + 1u) & (SLOTS - 1u)) {
+            const uint32_t old = atomicCAS(&tag[s], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { atomicAdd(&sum[s], v); return; }
+        }
+        atomicAdd(&global[key], (unsigned long long)v);   // (no slot within kTotProbes)
+    }
+    __device__ __forceinline__ void flush(unsigned long long *__restrict__ global) {
+        for (uint32_t i = threadIdx.x; i < SLOTS; i += blockDim.x)
+            if (tag[i] != 0xFFFFFFFFu && sum[i]) atomicAdd(&global[tag[i]], (unsigned long long)sum[i]);
+    }
+};
 __global__ __launch_bounds__(kTotThreads) void k_slab_totals(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t n_guides, const uint64_t *__restrict__ targets,
-                                                             unsigned long long *__restrict__ totals /* zeroed */) {
-    __shared__ uint32_t tag[kTotSlots], sum[kTotSlots];
-    for (uint32_t i = threadIdx.x; i < kTotSlots; i += kTotThreads) { tag[i] = 0xFFFFFFFFu; sum[i] = 0u; }
-    const uint64_t base = (uint64_t)blockIdx.x * (kTotThreads * kTotRows), mask = (1ull << tbits) - 1ull;
+                                                             unsigned long long *__restrict__ totals /* zeroed */, uint16_t *__restrict__ cnt_out /* nullable; per record: its position count */) {
+    __shared__ LdsSums<kTotSlots> T;
+    T.clear();
+    const uint64_t base = (uint64_t)blockIdx.x * kTotChunk, mask = (1ull << tbits) - 1ull;
     uint64_t key[kTotRows];
     uint32_t cnt[kTotRows];
 #pragma unroll
@@ -967,22 +992,121 @@ __global__ __launch_bounds__(kTotThreads) void k_slab_totals(const uint64_t *__r
     }
 #pragma unroll
     for (int r = 0; r < (int)kTotRows; ++r) cnt[r] = (key[r] >> tbits) < n_guides ? (uint32_t)(targets[key[r] & mask] >> 48) : 0u;   // (16 gathers in flight per lane)
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * kTotThreads + threadIdx.x;
+        if (cnt_out && i < n) cnt_out[i] = (uint16_t)cnt[r];
+    }
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r)
+        if ((key[r] >> tbits) < n_guides) T.add((uint32_t)(key[r] >> tbits), cnt[r], totals);
+    __syncthreads();
+    T.flush(totals);
+}
+// ---- stopping a guide INSIDE the slab in which it reaches the limit ----
+// The ordered cut-off keeps a guide's hits, in database order, while the positions before a hit are below the limit; what lies behind
+// the hit that reaches it is never delivered.  Retiring guides slab by slab leaves all of the guide's hits of that last slab in the
+// records -- 2.7 raw hits per kept one on the repeat-structured workload, all of them ordered by the five-pass sort.  So, for the guides
+// that reach the limit in the slab just scanned (k_bound_update: allow[g] > 0), the slab's index span is cut into kSubRanges equal parts,
+// the guide's positions are added up per part (k_slab_subhist: the counts k_slab_totals left per record, an LDS table per block like
+// there), thr[g] = the part in which the running total reaches what the guide had left (k_slab_threshold), and the slab's records are
+// copied out without the chunk padding and without the records of parts behind thr[g] (k_slab_filter, k_slab_keep).  Every dropped
+// record has, before it in database order, records of its guide that reach the limit: the delivered lists do not change.
+constexpr uint32_t kSubRanges = 32, kSubSlots = 8192;
+// the part of the slab an index lies in: any non-decreasing function of the index does, as long as every kernel uses the same one --
+// a multiplication by scale = 2^32 kSubRanges / (slab length), worked out on the host (sub_scale), instead of a 64-bit division per record
+__device__ __forceinline__ uint32_t sub_range(uint32_t idx, uint32_t lo, uint32_t scale) {
+    return min(kSubRanges - 1u, (uint32_t)(((uint64_t)(idx - lo) * scale) >> 32));
+}
+inline uint32_t sub_scale(uint64_t slab_len) { return (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)kSubRanges << 32) / std::max<uint64_t>(slab_len, 1)); }
+__global__ __launch_bounds__(kTotThreads) void k_slab_subhist(const uint64_t *__restrict__ hits, const uint16_t *__restrict__ cnt, uint64_t n, int tbits, uint32_t n_guides,
+                                                              const uint32_t *__restrict__ allow, uint32_t slab_lo, uint32_t slab_scale,
+                                                              unsigned long long *__restrict__ hist /* [n_guides][kSubRanges], zeroed */) {
+    __shared__ LdsSums<kSubSlots> T;
+    T.clear();
+    const uint64_t base = (uint64_t)blockIdx.x * kTotChunk, mask = (1ull << tbits) - 1ull;
+    uint64_t key[kTotRows];
+    uint32_t a[kTotRows], v[kTotRows];
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * kTotThreads + threadIdx.x;
+        key[r] = i < n ? hits[i] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) a[r] = (key[r] >> tbits) < n_guides ? allow[key[r] >> tbits] : 0u;
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) v[r] = a[r] ? (uint32_t)cnt[base + (uint64_t)r * kTotThreads + threadIdx.x] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r)
+        if (a[r]) T.add((uint32_t)(key[r] >> tbits) * kSubRanges + sub_range((uint32_t)(key[r] & mask), slab_lo, slab_scale), v[r], hist);
+    __syncthreads();
+    T.flush(hist);
+}
+// thr[g] = the last part of the slab whose records guide g keeps (kSubRanges: all of them)
+__global__ void k_slab_threshold(const unsigned long long *__restrict__ hist, const uint32_t *__restrict__ allow, uint32_t n_guides, uint8_t *__restrict__ thr) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_guides) return;
+    const uint32_t a = allow[g];
+    uint32_t t = kSubRanges;
+    if (a) {
+        unsigned long long run = 0;
+        for (uint32_t s = 0; s < kSubRanges; ++s) {
+            run += hist[(uint64_t)g * kSubRanges + s];
+            if (run >= a) { t = s; break; }
+        }
+    }
+    thr[g] = (uint8_t)t;
+}
+// the slab's records [0, n) -> out[0 .. *kept): hits only, and of a guide with a threshold only those of the parts up to it; any order
+__global__ __launch_bounds__(kTotThreads) void k_slab_filter(const uint64_t *__restrict__ hits, uint64_t n, int tbits, uint32_t n_guides, const uint8_t *__restrict__ thr,
+                                                             uint32_t slab_lo, uint32_t slab_scale, uint64_t *__restrict__ out, unsigned long long *__restrict__ kept /* zeroed */) {
+    const uint64_t base = (uint64_t)blockIdx.x * (kTotThreads * kTotRows), mask = (1ull << tbits) - 1ull;
+    uint64_t key[kTotRows];
+    uint64_t keep_mask[kTotRows];   // (wave-uniform: the row's ballot)
+    uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint64_t i = base + (uint64_t)r * kTotThreads + threadIdx.x;
+        key[r] = i < n ? hits[i] : ~0ull;
+    }
 #pragma unroll
     for (int r = 0; r < (int)kTotRows; ++r) {
         const uint32_t g = (uint32_t)(key[r] >> tbits);
-        if (g >= n_guides) continue;
-        uint32_t s = (g * 2654435761u) >> 19;   // 13 bits
-        bool placed = false;
-        for (uint32_t k = 0; k < kTotProbes && !placed; ++k, s = (s + 1u) & (kTotSlots - 1u)) {
-            const uint32_t old = atomicCAS(&tag[s], 0xFFFFFFFFu, g);
-            if (old == 0xFFFFFFFFu || old == g) { atomicAdd(&sum[s], cnt[r]); placed = true; }
-        }
-        if (!placed) atomicAdd(&totals[g], (unsigned long long)cnt[r]);
+        bool keep = g < n_guides;
+        if (keep) { const uint32_t t = thr[g]; keep = t >= kSubRanges || sub_range((uint32_t)(key[r] & mask), slab_lo, slab_scale) <= t; }
+        keep_mask[r] = __ballot(keep);
+        tot += (uint32_t)__popcll(keep_mask[r]);
+    }
+    // ONE reservation per block (same-address atomics complete at ~90 per microsecond: one per wave, 46 000 of them, took 0.5 ms of the
+    // repeat-structured step); every row's kept records leave side by side
+    __shared__ uint32_t wave_tot[kTotThreads / 64];
+    __shared__ unsigned long long block_at;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_tot[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t all = 0;
+        for (uint32_t w = 0; w < kTotThreads / 64; ++w) all += wave_tot[w];
+        block_at = all ? atomicAdd(kept, (unsigned long long)all) : 0ull;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kTotSlots; i += kTotThreads)
-        if (tag[i] != 0xFFFFFFFFu && sum[i]) atomicAdd(&totals[tag[i]], (unsigned long long)sum[i]);
+    unsigned long long at = block_at;
+    for (uint32_t w = 0; w < wave; ++w) at += wave_tot[w];
+#pragma unroll
+    for (int r = 0; r < (int)kTotRows; ++r) {
+        const uint64_t m = keep_mask[r];
+        if ((m >> lane) & 1ull) out[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key[r];
+        at += (uint32_t)__popcll(m);
+    }
+}
+// ... back to where the slab's records began, and the hit cursor / hit count set to what is left (the next compare launch appends there)
+__global__ void k_slab_keep(const uint64_t *__restrict__ from, uint64_t *__restrict__ to, const unsigned long long *__restrict__ kept, unsigned long long *__restrict__ counters,
+                            unsigned long long cursor_at_start, unsigned long long hits_at_start) {
+    const unsigned long long n = *kept;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) to[i] = from[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[0] = cursor_at_start + n; counters[1] = hits_at_start + n; }
 }
 // the guides still active, packed: their longs and their numbers in the caller's guide array
 __global__ void k_bound_compact(const uint64_t *__restrict__ guides, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,

@@ -183,6 +183,35 @@ def test_repeat_structured_genome_with_guides_sampled_from_it(capi, oracle, max_
     assert int((t >> np.uint64(48)).max()) >= 100                        # multi-copy targets (low-complexity tracts) are in play
 
 
+@pytest.mark.parametrize("max_mm,max_ot", [(4, 2000), (4, 60), (5, 500)])
+def test_bounded_scan_stops_a_guide_inside_the_slab_where_it_reaches_the_limit(capi, oracle, monkeypatch, max_mm, max_ot):
+    """round 5: after every slab of a bounded scan the records of a guide that reaches maximumOffTargets IN that slab are dropped behind
+    the part (1/32 of the slab's index span) in which it reaches it (k_slab_totals, k_slab_subhist, k_slab_threshold, k_slab_filter,
+    k_slab_keep).  Every dropped record has records of its guide that reach the limit before it in database order, so the delivered
+    lists, positions, scores and aggregates are those of the oracle and of the scan with the filter off (FFH_SLAB_FILTER=0), while
+    fewer records reach the ordering."""
+    db = synth.make_repeat_database(2_500_000, seed=synth.DB_SEED + 31)
+    g = synth.as_u64(synth.make_guides_from_database(db, 1500, seed=synth.GUIDE_SEED + 31))
+    t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
+    odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
+    res, raw = {}, {}
+    for filt in ("1", "0"):
+        monkeypatch.setenv("FFH_SLAB_FILTER", filt)
+        with capi.Context(3) as ctx:
+            ctx.load_soa(t, p)
+            ctx.set_bounding(1)
+            res[filt] = ctx.discover(g, max_mm, max_ot, jost=True)
+            tm = ctx.timings()
+            assert tm.bounded_slabs >= 3
+            raw[filt] = tm.n_raw_hits
+            again = ctx.discover(g, max_mm, max_ot, summaries_only=True)          # (the buffers of the first call reused)
+            assert again.summaries.tobytes() == res[filt].summaries.tobytes()
+    assert_same_hits(res["1"], odb.discover(g, max_mm, max_ot))
+    assert res["1"].summaries.tobytes() == res["0"].summaries.tobytes()
+    assert np.array_equal(res["1"].hit_targets, res["0"].hit_targets) and np.array_equal(res["1"].positions, res["0"].positions)
+    assert res["1"].n_hits <= raw["1"] < raw["0"], (res["1"].n_hits, raw)
+
+
 def test_bounded_scan_with_guide_batches_and_other_enzymes(capi, oracle, monkeypatch):
     """the slabs of a bounded scan run on the packed set of guides still active, batch by batch: any batch size gives the oracle's
     result; a 19-mer 3'-PAM pack is bounded as well, a 5'-PAM pack (Cpf1) silently stays unbounded"""
