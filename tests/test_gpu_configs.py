@@ -204,7 +204,7 @@ def test_bounded_scan_stops_a_guide_inside_the_slab_where_it_reaches_the_limit(c
             tm = ctx.timings()
             assert tm.bounded_slabs >= 3
             raw[filt] = tm.n_raw_hits
-            again = ctx.discover(g, max_mm, max_ot, summaries_only=True)          # (the buffers of the first call reused)
+            again = ctx.discover(g, max_mm, max_ot, summaries_only=True, jost=True)   # (the buffers of the first call reused)
             assert again.summaries.tobytes() == res[filt].summaries.tobytes()
     assert_same_hits(res["1"], odb.discover(g, max_mm, max_ot))
     assert res["1"].summaries.tobytes() == res["0"].summaries.tobytes()
