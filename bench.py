@@ -511,7 +511,7 @@ def main():
                 err = repr(e)
             if all_ranks_ok(comm is not None):
                 try:
-                    reduced = np.zeros(G, dtype=capi.SUMMARY_DTYPE)
+                    reduced = capi.host_summaries(G)   # page-locked (ffh_host_alloc): the reduced aggregates are copied straight into it
                     comm.discover_device(guides_dev.data_ptr(), int(guides_dev.shape[0]), args.max_mismatch, args.max_offtargets, want_summaries=(rank == 0), out=reduced)
                 except Exception as e:   # noqa: BLE001 -- whatever it is, the run goes on with the other exchange
                     err = repr(e)

@@ -283,6 +283,13 @@ int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, f
     return FFH_OK;
 }
 
+void *ffh_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void ffh_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 const char *ffh_comm_last_error(const ffh_comm *cm) { return cm ? cm->err.c_str() : g_create_error.c_str(); }
 int ffh_comm_world(const ffh_comm *cm) { return cm ? cm->world : 0; }
 int ffh_comm_first_shard(const ffh_comm *cm) { return cm ? cm->first : 0; }

@@ -258,6 +258,25 @@ int ffo_db_add_contig(ffo_db *db, const char *name) { /* BitPosition.addReferenc
     return db->n_contigs; /* 1-based id */
 }
 int ffo_db_n_bins(const ffo_db *db) { return db->n_bins; }
+/* test aid (tools/stress_parity.py): a checksum over every bin's longs, and the first bin whose own checksum differs from `expect[bin]`
+ * (expect == NULL: none).  The randomised sweep asks for it before and after every case: a database whose memory changes under the
+ * checker is a heap write by somebody else, a database that stays the same while two discover calls disagree is the checker's own. */
+static uint64_t bin_sum(const ffo_bin *b) {
+    uint64_t h = 1469598103934665603ULL ^ (uint64_t)b->n_longs;
+    for (size_t i = 0; i < b->n_longs; i++) { h ^= (uint64_t)b->longs[i]; h *= 1099511628211ULL; }
+    return h;
+}
+uint64_t ffo_db_checksum(const ffo_db *db, uint64_t *per_bin /* NULL or [n_bins]: filled */, const uint64_t *expect, int *first_changed) {
+    uint64_t all = 0;
+    if (first_changed) *first_changed = -1;
+    for (int i = 0; i < db->n_bins; i++) {
+        uint64_t h = db->bins[i].longs ? bin_sum(&db->bins[i]) : 0;
+        if (per_bin) per_bin[i] = h;
+        if (expect && first_changed && *first_changed < 0 && expect[i] != h) *first_changed = i;
+        all = (all ^ h) * 1099511628211ULL;
+    }
+    return all;
+}
 int ffo_db_bin_width(const ffo_db *db) { return db->bin_width; }
 int ffo_db_enzyme(const ffo_db *db) { return db->pack->index; }
 int ffo_db_n_contigs(const ffo_db *db) { return db->n_contigs; }

@@ -71,6 +71,8 @@ class Oracle:
         L.ffo_db_set_bin.argtypes = [C.c_void_p, C.c_uint32, i64p, C.c_size_t, C.c_int]
         L.ffo_db_add_contig.argtypes = [C.c_void_p, C.c_char_p]
         L.ffo_db_n_bins.argtypes = [C.c_void_p]
+        L.ffo_db_checksum.restype = C.c_uint64
+        L.ffo_db_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.ffo_db_bin_width.argtypes = [C.c_void_p]
         L.ffo_db_enzyme.argtypes = [C.c_void_p]
         L.ffo_db_n_contigs.argtypes = [C.c_void_p]
@@ -243,6 +245,17 @@ class OracleDB:
     @property
     def n_bins(self):
         return self.o.lib.ffo_db_n_bins(self.h)
+
+    def checksums(self):
+        """(checksum of the whole database, per-bin checksums): tools/stress_parity.py watches the checker's memory with it"""
+        per = np.zeros(self.n_bins, dtype=np.uint64)
+        return int(self.o.lib.ffo_db_checksum(self.h, per.ctypes.data_as(C.POINTER(C.c_uint64)), None, None)), per
+
+    def first_changed_bin(self, per):
+        """index of the first bin whose checksum is not per[bin] any more, or -1"""
+        ch = C.c_int(-1)
+        self.o.lib.ffo_db_checksum(self.h, None, per.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(ch))
+        return ch.value
 
     @property
     def bin_width(self):

@@ -96,6 +96,26 @@ def test_one_rank_rccl_communicator(capi, case):
     assert np.array_equal(lists.hit_targets, full.hit_targets)
 
 
+def test_reduced_summaries_into_page_locked_and_into_pageable_memory(capi, case):
+    """summaries_out of ffh_discover_sharded may be any host memory: a page-locked buffer from ffh_host_alloc (capi.host_summaries, what
+    Comm.discover takes by default: copied straight into) or a pageable numpy array (staged by the runtime) -- the same bytes"""
+    odb, targets, positions, guides, sizes = case
+    pinned = capi.host_summaries(len(guides))
+    assert pinned.dtype == capi.SUMMARY_DTYPE and len(pinned) == len(guides) and not pinned.tobytes().strip(b"\0")
+    pageable = np.zeros(len(guides), dtype=capi.SUMMARY_DTYPE)
+    with capi.Context(3) as ctx:
+        ctx.load_soa(targets, positions)
+        with capi.Comm.local([ctx]) as comm:
+            g = np.ascontiguousarray(guides).view(np.uint64)
+            comm._discover(g.ctypes.data, len(g), 4, 37, True, True, pinned)
+            comm._discover(g.ctypes.data, len(g), 4, 37, True, True, pageable)
+        full = ctx.discover(guides, 4, 37, jost=True)
+    assert pinned.tobytes() == pageable.tobytes() == full.summaries.tobytes()
+    view = pinned[3:5]
+    del pinned                                                   # (the block lives as long as any view of it)
+    assert view.tobytes() == full.summaries[3:5].tobytes()
+
+
 def test_exchange_alone_after_the_callers_own_scans(capi, case):
     odb, targets, positions, guides, sizes = case
     ctxs = []

@@ -44,7 +44,7 @@ def main():
             tms.append(ctx.timings().as_dict())
         if args.comm:
             with capi.Comm.rank(ctx, 0, 1, capi.comm_unique_id()) as comm:
-                out = np.zeros(args.guides, dtype=capi.SUMMARY_DTYPE)
+                out = capi.host_summaries(args.guides)
                 for _ in range(3):
                     comm.discover_device(gd.data_ptr(), args.guides, 4, 2000, out=out)
                 tc, ex = [], []

@@ -75,6 +75,20 @@ while time.time() - t0 < budget:
         odb, t, p, g = dense_case(oracle, n_random=par[0], n_guides=par[1], n_dense=par[2], variants=par[3], seed=seed)
     # the inputs as the checker and the library were given them: they must not change under either
     t_sum, p_sum, g_copy = int(t.sum(dtype=np.uint64)), int(p.sum(dtype=np.uint64)), g.copy()
+    # ... and neither must the checker's own database (in-process checker only: round 5 saw ONE case in 15 810 where the in-process
+    # database answered with every hit of a bin twice and differently when asked again, while a fresh database and the isolated checker
+    # agreed with the library -- a write into the checker's heap, or the checker reading memory it never wrote?  The checksums say which)
+    watch = mode == "inproc" and hasattr(odb, "checksums")
+    db_sum, db_per = odb.checksums() if watch else (0, None)
+
+    def db_state(when):
+        if not watch:
+            return True
+        now, _ = odb.checksums()
+        if now == db_sum:
+            return True
+        print("ORACLE DATABASE CHANGED %s: case %d, first changed bin %d of %d" % (when, n + 1, odb.first_changed_bin(db_per), odb.n_bins), flush=True)
+        return False
     with capi.Context(enz) as ctx:
         ctx.load_soa(t, p)
         ctx.set_bounding(bounding)
@@ -89,8 +103,10 @@ while time.time() - t0 < budget:
             assert np.array_equal(lean.positions, gpu.positions) and np.array_equal(lean.pos_offsets, gpu.pos_offsets)
         if sc:
             assert lean.hit_cfd.tobytes() == gpu.hit_cfd.tobytes()
+    assert db_state("while the library ran"), "the checker's in-process database changed while the library ran"
     ora = odb.discover(g, max_mm, max_ot)
-    if not np.array_equal(gpu.guide_offsets, ora.guide_offsets) or not np.array_equal(gpu.hit_targets, ora.hit_targets):
+    db_same = db_state("during the checker's own discover")
+    if not db_same or not np.array_equal(gpu.guide_offsets, ora.guide_offsets) or not np.array_equal(gpu.hit_targets, ora.hit_targets):
         # what differs, and whether the same context gives the same answer when asked again (a stale buffer or a race would not)
         bad = [k for k in range(len(g)) if not np.array_equal(gpu.hits(k), ora.hits(k))]
         print("MISMATCH case %d (%s oracle): %d guides differ: %s" % (n + 1, mode, len(bad), bad[:10]), flush=True)
@@ -102,8 +118,10 @@ while time.time() - t0 < budget:
             print("  guide %d (%016x): gpu list %s, oracle list %s (database indices), overflow gpu %d oracle %d, gpu ot_count %d" % (
                 k, int(g[k]), [idx[v] for v in a][:8], [idx.get(v, -1) for v in b][:8], int(gpu.summaries["overflow"][k]), int(ora.full[k]), int(gpu.summaries["ot_count"][k])), flush=True)
         ora_again = odb.discover(g, max_mm, max_ot)
-        print("  the same oracle database asked again: %s" % (
-            "same answer" if np.array_equal(ora_again.guide_offsets, ora.guide_offsets) and np.array_equal(ora_again.hit_targets, ora.hit_targets) else "ANOTHER answer"), flush=True)
+        print("  the same oracle database asked again: %s%s; its memory is %s" % (
+            "same answer" if np.array_equal(ora_again.guide_offsets, ora.guide_offsets) and np.array_equal(ora_again.hit_targets, ora.hit_targets) else "ANOTHER answer",
+            " (the library's)" if np.array_equal(ora_again.guide_offsets, gpu.guide_offsets) and np.array_equal(ora_again.hit_targets, gpu.hit_targets) else "",
+            "as it was built" if db_state("by the time of the second question") else "NOT as it was built"), flush=True)
         for tag, orc in (("a fresh in-process oracle database", oracle_lib.load()), ("a fresh isolated oracle", __import__("oracle_proc").RemoteOracle())):
             o2 = orc.db_from_sorted(enz, t, p, contigs=["c1"]).discover(g, max_mm, max_ot)
             print("  %s: %s" % (tag, "agrees with the library" if np.array_equal(o2.guide_offsets, gpu.guide_offsets) and np.array_equal(o2.hit_targets, gpu.hit_targets) else
@@ -118,6 +136,7 @@ while time.time() - t0 < budget:
                                                                                         "equal to" if np.array_equal(r2.hit_targets, gpu.hit_targets) else "NOT equal to")), flush=True)
         print("  pool errors so far: %d" % L.ffh_debug_pool_errors(), flush=True)
     assert_same_hits(gpu, ora)
+    assert db_same, "the checker's in-process database changed"
     if mode == "isolated":
         oracle.prefetch(enz, g, ora)
     assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
