@@ -285,7 +285,7 @@ int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, f
 
 void *ffh_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (portable: whichever device the caller's contexts sit on)
     return p;
 }
 void ffh_host_free(void *p) { if (p) (void)hipHostFree(p); }
