@@ -335,3 +335,18 @@ def test_jost_and_santos_known_answers(oracle, ka):
     s, _ = oracle.score_guide(1, oracle.encode("TTTA" + "A" * 20), [])
     assert not s.jost_valid                                       # Cpf1: JostAndSantosCRISPRi.scala:53-58
     assert np.isnan(oracle.lib.ffo_jost_calc_score(oracle.pack(2), b"ACGT", b"ACGT"))  # the length asserts :94-95
+
+
+def test_database_checksums_watch_the_checkers_memory(oracle):
+    """tools/stress_parity.py checksums the in-process checker's database around every step (round 5: one sweep case in which that
+    database answered twice differently while fresh checkers agreed with the library): the sums do not move under discover, and a bin
+    that is replaced is the one reported"""
+    from tests.helpers import make_case
+    odb, t, p, g = make_case(oracle, 20000, 12, enzyme=3, seed=11)
+    total, per = odb.checksums()
+    odb.discover(g, 4, 50)
+    odb.discover(g, 3, 2000, force_linear=True)
+    assert odb.checksums()[0] == total and odb.first_changed_bin(per) == -1
+    b = int(np.flatnonzero(per)[3])
+    odb.set_bin(b, np.array([1, int(t[0])] + [7] * int(t[0] >> np.uint64(48)), dtype=np.int64), 1)
+    assert odb.checksums()[0] != total and odb.first_changed_bin(per) == b
