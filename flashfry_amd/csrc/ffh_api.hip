@@ -21,6 +21,7 @@
 
 #include "../../include/flashfry_hip.h"
 #include "ffh_debug.hpp"
+#include "ffh_streams.hpp"
 #include "ffh_dbfile.hpp"
 #include "ffh_ingest.hpp"
 #include "ffh_inflate.hpp"

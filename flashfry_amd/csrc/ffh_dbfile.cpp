@@ -1,6 +1,7 @@
 // ffh_dbfile.cpp -- see ffh_dbfile.hpp.  Host side of the ingest: header parse, BGZF member directory, parallel
 // inflate into page-locked buffers with the copies to the device overlapped (zlib + std::thread + HIP streams).
 #include "ffh_dbfile.hpp"
+#include "ffh_streams.hpp"
 
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
@@ -259,13 +260,13 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
     std::vector<Lane> lanes(nthreads);
     uint8_t *arena = nullptr;
     auto release = [&]() {
-        for (auto &l : lanes) { for (auto e : l.ev) if (e) (void)hipEventDestroy(e); if (l.st) (void)hipStreamDestroy(l.st); }
+        for (auto &l : lanes) { for (auto e : l.ev) if (e) (void)hipEventDestroy(e); ffh::stream_pool().release(device, l.st); }
         if (arena) (void)hipHostFree(arena);
     };
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipHostMalloc((void **)&arena, (size_t)nthreads * 2 * kChunkBytes, hipHostMallocDefault);
     for (unsigned t = 0; t < nthreads && he == hipSuccess; ++t) {
-        he = hipStreamCreateWithFlags(&lanes[t].st, hipStreamNonBlocking);
+        he = ffh::stream_pool().acquire(device, &lanes[t].st);   // (pooled, never destroyed: ffh_streams.hpp)
         for (int i = 0; i < 2 && he == hipSuccess; ++i) {
             lanes[t].buf[i] = arena + ((size_t)t * 2 + (size_t)i) * kChunkBytes;
             he = hipEventCreateWithFlags(&lanes[t].ev[i], hipEventDisableTiming);

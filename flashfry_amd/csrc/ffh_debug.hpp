@@ -3,7 +3,7 @@
 // otherwise picks from the workload); two are resource knobs a deployment may set (FFH_PINNED_LIMIT_MB, FFH_COMPARE_GRID).
 // The file-I/O side keeps its own, read where a file is opened or written: FFH_LOAD_THREADS, FFH_VERBOSE (ffh_dbfile.cpp),
 // FFH_DEFLATE_LEVEL (ffh_dbwrite.cpp); the communicator reads FFH_RCCL_LIBRARY once per process and FFH_COMM when it is created
-// (ffh_comm.hpp).
+// (ffh_comm.hpp); the stream pool reads FFH_STREAM_DESTROY once per process (ffh_streams.hpp).
 #pragma once
 #include <stdint.h>
 

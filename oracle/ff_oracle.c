@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "ff_oracle_internal.h"
 
@@ -237,14 +239,37 @@ ffo_db *ffo_db_new(int enzyme_index, int bin_width) {
 }
 void ffo_db_free(ffo_db *db) {
     if (!db) return;
-    for (int i = 0; i < db->n_bins; i++) free(db->bins[i].longs);
+    if (db->sealed) munmap(db->sealed, db->sealed_bytes);
+    else {
+        for (int i = 0; i < db->n_bins; i++) free(db->bins[i].longs);
+        free(db->bins);
+    }
     for (int i = 0; i < db->n_contigs; i++) free(db->contigs[i]);
     free(db->contigs);
-    free(db->bins);
     free(db);
 }
+int ffo_db_seal(ffo_db *db) {
+    if (db->sealed) return 0;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    size_t table = ((sizeof(ffo_bin) * (size_t)db->n_bins + 63) / 64) * 64, longs = 0;
+    for (int i = 0; i < db->n_bins; i++) longs += db->bins[i].n_longs;
+    size_t bytes = ((table + longs * sizeof(int64_t) + page - 1) / page) * page;
+    char *m = (char *)mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) { ffo_set_error("ffo_db_seal: mmap of %zu bytes failed", bytes); return -1; }
+    ffo_bin *nb = (ffo_bin *)m;
+    int64_t *w = (int64_t *)(m + table);
+    for (int i = 0; i < db->n_bins; i++) {
+        nb[i] = db->bins[i];
+        if (db->bins[i].longs) { memcpy(w, db->bins[i].longs, db->bins[i].n_longs * sizeof(int64_t)); nb[i].longs = w; w += db->bins[i].n_longs; free(db->bins[i].longs); }
+    }
+    free(db->bins);
+    db->bins = nb;
+    db->sealed = m; db->sealed_bytes = bytes;
+    if (mprotect(m, bytes, PROT_READ)) { ffo_set_error("ffo_db_seal: mprotect failed"); return -2; }
+    return 0;
+}
 int ffo_db_set_bin(ffo_db *db, uint32_t bi, const int64_t *longs, size_t n, int n_targets) {
-    if ((int)bi >= db->n_bins) return -1;
+    if ((int)bi >= db->n_bins || db->sealed) return -1;
     free(db->bins[bi].longs);
     db->bins[bi].longs = (int64_t *)malloc(n * sizeof(int64_t));
     memcpy(db->bins[bi].longs, longs, n * sizeof(int64_t));
@@ -298,6 +323,7 @@ uint32_t ffo_target_bin(const ffo_pack *p, int bin_width, uint64_t target) {
 int ffo_db_build_from_sorted(ffo_db *db, const uint64_t *targets, const uint64_t *positions, size_t n,
                              int max_linear) { /* reference/binary/DatabaseWriter.scala:76-97 */
     const ffo_pack *p = db->pack;
+    if (db->sealed) { ffo_set_error("the database is sealed"); return -1; }
     /* group by bin, preserving input order inside each bin (BlockReader.fetchBin keeps sorted order) */
     size_t *bin_n = (size_t *)calloc((size_t)db->n_bins + 1, sizeof(size_t));
     size_t *pos_off = (size_t *)malloc((n + 1) * sizeof(size_t));

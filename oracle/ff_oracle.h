@@ -92,6 +92,10 @@ void    ffo_db_free(ffo_db *db);
 int     ffo_db_set_bin(ffo_db *db, uint32_t bin_index, const int64_t *longs, size_t n_longs, int n_targets);
 int     ffo_db_add_contig(ffo_db *db, const char *name);
 int     ffo_db_n_bins(const ffo_db *db);
+/* test aid (tools/stress_parity.py --seal): move every bin's longs and the bin table into ONE mapping and make it read-only, so that a
+ * stray CPU store into the checker's database faults where it happens instead of changing an answer; 0 on success.  The database
+ * cannot be modified afterwards (ffo_db_set_bin fails). */
+int     ffo_db_seal(ffo_db *db);
 uint64_t ffo_db_checksum(const ffo_db *db, uint64_t *per_bin, const uint64_t *expect, int *first_changed);   /* test aid: see ff_oracle.c */
 int     ffo_db_bin_width(const ffo_db *db);
 int     ffo_db_enzyme(const ffo_db *db);

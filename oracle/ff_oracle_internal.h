@@ -17,6 +17,8 @@ struct ffo_db {
     ffo_bin *bins;
     char **contigs; /* id = index + 1, bitcoding/BitPosition.scala:38-49 */
     int n_contigs;
+    void *sealed;        /* ffo_db_seal: every bin's longs AND the bin table live in this one read-only mapping */
+    size_t sealed_bytes;
 };
 
 typedef struct ffo_hit { /* crispr/CRISPRHit.scala:39-43 */

@@ -73,6 +73,7 @@ class Oracle:
         L.ffo_db_n_bins.argtypes = [C.c_void_p]
         L.ffo_db_checksum.restype = C.c_uint64
         L.ffo_db_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.ffo_db_seal.argtypes = [C.c_void_p]
         L.ffo_db_bin_width.argtypes = [C.c_void_p]
         L.ffo_db_enzyme.argtypes = [C.c_void_p]
         L.ffo_db_n_contigs.argtypes = [C.c_void_p]
@@ -251,6 +252,11 @@ class OracleDB:
         per = np.zeros(self.n_bins, dtype=np.uint64)
         return int(self.o.lib.ffo_db_checksum(self.h, per.ctypes.data_as(C.POINTER(C.c_uint64)), None, None)), per
 
+    def seal(self):
+        """all bins into one read-only mapping: a stray CPU store into the checker's database faults (tools/stress_parity.py --seal)"""
+        if self.o.lib.ffo_db_seal(self.h):
+            raise RuntimeError(self.o.error())
+
     def first_changed_bin(self, per):
         """index of the first bin whose checksum is not per[bin] any more, or -1"""
         ch = C.c_int(-1)
@@ -311,5 +317,6 @@ class OracleDB:
 def load():
     global _LIB
     if _LIB is None:
-        _LIB = Oracle(C.CDLL(build()))
+        # FFO_LIBRARY: another build of the checker (tools/r06_stress_sanitized.sh: the oracle under AddressSanitizer next to the library's host side)
+        _LIB = Oracle(C.CDLL(os.environ.get("FFO_LIBRARY") or build()))
     return _LIB

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from flashfry_amd import capi
 import oracle_lib
 from helpers import make_case, make_enzyme_case, assert_same_hits, assert_same_scores
-from test_gpu_parity import dense_case
+import stress_cases
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 mode = "inproc"
@@ -25,6 +25,7 @@ if "--oracle" in sys.argv:
     mode = sys.argv[sys.argv.index("--oracle") + 1]
     args.remove(mode)
 quiet = "--quiet" in sys.argv
+seal = "--seal" in sys.argv
 assert mode in ("inproc", "isolated")
 if mode == "isolated":
     import oracle_proc
@@ -32,47 +33,31 @@ if mode == "isolated":
 else:
     oracle = oracle_lib.load()
 L = capi.load_library()
+# tools/heapwatch.c preloaded (LD_PRELOAD): every freed chunk of the process is parked, poisoned and verified -- after every case here
+import ctypes
+try:
+    _hw = ctypes.CDLL(None)
+    _hw.heapwatch_check_all.restype = ctypes.c_ulonglong
+    heapwatch = _hw.heapwatch_check_all
+except AttributeError:
+    heapwatch = None
+hw_seen = 0
 budget = float(args[0]) if len(args) > 0 else 120.0
 rng = np.random.default_rng(int(args[1]) if len(args) > 1 else 12345)
 t0, n = time.time(), 0
 start = int(args[2]) if len(args) > 2 else 1      # replay: skip the cases before this one (same random draws, nothing built)
 by_kind = {}
 while time.time() - t0 < budget:
-    seed = int(rng.integers(0, 1 << 30))
-    kind = int(rng.integers(0, 4))
-    enz = 3
-    max_mm = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 6]))
-    max_ot = int(rng.choice([5, 40, 60, 300, 2000]))
-    if kind == 0:
-        par = (int(rng.integers(100, 400000)), int(rng.integers(1, 600)))
-    elif kind == 2:   # repeat-structured genome, guides sampled from it (families, multi-copy targets, many OVERFLOW guides)
-        par = (int(rng.integers(70000, 900000)), float(rng.uniform(0.1, 0.6)), int(rng.integers(20, 400)))
-        max_mm = min(max_mm, 5)
-    elif kind == 3:   # any of the six packs (Cpf1's 5' PAM and bin order, NAG, the 19-mers with their 7 .. 12-base rest keys)
-        enz = int(rng.integers(1, 7))
-        par = (int(rng.integers(500, 300000)), int(rng.integers(1, 400)))
-    else:
-        ng = int(rng.integers(10, 500))
-        par = (int(rng.integers(1000, 120000)), ng, int(rng.integers(1, min(60, ng))), int(rng.integers(10, 200)))
-    bounding = int(rng.choice([-1, 0, 1, 1]))     # ffh_scan_bounded engages for databases of >= 65536 targets
-    pos, sc = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    c = stress_cases.draw(rng)   # (the draws, in their order: tools/stress_cases.py -- tools/oracle_case_dump.py names the same cases)
+    seed, kind, enz, max_mm, max_ot, par, bounding, pos, sc = (c[k] for k in ("seed", "kind", "enz", "max_mm", "max_ot", "par", "bounding", "pos", "sc"))
     if n + 1 < start:
         n += 1
         continue
     if not quiet:
         print("case %d seed %d kind %d enzyme %d mm %d max_ot %d par %s bounding %d" % (n + 1, seed, kind, enz, max_mm, max_ot, par, bounding), flush=True)
-    if kind == 0:
-        odb, t, p, g = make_case(oracle, par[0], par[1], enzyme=3, seed=seed)
-    elif kind == 2:
-        from flashfry_amd import synth
-        db = synth.make_repeat_database(par[0], seed=seed, repeat_fraction=par[1])
-        g = synth.as_u64(synth.make_guides_from_database(db, par[2], seed=seed + 1))
-        t, p = synth.as_u64(db["targets"]), synth.as_u64(db["positions"])
-        odb = oracle.db_from_sorted(3, t, p, contigs=synth.CONTIGS_24)
-    elif kind == 3:
-        odb, t, p, g = make_enzyme_case(oracle, enz, par[0], par[1], seed=seed)
-    else:
-        odb, t, p, g = dense_case(oracle, n_random=par[0], n_guides=par[1], n_dense=par[2], variants=par[3], seed=seed)
+    odb, t, p, g = stress_cases.build(oracle, c)
+    if seal and hasattr(odb, "seal"):
+        odb.seal()   # the checker's database in ONE read-only mapping: a stray CPU store into it faults on the spot (heapwatch prints the backtrace)
     # the inputs as the checker and the library were given them: they must not change under either
     t_sum, p_sum, g_copy = int(t.sum(dtype=np.uint64)), int(p.sum(dtype=np.uint64)), g.copy()
     # ... and neither must the checker's own database (in-process checker only: round 5 saw ONE case in 15 810 where the in-process
@@ -142,6 +127,11 @@ while time.time() - t0 < budget:
     assert_same_scores(oracle, enz, g, gpu, ora, jost=True)
     assert int(t.sum(dtype=np.uint64)) == t_sum and int(p.sum(dtype=np.uint64)) == p_sum and np.array_equal(g, g_copy), "an input array changed during the case"
     assert L.ffh_debug_pool_errors() == 0, "the page-locked pool checks fired"
+    if heapwatch is not None:
+        e = int(heapwatch())
+        if e != hw_seen:
+            print("HEAPWATCH: %d damaged chunk(s) found by the end of case %d (kind %d enzyme %d mm %d max_ot %d par %s bounding %d)" % (e - hw_seen, n + 1, kind, enz, max_mm, max_ot, par, bounding), flush=True)
+            hw_seen = e
     n += 1
     by_kind[(kind, enz)] = by_kind.get((kind, enz), 0) + 1
     if not quiet or n % 500 == 0:
@@ -150,5 +140,5 @@ while time.time() - t0 < budget:
 del gpu, only, lean
 import gc
 gc.collect()
-print("all %d cases agree (%s oracle, pool errors %d, %.0f s)" % (n - (start - 1), mode, L.ffh_debug_pool_errors(), time.time() - t0))
+print("all %d cases agree (%s oracle, pool errors %d, heapwatch %s, %.0f s)" % (n - (start - 1), mode, L.ffh_debug_pool_errors(), "off" if heapwatch is None else "%d damaged chunks" % hw_seen, time.time() - t0))
 print("cases by (kind, enzyme):", dict(sorted(by_kind.items())))
