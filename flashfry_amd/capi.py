@@ -24,7 +24,7 @@ SYMBOLS = [
     "ffh_version", "ffh_device_count", "ffh_debug_pool_errors", "ffh_create", "ffh_destroy", "ffh_last_error", "ffh_db_load_blocks",
     "ffh_db_load_soa", "ffh_db_open", "ffh_db_open_header", "ffh_db_bin_bytes", "ffh_db_info_get", "ffh_db_load_stats", "ffh_host_threads", "ffh_db_write", "ffh_indexer_create", "ffh_indexer_destroy", "ffh_indexer_last_error",
     "ffh_indexer_add_contig", "ffh_indexer_finish", "ffh_db_contig", "ffh_set_plan", "ffh_scan",
-    "ffh_scan_bounded", "ffh_set_bounding", "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
+    "ffh_scan_bounded", "ffh_set_bounding", "ffh_get_bounding", "ffh_discover_bulge", "ffh_bulge_result_n_guides", "ffh_bulge_result_n_hits", "ffh_bulge_result_guide_offsets",
     "ffh_bulge_result_hit_targets", "ffh_bulge_result_hit_mismatches", "ffh_bulge_result_hit_bulge_type", "ffh_bulge_result_hit_bulge_position",
     "ffh_bulge_result_free", "ffh_exchange_pack", "ffh_exchange_mask", "ffh_exchange_unpack", "ffh_use_stream", "ffh_finalize_shard", "ffh_exchange_prior", "ffh_finalize_shard_fixup", "ffh_shard_totals", "ffh_shard_totals_device", "ffh_summaries_to_device", "ffh_finalize", "ffh_discover", "ffh_score_lists", "ffh_result_n_guides", "ffh_result_n_hits",
     "ffh_result_n_positions", "ffh_result_scores_valid", "ffh_result_summaries", "ffh_result_guide_offsets",
@@ -145,6 +145,7 @@ def load_library(build=True):
     L.ffh_scan.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int]
     L.ffh_scan_bounded.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int]
     L.ffh_set_bounding.argtypes = [C.c_void_p, C.c_int]
+    L.ffh_get_bounding.argtypes = [C.c_void_p]
     L.ffh_shard_totals.argtypes = [C.c_void_p, u32p, C.c_uint32]
     L.ffh_discover_bulge.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_bulge_result_n_guides.restype = C.c_uint32

@@ -405,11 +405,16 @@ static int discover_sharded_split(ffh_comm *cm, const uint64_t *guides, uint32_t
     if (n_guides < 2) return FFH_E_STATE;
     split = true;
     const uint32_t h = n_guides / 2;
-    const double scan0 = cm->scan_ms, ex0 = cm->exchange_ms;
+    // (the timings of the attempt that had to be split and of the parts, added up once: every call below overwrites cm->scan_ms / exchange_ms)
+    double scan = cm->scan_ms, ex = cm->exchange_ms;
     rc = discover_sharded_split(cm, guides, h, max_mismatch, max_offtargets, flags, summaries_out, split);
-    const double scan1 = cm->scan_ms, ex1 = cm->exchange_ms;
-    if (!rc) rc = discover_sharded_split(cm, guides + h, n_guides - h, max_mismatch, max_offtargets, flags, summaries_out ? summaries_out + h : nullptr, split);
-    cm->scan_ms += scan0 + scan1; cm->exchange_ms += ex0 + ex1;
+    scan += cm->scan_ms; ex += cm->exchange_ms;
+    if (!rc) {
+        rc = discover_sharded_split(cm, guides + h, n_guides - h, max_mismatch, max_offtargets, flags, summaries_out ? summaries_out + h : nullptr, split);
+        scan += cm->scan_ms; ex += cm->exchange_ms;
+    }
+    cm->scan_ms = scan; cm->exchange_ms = ex;
+    if (!rc) cm->err.clear();   // (the "more than 2^32 raw hits" text of the attempt that was split is not this call's outcome)
     return rc;
 }
 int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {

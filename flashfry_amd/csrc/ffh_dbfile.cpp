@@ -196,15 +196,16 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
     size_t m0 = 0, m1 = ms.size();
     member_range(bf, need_lo, need_hi, m0, m1);
     if (m1 <= m0) return "";
+    const auto count_compressed = [&]() { for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26; };   // (every path below accounts once)
     const size_t file_lo = ms[m0].coff;  // raw_copy: the members' file bytes go to d_raw + (file offset - file_lo), still compressed
-    if (!raw_copy && need_hi - need_lo <= kSmallBodyBytes && !force_pipeline) {
+    if (!raw_copy && need_hi - need_lo <= kSmallBodyBytes && !force_pipeline) {   // (compared here: the INFLATED size of what is needed)
         // a small body (a chr22-scale database: 57 MB -> 100 MB): the host threads inflate into one pageable buffer and ONE copy takes it
         // over.  The page-locked arena, the 16 streams and their teardown cost 0.15 s there, the device's inflate kernel 0.1 s whatever
         // the size (a member is decoded by one lane); this is 0.03 s (profiles/r05/ab_log.txt 12).
         const uint64_t u0 = ms[m0].uoff, u1 = ms[m1 - 1].uoff + ms[m1 - 1].isize;
         std::unique_ptr<uint8_t[]> buf(new (std::nothrow) uint8_t[(size_t)(u1 - u0)]);   // (not value-initialised: first touched by the thread that fills it)
         if (!buf) return "out of host memory inflating the database body";
-        for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26;
+        count_compressed();
         const unsigned nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>(usable_cpus(), (m1 - m0 + 15) / 16));
         stats.threads = nthreads;
         std::atomic<size_t> next(m0);
@@ -238,11 +239,12 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
         return he == hipSuccess ? "" : std::string("copy to the device failed: ") + hipGetErrorString(he);
     }
     if (raw_copy) {
-        // a small body goes over in ONE copy straight from the file mapping: the page-locked arena, the 16
-        // (the pipeline below pays from a few hundred MB on: 3.2 GB of hg38 in 0.1 s)
+        // the device inflates: a small body goes over in ONE copy straight from the file mapping (compared here: the COMPRESSED span
+        // [file_lo, file_hi) against kSmallBodyBytes) -- the page-locked arena, the 16 streams and the loader threads of the pipeline below
+        // pay from a few hundred MB on (3.2 GB of hg38 in 0.1 s)
         const size_t file_hi = ms[m1 - 1].cdata_off + ms[m1 - 1].cdata_len + 8;
-                if (file_hi - file_lo <= kSmallBodyBytes && !force_pipeline) {
-            for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26;
+        if (file_hi - file_lo <= kSmallBodyBytes && !force_pipeline) {
+            count_compressed();
             stats.threads = 1;
             hipError_t he = hipSetDevice(device);
             if (he == hipSuccess) he = hipMemcpy(d_raw, bf.data + file_lo, file_hi - file_lo, hipMemcpyHostToDevice);
@@ -254,7 +256,7 @@ std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t nee
     const size_t nchunks = (m1 - m0 + kGroup - 1) / kGroup;
     const unsigned nthreads = (unsigned)std::max<size_t>(1, std::min<size_t>(usable_cpus(), nchunks));
     stats.threads = nthreads;
-    for (size_t i = m0; i < m1; ++i) stats.compressed_bytes += ms[i].cdata_len + 26;
+    count_compressed();
 
     struct Lane { hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; uint8_t *buf[2] = {nullptr, nullptr}; };
     std::vector<Lane> lanes(nthreads);

@@ -64,7 +64,7 @@ void member_range(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, size_t
 // raw_copy == false: inflates [need_lo, need_hi) of the uncompressed stream on the host threads straight into device memory at d_raw.
 // raw_copy == true : copies the file bytes of the overlapping members, still compressed, to d_raw (d_raw[0] = first byte of member m0);
 //                    the device inflates them (ffh_inflate.hpp).  Same pipeline either way: page-locked slices, one stream per thread.
-constexpr uint64_t kSmallBodyBytes = 256ull << 20;   // bodies up to this many (inflated) bytes: host inflate + one copy; beyond: the device inflates
+constexpr uint64_t kSmallBodyBytes = 256ull << 20;   // host inflate (FFH_INFLATE=host): bodies of up to this many INFLATED bytes are inflated by host threads and go over in one copy; device inflate: a COMPRESSED span up to this size goes over in one copy from the file mapping; beyond: the threaded page-locked pipeline
 std::string inflate_to_device(const BodyFile &bf, uint64_t need_lo, uint64_t need_hi, uint8_t *d_raw, int device, IngestStats &stats, bool raw_copy,
                               bool force_pipeline = false /* FFH_LOAD_PIPELINE=1: the threaded copy pipeline whatever the size */);
 

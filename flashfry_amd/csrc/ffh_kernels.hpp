@@ -963,6 +963,7 @@ constexpr uint32_t kTotThreads = 1024, kTotRows = 16, kTotSlots = 8192, kTotProb
 // or twice per chunk -- a guide's hits from the suffix image arrive in no order of the index -- i.e. by the flush's ~7e6 global atomics.)
 template <uint32_t SLOTS>
 struct LdsSums {
+    static_assert(2 * sizeof(uint32_t) * SLOTS <= kLdsPerBlock, "LdsSums: the table must fit gfx950's LDS");
     uint32_t tag[SLOTS], sum[SLOTS];
     __device__ __forceinline__ void clear() {
         for (uint32_t i = threadIdx.x; i < SLOTS; i += blockDim.x) { tag[i] = 0xFFFFFFFFu; sum[i] = 0u; }

@@ -11,6 +11,14 @@ namespace ffh {
 
 constexpr int kWave = 64;
 
+// The library is written for gfx950 only: wave64, and 160 KB of LDS per workgroup -- k_msd_scatter stages 128 KB, k_binsort ~66 KB,
+// k_slab_totals / k_slab_subhist 64 KB (static_asserts at the kernels).  Another --offload-arch (gfx942 and gfx90a stop at 64 KB) must
+// not get as far as a launch failure:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "flashfry_hip is gfx950-only: build with --offload-arch=gfx950"
+#endif
+constexpr size_t kLdsPerBlock = 160 * 1024;
+
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // number of set bits of `mask` below this lane
@@ -662,6 +670,7 @@ __global__ __launch_bounds__(kMsdThreads) void k_msd_scatter(const uint64_t *__r
     __shared__ uint64_t staged[kMsdChunk];                  // the chunk, digit-ordered (128 KB at 16 rows)
     __shared__ uint32_t cnt[1 << kMsdMaxBits], dig_start[1 << kMsdMaxBits], dig_goff[1 << kMsdMaxBits];
     __shared__ uint32_t scan_lds[16];
+    static_assert(sizeof staged + 3 * sizeof cnt + sizeof scan_lds <= kLdsPerBlock, "k_msd_scatter: the staged chunk must fit gfx950's 160 KB of LDS");
     const uint32_t t = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * kMsdChunk;
     const uint32_t here = (uint32_t)min((uint64_t)kMsdChunk, n - base);
@@ -765,6 +774,9 @@ __global__ __launch_bounds__(kMsdThreads) void k_binsort(uint64_t *__restrict__ 
     __shared__ uint32_t cnt[(1 << kBinMaxSubBits) + 2], start[(1 << kBinMaxSubBits) + 2];
     __shared__ uint32_t scan_lds[16];
     __shared__ uint32_t big[COOP ? kBinCap / 256 + 2 : 1], n_big;   // the bin's guides with more than 256 hits: ranked by all waves together (below)
+    static_assert(sizeof idx + sizeof cnt + sizeof start + sizeof scan_lds + sizeof big + 4 <= kLdsPerBlock, "k_binsort: a bin's keys must fit gfx950's 160 KB of LDS (a smaller kBinCap elsewhere)");
+    // (the cross-chunk ranking below bisects with a strict `<`: it relies on the (guide, database index) records of a scan being unique, which the
+    // compare launch guarantees -- a pair within the prefix radius is the prefix image's to report and nobody else's, ffh_compare.hpp)
     const uint32_t t = threadIdx.x, lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), bin = blockIdx.x;
     if (COOP && t == 0) n_big = 0;
     // offs == nullptr: ONE bin = all n_total records as the compare launch left them, chunk padding included (a small scan: this launch

@@ -183,9 +183,13 @@ int ffh_scan(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mi
  * the size of the guide's repeat family.  3'-PAM enzymes only (database order must follow the compared bases); elsewhere, and
  * when bounding is switched off, it is ffh_scan.  ffh_discover scans this way when bounding is on.
  * ffh_set_bounding: 0 = never, 1 = always, -1 (default) = switch itself on for the context once a scan has collected more than
- * 2048 raw hits per guide. */
+ * 2048 raw hits per guide, or could not be finished unbounded (more than 2^32 raw hits: ffh_discover's retry).  Once on it STAYS on for
+ * the context -- the later scans of that context, ffh_scan_bounded / ffh_finalize included, are bounded -- until ffh_set_bounding(ctx, 0)
+ * or (ctx, -1) takes it back; on a sharded call every shard's context decides for itself.  ffh_get_bounding: 1 if the context's next scan
+ * will be bounded, 0 if not. */
 int ffh_scan_bounded(ffh_ctx *ctx, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets);
 int ffh_set_bounding(ffh_ctx *ctx, int mode);
+int ffh_get_bounding(const ffh_ctx *ctx);
 
 /* per guide: sum of positions over ALL hits of this shard, saturated at `clamp` (pass max_offtargets) */
 int ffh_shard_totals(ffh_ctx *ctx, uint32_t *totals /* n_guides */, uint32_t clamp);
@@ -206,7 +210,7 @@ int ffh_finalize(ffh_ctx *ctx, const uint32_t *prior_totals /* NULL = first shar
 
 /* ffh_scan_bounded + ffh_finalize in one call -- what Traverser.scan(...) binds (reference/traverser/Traverser.scala:53-60).
  * ONE scan holds fewer than 2^32 raw hits (its segment arithmetic is 32-bit).  A guide set that collects more (<= 5-6 mismatches on a
- * repeat-rich genome) is not refused: the call first bounds the scan (as if ffh_set_bounding(1)), and if that is not enough halves the
+ * repeat-rich genome) is not refused: the call first bounds the scan (the automatic rule of ffh_set_bounding: bounding then stays on for the context), and if that is not enough halves the
  * guide set as often as needed and concatenates the parts' results -- guides are independent of each other everywhere on the path, the
  * reference is slow on such a set, not wrong (reference/binary/blocks/BlockManager.scala:212-254).  ffh_discover_sharded and
  * ffh_discover_bulge do the same; the two-step ffh_scan / ffh_finalize report FFH_E_ARG ("more than 2^32 raw hits") and leave the
