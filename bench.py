@@ -112,14 +112,17 @@ VALU_CYCLES_HALF_RATE = 4.4
 
 
 def epilogue_roofline(raw_hits, ms):
-    """the second kernel of the step, priced by the 128-byte line every gathered target long costs + the 8-byte key.  None when the
-    step's epilogue was not timed on its own (the sharded step: it runs inside ffh_discover_sharded)."""
+    """the second kernel of the step.  `achieved` / `frac` by SURVEY.md section 8d's figure -- 16 B per hit (the 8-byte record + the 8-byte target
+    long it gathers); beside it what the memory system moves for that: one 128-byte line per gathered target long + the 8-byte key
+    (`line_*`).  None when the step's epilogue was not timed on its own (the sharded step: it runs inside ffh_discover_sharded)."""
     if not ms or ms <= 0 or not raw_hits:
         return None
-    gbps = 136 * raw_hits / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "ffh::k_guide_epilogue", "launch_ms": ms, "algorithmic_bytes_per_launch": 16 * raw_hits, "line_bytes_per_launch": 136 * raw_hits,
+    gbps = 16 * raw_hits / (ms * 1e-3) / 1e9
+    line = 136 * raw_hits / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ffh::k_guide_epilogue", "launch_ms": ms, "algorithmic_bytes_per_launch": 16 * raw_hits,
             "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-            "note": "achieved counts the 128-byte line every gathered target long costs + the 8-byte key; by SURVEY 8d's 16 B per hit the fraction is 16/136 of this"}
+            "line_bytes_per_launch": 136 * raw_hits, "line_achieved": line, "line_frac": line / 8000.0,
+            "note": "frac prices SURVEY 8d's 16 B per hit; line_frac the 128-byte line every randomly gathered target long costs + the 8-byte key (8.5 x as much)"}
 
 
 def pair_step_valu(rest_bases, far):
@@ -582,7 +585,19 @@ def main():
         host_ms = (time.perf_counter() - th) * 1e3 / args.steps
         if res_h.summaries.tobytes() != res.summaries.tobytes():
             raise SystemExit("bench: the step fed from a host buffer differs from the step fed from device memory")
+    # what every rank did, for the scaling curve: its shard, its own wall time per step, the compare launch, the library's scan / exchange split
+    mine = {"rank": rank, "targets": int(T), "ms_per_step": dt / args.steps * 1e3, "compare_ms": float(np.mean([t["compare_ms"] for t in tms])),
+            "prepare_ms": float(np.mean([t["prepare_ms"] for t in tms])), "sort_ms": float(np.mean([t["sort_ms"] for t in tms])),
+            "raw_hits": int(np.mean([t["n_raw_hits"] for t in tms]))}
+    if comm is not None:
+        try:
+            mine.update(comm.timings())   # (of the last step: scan_ms = the shard's scan, exchange_ms = epilogue + all-gather + fold (+ rank 0's copy-out))
+        except Exception:   # noqa: BLE001
+            pass
+    per_rank = [mine]
     if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
@@ -656,7 +671,7 @@ def main():
             "value": G * T_total * args.steps / dt,
             "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": ("strong" if strong else "weak") if world > 1 else None, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d random NGG guides vs %d unique targets %s (%d positions on this rank), <=%d mismatches, maximumOffTargets %d, spCas9-NGG; "
                                    "N > 1 is %s" % (args.workload, G, T_total if strong else T, "in ONE database split by bins over the ranks" if strong else "per GPU", P,
@@ -716,6 +731,8 @@ def main():
                      "tiles": tms[-1]["tiles_prefix"] + tms[-1]["tiles_suffix"]},
             "hits": {"raw": raw_hits, "raw_per_guide": raw_hits / max(G, 1), "kept_positions": kept_pos, "overflowed_guides": int(final["overflow"].sum())},
             "algorithmic_bytes_survey": b_survey,
+            # N > 1: every rank's own figures (rank 0's compare launch is the one `roofline` prices); no scaling efficiency is computed here
+            "per_rank": per_rank if world > 1 else None,
             "skewed": skewed,
             # BASELINE.json configs[1] / SURVEY.md section 8d: the chr22-scale step and the CLI's wall time from argv to the closed table
             "c2": c2,

@@ -20,7 +20,7 @@ def last_json(stdout):
     return json.loads(lines[-1])
 
 
-def check_contract(d, n_gpus, scaling="weak"):
+def check_contract(d, n_gpus, scaling=None):   # (N = 1: "scaling" is null -- nothing scales)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -64,6 +64,7 @@ def test_two_rank_line_on_one_gpu(scaling):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = last_json(r.stdout)
     check_contract(d, 2, scaling)
+    assert len(d["per_rank"]) == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["compare_ms"] > 0 for r in d["per_rank"])
     assert d["config"]["targets_total"] > d["config"]["targets_per_gpu"] and d["config"]["parallelism"] == "bin-shard x2"
     if scaling == "strong":  # ONE database split by bins: the ranks' shards add up to the single-GPU database (3e6 drawn, duplicates collapse)
         assert 2.9e6 < d["config"]["targets_total"] < 3.1e6
