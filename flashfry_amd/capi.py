@@ -32,7 +32,7 @@ SYMBOLS = [
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
     "ffh_comm_unique_id", "ffh_comm_create_rank", "ffh_comm_create_local", "ffh_comm_destroy", "ffh_comm_last_error", "ffh_comm_world",
     "ffh_comm_first_shard", "ffh_comm_local_shards", "ffh_comm_transport", "ffh_discover_sharded", "ffh_comm_exchange", "ffh_comm_shard_lists",
-    "ffh_comm_device_summaries", "ffh_comm_timings", "ffh_host_alloc", "ffh_host_free",
+    "ffh_comm_device_summaries", "ffh_comm_timings", "ffh_comm_set_exchange", "ffh_comm_get_exchange", "ffh_host_alloc", "ffh_host_free",
 ]
 
 
@@ -194,6 +194,8 @@ def load_library(build=True):
     L.ffh_comm_shard_lists.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.ffh_comm_device_summaries.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.ffh_comm_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ffh_comm_set_exchange.argtypes = [C.c_void_p, C.c_int]
+    L.ffh_comm_get_exchange.argtypes = [C.c_void_p]
     if hasattr(L, "ffh_host_alloc"):   # (absent from A/B builds of earlier revisions: FFH_LIBRARY)
         L.ffh_host_alloc.restype = C.c_void_p
         L.ffh_host_alloc.argtypes = [C.c_size_t]
@@ -660,6 +662,10 @@ class Comm:
         out = C.c_void_p()
         self._check(self.L.ffh_comm_shard_lists(self.h, local_shard, Context._finalize_flags(False, jost, positions, hit_scores), C.byref(out)))
         return Result(self.L, out.value, lists=True, positions=positions, hit_scores=hit_scores)
+
+    def set_exchange(self, mode):
+        """0 / "gather": one all-gather of all records; 1 / "slice": all-to-all by guide slices (ffh_comm_set_exchange)"""
+        self._check(self.L.ffh_comm_set_exchange(self.h, {"gather": 0, "slice": 1}.get(mode, mode)))
 
     def timings(self):
         a, b = C.c_double(), C.c_double()

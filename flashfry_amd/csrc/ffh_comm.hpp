@@ -33,6 +33,8 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclSend) Send = nullptr;     // (the slice exchange only: a runtime without them keeps the all-gather form)
+    decltype(&ncclRecv) Recv = nullptr;
     std::string err;
 };
 
@@ -63,6 +65,7 @@ static RcclApi *rccl_api() {   // nullptr-safe: check ->lib
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (ok) { api.Send = (decltype(api.Send))dlsym(api.lib, "ncclSend"); api.Recv = (decltype(api.Recv))dlsym(api.lib, "ncclRecv"); }
         if (!ok) { dlclose(api.lib); api.lib = nullptr; }
     });
     return &api;
@@ -123,9 +126,96 @@ __global__ void k_exchange_reduce(const GuideSummary *__restrict__ all /* [world
     red[g] = acc;
 }
 
+
+// ---- the exchange by GUIDE SLICES (round 6; selectable: ffh_comm_set_exchange / FFH_EXCHANGE=slice) ----------------------------------
+// The all-gather form hands every rank every shard's record of every guide: world x G x 88 bytes received per rank (70 MB at world 8),
+// of which a rank needs, to fold, nothing but ... everything, because every rank folds every guide.  The slice form lets rank j fold only
+// the guides of slice j = [j * sl, (j + 1) * sl), sl = ceil(G / world):
+//   (1) all-to-all: shard i sends shard j its records of slice j + its status record           G x 88 x (world - 1) / world bytes per rank
+//   (2) rank j folds its slice in shard order (the arithmetic of k_exchange_reduce) and works out, for EVERY shard, the prior of the
+//       slice's guides
+//   (3) all-to-all back: the priors (4 bytes per guide and shard) + the slice's flag word; every shard assembles its own prior[G] -- what
+//       the second round and ffh_comm_shard_lists need -- and the sum of the flag words
+//   (4) all-gather of the folded slices: every rank holds the reduced aggregates, as in the all-gather form          G x 88 bytes per rank
+// Three collectives instead of one, an eighth of the payload at world 8.  Results are bit-identical to the all-gather form: the same
+// records folded by the same code in the same order.
+__global__ void k_slice_pack(const GuideSummary *__restrict__ summ /* [G + 1], record G = status */, uint32_t G, uint32_t sl, uint32_t world,
+                             GuideSummary *__restrict__ send /* [world][sl + 1] */) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= world * (sl + 1u)) return;
+    const uint32_t j = t / (sl + 1u), k = t % (sl + 1u), g = j * sl + k;
+    GuideSummary v{};
+    if (k == sl) v = summ[G];
+    else if (g < G) v = summ[g];
+    send[t] = v;
+}
+// fold of one slice: `all` = [world][sl + 1] (per source shard: the slice's records, then the shard's status record); n_slice guides of it
+// exist.  prior_all [world][sl + 1]: row r = the prior of shard r for the slice's guides (first round only; word sl of every row is filled
+// with the slice's flag word by k_slice_flag).  flag[0] as in k_exchange_reduce.
+__global__ void k_exchange_reduce_slice(const GuideSummary *__restrict__ all, uint32_t n_slice, uint32_t sl, uint32_t world, uint32_t clamp, int adjusted,
+                                        uint32_t *__restrict__ prior_all, GuideSummary *__restrict__ red /* [sl] */, uint32_t *__restrict__ flag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0)
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t status = all[(size_t)r * (sl + 1) + sl].n_hits;
+            if (status != 0u) atomicOr(flag, status == kStatusTooManyHits ? 0x80000000u : 0xC0000000u);
+        }
+    if (k >= sl) return;
+    GuideSummary acc{};
+    acc.closest = 0xFFFFFFFFu;
+    if (k >= n_slice) {   // (padding of the last slices: a defined record, a zero prior)
+        red[k] = acc;
+        if (!adjusted) for (uint32_t r = 0; r < world; ++r) prior_all[(size_t)r * (sl + 1) + k] = 0u;
+        return;
+    }
+    uint64_t run = 0;
+    bool crossing = false, any = false;
+    for (uint32_t r = 0; r < world; ++r) {
+        const GuideSummary v = all[(size_t)r * (sl + 1) + k];
+        bool use = true;
+        if (!adjusted) {
+            const uint32_t t = min(v.ot_count, clamp), p = (uint32_t)(run < clamp ? run : clamp);
+            prior_all[(size_t)r * (sl + 1) + k] = p;
+            run += t;
+            if (p > 0u && (uint64_t)p + t >= clamp) {
+                use = false;
+                if (p >= clamp) acc.overflow = 1u;
+                else crossing = true;
+            }
+        }
+        if (!use) continue;
+        acc.n_hits += v.n_hits; acc.ot_count += v.ot_count; acc.in_genome += v.in_genome; acc.n_scored += v.n_scored;
+        for (int q = 0; q < 5; ++q) acc.hist[q] += v.hist[q];
+        acc.overflow = max(acc.overflow, v.overflow);
+        acc.cfd_max = fmax(acc.cfd_max, v.cfd_max); acc.jost_max = fmax(acc.jost_max, v.jost_max);
+        if (v.closest < acc.closest) { acc.closest = v.closest; acc.closest_count = v.closest_count; }
+        else if (v.closest == acc.closest && v.closest != 0xFFFFFFFFu) acc.closest_count += v.closest_count;
+        if (!any) { acc.cfd_sum = v.cfd_sum; acc.hsu_sum = v.hsu_sum; acc.jost_sum = v.jost_sum; any = true; }
+        else { acc.cfd_sum += v.cfd_sum; acc.hsu_sum += v.hsu_sum; acc.jost_sum += v.jost_sum; }
+    }
+    if (crossing) atomicAdd(flag, 1u);
+    red[k] = acc;
+}
+// the slice's flag word into word sl of every row of prior_all (it travels back with the priors)
+__global__ void k_slice_flag(const uint32_t *__restrict__ flag, uint32_t sl, uint32_t world, uint32_t *__restrict__ prior_all) {
+    if (threadIdx.x < world) prior_all[(size_t)threadIdx.x * (sl + 1) + sl] = flag[0];
+}
+// what came back: prior_in [world][sl + 1], row j = my priors of slice j + slice j's flag word -> prior[G], flag[0] = failure bits OR-ed,
+// crossing counts added
+__global__ void k_slice_assemble(const uint32_t *__restrict__ prior_in, uint32_t G, uint32_t sl, uint32_t world, int with_prior, uint32_t *__restrict__ prior, uint32_t *__restrict__ flag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        uint32_t bits = 0u, count = 0u;
+        for (uint32_t j = 0; j < world; ++j) { const uint32_t w = prior_in[(size_t)j * (sl + 1) + sl]; bits |= w & 0xC0000000u; count += w & 0x3FFFFFFFu; }
+        flag[0] = bits | (count > 0x3FFFFFFFu ? 0x3FFFFFFFu : count);
+    }
+    if (with_prior && g < G) prior[g] = prior_in[(size_t)(g / sl) * (sl + 1) + g % sl];
+}
+
 }  // namespace ffh
 
 enum { FFH_COMM_COPY = 0, FFH_COMM_ALL = 1, FFH_COMM_RANK = 2 };
+enum { FFH_EXCHANGE_GATHER = 0, FFH_EXCHANGE_SLICE = 1 };
 static const char *const kSplitMessage = "the guide set was split (more raw hits than one scan holds): hit lists and device summaries are per call -- pass fewer guides per ffh_discover_sharded";
 constexpr int kSplitGuides = -1000;   // internal: comm_exchange -> discover_sharded_split (never returned through the C ABI)
 
@@ -137,6 +227,8 @@ struct ffh_comm {
     struct Buf {
         DevBuf<uint32_t> totals, prior, flag;    // the shard's own saturated totals, its prior (k_exchange_reduce), {crossing guides | failure bit}
         DevBuf<GuideSummary> summ, all, red;     // [G + 1] this shard's aggregates + status record; [world][G + 1] everybody's; [G] the reduced ones
+        DevBuf<GuideSummary> send, red_slice;    // slice exchange: [world][sl + 1] packed by destination; [sl] the folded slice (red then is [world * sl])
+        DevBuf<uint32_t> prior_all, prior_in;    // slice exchange: [world][sl + 1] priors of every shard for my slice (+ flag word); what came back
         hipEvent_t ev = nullptr, ev_done = nullptr;   // COPY transport: "my record is ready", "I have read everybody's"
     };
     std::vector<std::unique_ptr<Buf>> buf;
@@ -147,6 +239,7 @@ struct ffh_comm {
     bool exchanged = false;
     bool was_split = false;              // the last ffh_discover_sharded halved its guide set: hit lists / device summaries are refused
     uint32_t crossing = 0;               // guides of the last exchange whose cut-off fell inside a shard with a non-zero prior (second round)
+    int exchange = FFH_EXCHANGE_GATHER;   // which form of the exchange (ffh_comm_set_exchange; FFH_EXCHANGE=slice at creation)
     double scan_ms = 0, exchange_ms = 0;  // host wall time of the last ffh_discover_sharded: scans (all local shards), exchange + copy-out
 };
 
@@ -197,6 +290,44 @@ int comm_all_gather(ffh_comm *cm, uint64_t len, ncclDataType_t dt, Src src, Dst 
     return rc;
 }
 
+
+// all-to-all of `len` elements of T per pair: shard i's src(i)[j * len ..] -> shard j's dst(j)[i * len ..]; stream-ordered on the contexts' streams
+template <typename T, typename Src, typename Dst>
+int comm_all_to_all(ffh_comm *cm, uint64_t len, ncclDataType_t dt, Src src, Dst dst) {
+    const size_t L = cm->ctx.size();
+    if (cm->mode == FFH_COMM_COPY) {
+        for (size_t i = 0; i < L; ++i) { FFC_HIP(hipSetDevice(cm->ctx[i]->device)); FFC_HIP(hipEventRecord(cm->buf[i]->ev, cm->ctx[i]->st)); }
+        for (size_t j = 0; j < L; ++j) {
+            FFC_HIP(hipSetDevice(cm->ctx[j]->device));
+            for (size_t i = 0; i < L; ++i) {
+                if (i != j) FFC_HIP(hipStreamWaitEvent(cm->ctx[j]->st, cm->buf[i]->ev, 0));
+                FFC_HIP(hipMemcpyAsync(dst(j) + (uint64_t)i * len, src(i) + (uint64_t)j * len, len * sizeof(T), hipMemcpyDeviceToDevice, cm->ctx[j]->st));
+            }
+            FFC_HIP(hipEventRecord(cm->buf[j]->ev_done, cm->ctx[j]->st));
+        }
+        for (size_t i = 0; i < L; ++i) {   // (nobody rewrites what it sent before every peer has read it: as in comm_all_gather)
+            FFC_HIP(hipSetDevice(cm->ctx[i]->device));
+            for (size_t j = 0; j < L; ++j) if (i != j) FFC_HIP(hipStreamWaitEvent(cm->ctx[i]->st, cm->buf[j]->ev_done, 0));
+        }
+        return FFH_OK;
+    }
+    RcclApi *R = rccl_api();
+    if (!R->Send || !R->Recv) { cm->err = "this RCCL has no ncclSend / ncclRecv: the slice exchange is not available"; return FFH_E_STATE; }
+    const int W = cm->world;
+    FFC_NCCL(R->GroupStart());
+    int rc = FFH_OK;
+    for (size_t i = 0; i < L && rc == FFH_OK; ++i) {   // (an error inside the group still closes it)
+        if (hipSetDevice(cm->ctx[i]->device) != hipSuccess) { cm->err = "hipSetDevice failed inside the collective"; rc = FFH_E_HIP; break; }
+        for (int peer = 0; peer < W && rc == FFH_OK; ++peer) {
+            ncclResult_t r = R->Send(src(i) + (uint64_t)peer * len, len, dt, peer, cm->nccl[i], cm->ctx[i]->st);
+            if (r == ncclSuccess) r = R->Recv(dst(i) + (uint64_t)peer * len, len, dt, peer, cm->nccl[i], cm->ctx[i]->st);
+            if (r != ncclSuccess) { cm->err = std::string("ncclSend / ncclRecv: ") + R->GetErrorString(r); rc = FFH_E_HIP; }
+        }
+    }
+    { const ncclResult_t r = R->GroupEnd(); if (r != ncclSuccess && rc == FFH_OK) { cm->err = std::string("ncclGroupEnd: ") + R->GetErrorString(r); rc = FFH_E_HIP; } }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,6 +348,7 @@ static ffh_comm *comm_new(ffh_ctx *const *ctxs, int n) {
     ffh_comm *cm = new (std::nothrow) ffh_comm();
     if (!cm) { g_create_error = "out of memory"; return nullptr; }
     cm->ctx.assign(ctxs, ctxs + n);
+    { const char *e = std::getenv("FFH_EXCHANGE"); if (e && std::strcmp(e, "slice") == 0) cm->exchange = FFH_EXCHANGE_SLICE; }
     for (int i = 0; i < n; ++i) {
         cm->buf.emplace_back(new ffh_comm::Buf());
         if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipEventCreateWithFlags(&cm->buf.back()->ev, hipEventDisableTiming) != hipSuccess ||
@@ -295,6 +427,12 @@ int ffh_comm_world(const ffh_comm *cm) { return cm ? cm->world : 0; }
 int ffh_comm_first_shard(const ffh_comm *cm) { return cm ? cm->first : 0; }
 int ffh_comm_local_shards(const ffh_comm *cm) { return cm ? (int)cm->ctx.size() : 0; }
 int ffh_comm_transport(const ffh_comm *cm) { return cm ? cm->mode : -1; }
+int ffh_comm_set_exchange(ffh_comm *cm, int mode) {
+    if (!cm || (mode != FFH_EXCHANGE_GATHER && mode != FFH_EXCHANGE_SLICE)) return FFH_E_ARG;
+    cm->exchange = mode;   // (every rank of the communicator must choose the same form: the collectives differ)
+    return FFH_OK;
+}
+int ffh_comm_get_exchange(const ffh_comm *cm) { return cm ? cm->exchange : FFH_E_ARG; }
 int ffh_comm_timings(const ffh_comm *cm, double *scan_ms, double *exchange_ms) {
     if (!cm) return FFH_E_ARG;
     if (scan_ms) *scan_ms = cm->scan_ms;
@@ -315,13 +453,20 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
     const size_t L = cm->ctx.size();
     const uint32_t W = (uint32_t)cm->world;
     const unsigned jost = flags & FFH_FINALIZE_JOST;
+    // the exchange by guide slices (see k_exchange_reduce_slice): sl guides per rank; one rank or no guide: the all-gather form is the same thing
+    const bool slice = cm->exchange == FFH_EXCHANGE_SLICE && W > 1 && G > 0;
+    const uint32_t sl = slice ? (G + W - 1) / W : 0u;
     std::vector<int> ok(L, 1);
     for (size_t i = 0; i < L; ++i) {
         ffh_ctx *ctx = cm->ctx[i];
         ffh_comm::Buf &b = *cm->buf[i];
         FFC_HIP(hipSetDevice(ctx->device));
         FFC_HIP(b.totals.reserve((size_t)G + 1)); FFC_HIP(b.prior.reserve((size_t)G + 1)); FFC_HIP(b.flag.reserve(4));
-        FFC_HIP(b.summ.reserve((size_t)G + 1)); FFC_HIP(b.all.reserve((size_t)W * ((size_t)G + 1))); FFC_HIP(b.red.reserve((size_t)G + 1));
+        FFC_HIP(b.summ.reserve((size_t)G + 1)); FFC_HIP(b.all.reserve((size_t)W * ((size_t)G + 1))); FFC_HIP(b.red.reserve(std::max((size_t)G, (size_t)W * sl) + 1));
+        if (slice) {
+            FFC_HIP(b.send.reserve((size_t)W * (sl + 1))); FFC_HIP(b.red_slice.reserve((size_t)sl + 1));
+            FFC_HIP(b.prior_all.reserve((size_t)W * (sl + 1))); FFC_HIP(b.prior_in.reserve((size_t)W * (sl + 1)));
+        }
         FFC_HIP(ctx->n_ret.reserve((size_t)G + 1));
         if (local_rc && local_rc[i]) ok[i] = 0;
         else if (!ctx->scanned || ctx->n_guides != G) { ok[i] = 0; ctx->err = "the shard has not been scanned with this guide set"; }
@@ -336,11 +481,46 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
                                   d_prior, ctx->guides.p, ctx->geo, ctx->d_tab, G, (uint32_t)max_ot, jost ? 1 : 0, ctx->n_ret.p, cm->buf[i]->summ.p, d_totals, d_fix,
                                   (GuideSummary *)nullptr);
     };
-    auto gather = [&]() {
-        return comm_all_gather<uint64_t>(cm, ((uint64_t)G + 1) * (sizeof(GuideSummary) / 8), ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->summ.p; },
+    constexpr uint64_t kWords = sizeof(GuideSummary) / 8;
+    auto gather = [&]() -> int {
+        if (slice) {   // every shard packs its records by destination, then the all-to-all: shard j receives everybody's records of slice j
+            for (size_t i = 0; i < L; ++i) {
+                FFC_HIP(hipSetDevice(cm->ctx[i]->device));
+                hipLaunchKernelGGL(k_slice_pack, dim3(blocks_for((uint64_t)W * (sl + 1), 256)), dim3(256), 0, cm->ctx[i]->st, (const GuideSummary *)cm->buf[i]->summ.p, G, sl, W, cm->buf[i]->send.p);
+            }
+            FFC_HIP(hipGetLastError());
+            return comm_all_to_all<uint64_t>(cm, ((uint64_t)sl + 1) * kWords, ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->send.p; },
+                                             [&](size_t j) { return (uint64_t *)cm->buf[j]->all.p; });
+        }
+        return comm_all_gather<uint64_t>(cm, ((uint64_t)G + 1) * kWords, ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->summ.p; },
                                          [&](size_t j) { return (uint64_t *)cm->buf[j]->all.p; });
     };
     auto reduce = [&](int adjusted) -> int {
+        if (slice) {
+            for (size_t i = 0; i < L; ++i) {
+                ffh_comm::Buf &b = *cm->buf[i];
+                const uint64_t s0 = (uint64_t)(cm->first + (int)i) * sl;
+                const uint32_t n_slice = s0 >= G ? 0u : (uint32_t)std::min<uint64_t>(sl, G - s0);
+                FFC_HIP(hipSetDevice(cm->ctx[i]->device));
+                FFC_HIP(hipMemsetAsync(b.flag.p, 0, 8, cm->ctx[i]->st));
+                hipLaunchKernelGGL(k_exchange_reduce_slice, dim3(blocks_for((uint64_t)sl + 1, 256)), dim3(256), 0, cm->ctx[i]->st, (const GuideSummary *)b.all.p, n_slice, sl, W, (uint32_t)max_ot,
+                                   adjusted, b.prior_all.p, b.red_slice.p, b.flag.p);
+                if (!adjusted) hipLaunchKernelGGL(k_slice_flag, dim3(1), dim3(1024), 0, cm->ctx[i]->st, (const uint32_t *)b.flag.p, sl, W, b.prior_all.p);
+            }
+            FFC_HIP(hipGetLastError());
+            if (adjusted) return FFH_OK;
+            // the priors (and the slices' flag words) back to the shards they are about
+            const int rc = comm_all_to_all<uint32_t>(cm, (uint64_t)sl + 1, ncclUint32, [&](size_t i) { return (const uint32_t *)cm->buf[i]->prior_all.p; },
+                                                     [&](size_t j) { return cm->buf[j]->prior_in.p; });
+            if (rc) return rc;
+            for (size_t i = 0; i < L; ++i) {
+                ffh_comm::Buf &b = *cm->buf[i];
+                FFC_HIP(hipSetDevice(cm->ctx[i]->device));
+                hipLaunchKernelGGL(k_slice_assemble, dim3(blocks_for((uint64_t)G + 1, 256)), dim3(256), 0, cm->ctx[i]->st, (const uint32_t *)b.prior_in.p, G, sl, W, 1, b.prior.p, b.flag.p);
+            }
+            FFC_HIP(hipGetLastError());
+            return FFH_OK;
+        }
         for (size_t i = 0; i < L; ++i) {
             ffh_comm::Buf &b = *cm->buf[i];
             FFC_HIP(hipSetDevice(cm->ctx[i]->device));
@@ -383,6 +563,11 @@ static int comm_exchange(ffh_comm *cm, uint32_t G, int max_ot, unsigned flags, f
         rc = gather();
         if (rc) return rc;
         rc = reduce(1);
+        if (rc) return rc;
+    }
+    if (slice) {   // the folded slices to every rank: red = [world][sl], slice j holds guides j * sl .. -- the reduced array of the all-gather form
+        rc = comm_all_gather<uint64_t>(cm, (uint64_t)sl * kWords, ncclUint64, [&](size_t i) { return (const uint64_t *)cm->buf[i]->red_slice.p; },
+                                       [&](size_t j) { return (uint64_t *)cm->buf[j]->red.p; });
         if (rc) return rc;
     }
     if (summaries_out && G) {

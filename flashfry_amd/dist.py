@@ -169,6 +169,42 @@ class DeviceExchange:
         f64[:, [7, 8, 10]] = acc
         return self.summ
 
+    def reduce_summaries_sliced(self):
+        """reduce_summaries by GUIDE SLICES (round 6; the torch.distributed form of ffh_comm_set_exchange(1)): ONE all-to-all -- rank j receives
+        every rank's records of slice j = [j * sl, (j + 1) * sl), sl = ceil(G / world) -- the slice folded locally in rank order (= database
+        order: integer lanes add, overflow / cfd_max / jost_max take the maximum, the closest hit the minimum with its count summed at that
+        level, the three f64 sums are added rank after rank), and ONE all-gather of the folded slices.  world x less payload into every
+        rank than the three collectives over all G guides; the same bytes in self.summ afterwards."""
+        torch, dist, G, W = self.torch, self.dist, self.G, self.world
+        sl = (G + W - 1) // W
+        if sl == 0:
+            return self.summ
+        send = torch.zeros(W * sl * self.itemsize, dtype=torch.uint8, device=self.device)
+        send[: G * self.itemsize] = self.summ                        # slice j of the guides is chunk j; the tail pads the last slices
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)          # chunk r of recv = rank r's records of MY slice
+        i32 = recv.view(torch.int32).view(W, sl, 22)
+        f64 = recv.view(torch.float64).view(W, sl, 11)
+        closest = i32[:, :, 8].to(torch.int64) & 0xFFFFFFFF           # 0xFFFFFFFF = none
+        gmin = closest.min(0).values
+        out = torch.zeros(sl * self.itemsize, dtype=torch.uint8, device=self.device)
+        o32, o64 = out.view(torch.int32).view(sl, 22), out.view(torch.float64).view(sl, 11)
+        cols = [0, 1, 3, 4, 5, 6, 7, 10, 11]                          # n_hits, ot_count, hist[5], in_genome, n_scored
+        o32[:, cols] = i32[:, :, cols].sum(0, dtype=torch.int32)
+        o32[:, 2] = i32[:, :, 2].max(0).values                        # overflow
+        o32[:, 9] = torch.where(closest == gmin.unsqueeze(0), i32[:, :, 9], torch.zeros_like(i32[:, :, 9])).sum(0, dtype=torch.int32)
+        o32[:, 8] = torch.where(gmin > 0x7FFFFFFF, gmin - (1 << 32), gmin).to(torch.int32)
+        o64[:, 6] = f64[:, :, 6].max(0).values                        # cfd_max
+        o64[:, 9] = f64[:, :, 9].max(0).values                        # jost_max
+        acc = f64[0][:, [7, 8, 10]].clone()                           # cfd_sum, hsu_sum, jost_sum: rank after rank
+        for r in range(1, W):
+            acc += f64[r][:, [7, 8, 10]]
+        o64[:, [7, 8, 10]] = acc
+        gathered = torch.empty(W * sl * self.itemsize, dtype=torch.uint8, device=self.device)
+        self._all_gather(gathered, out)
+        self.summ.copy_(gathered[: G * self.itemsize])
+        return self.summ
+
     def reduce_summaries_fused(self, ctx):
         """reduce_summaries with the packing, masking and unpacking done by three library kernels (the torch form costs ~20 small
         launches): same three collectives, same arithmetic"""

@@ -314,6 +314,15 @@ int ffh_comm_world(const ffh_comm *comm);          /* shards in total */
 int ffh_comm_first_shard(const ffh_comm *comm);    /* number of this process's first shard */
 int ffh_comm_local_shards(const ffh_comm *comm);   /* shards held by this process */
 int ffh_comm_transport(const ffh_comm *comm);      /* 0 copies (shards share a device), 1 RCCL ncclCommInitAll, 2 RCCL ncclCommInitRank */
+/* Which form the exchange of ffh_discover_sharded / ffh_comm_exchange takes (every rank of the communicator must choose the same):
+ *   0  ONE all-gather of every shard's 88-byte per-guide records, folded by every rank (world x n_guides x 88 bytes received per rank; one latency)
+ *   1  by guide slices: an all-to-all (rank j receives everybody's records of slice j and folds them), the priors back in a second
+ *      all-to-all, the folded slices all-gathered: three collectives, ~1 / world of the payload.  Bit-identical results.
+ * Default 0; FFH_EXCHANGE=slice in the environment makes 1 the default of communicators created afterwards.  Which one is faster on
+ * xGMI at which world size is a measurement nobody has made yet (no multi-GPU run exists): bench.py --gpus N reports both per-rank
+ * exchange times when asked (FFH_EXCHANGE). */
+int ffh_comm_set_exchange(ffh_comm *comm, int mode);
+int ffh_comm_get_exchange(const ffh_comm *comm);
 /* Page-locked host memory for buffers the CALLER hands to the library (summaries_out of ffh_discover_sharded / ffh_comm_exchange): the
  * copy-out of 100 000 summaries (8.8 MB) takes 0.17 ms into such a buffer and about twice that into pageable memory, where the runtime
  * stages it.  (The results of ffh_finalize / ffh_discover live in page-locked blocks of the context's own pool already.)  A JNI binding

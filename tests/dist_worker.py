@@ -66,8 +66,13 @@ def main():
     prior_dev = ex.prior_from_totals(max_ot).numpy().astype(np.uint32)
     ex.summ.copy_(torch.from_numpy(summ.view(np.uint8).reshape(-1).copy()))
     ex.reduce_summaries()
+    # ... and so must the exchange by guide slices (one all-to-all + one all-gather: ffh_comm_set_exchange(1)'s torch.distributed form)
+    ex2 = ffdist.DeviceExchange(G, "cpu")
+    ex2.summ.copy_(torch.from_numpy(summ.view(np.uint8).reshape(-1).copy()))
+    ex2.reduce_summaries_sliced()
     ffdist.allreduce_summaries(summ)
     same_exchange = bool(np.array_equal(prior_dev, prior)) and ex.summ.numpy().tobytes() == summ.tobytes()
+    same_sliced = ex2.summ.numpy().tobytes() == summ.tobytes()
     gathered = [None] * world
     dist.all_gather_object(gathered, kept)
     if rank == 0:
@@ -75,7 +80,7 @@ def main():
         ok_hits = all(sum((gathered[r][g] for r in range(world)), []) == [int(x) for x in full.hits(g)] for g in range(G))
         exp = [oracle.score_guide(3, int(guides[g]), full.hits(g))[0] for g in range(G)]
         res = {
-            "world": world, "ok_hits": bool(ok_hits), "ok_device_exchange": same_exchange,
+            "world": world, "ok_hits": bool(ok_hits), "ok_device_exchange": same_exchange, "ok_sliced_exchange": same_sliced,
             "ok_totals": bool(np.array_equal(summ["ot_count"].astype(np.int64), full.current_total)),
             "ok_overflow": bool(np.array_equal(summ["overflow"].astype(bool), full.full)),
             "ok_hist": all(list(summ["hist"][g]) == list(exp[g].hist) for g in range(G)),

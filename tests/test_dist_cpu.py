@@ -30,7 +30,7 @@ def test_sharded_discover_over_gloo(tmp_path, world, max_ot):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     res = json.load(open(out))
     assert res["world"] == world
-    for k in ("ok_hits", "ok_totals", "ok_overflow", "ok_hist", "ok_closest", "ok_device_exchange"):
+    for k in ("ok_hits", "ok_totals", "ok_overflow", "ok_hist", "ok_closest", "ok_device_exchange", "ok_sliced_exchange"):
         assert res[k], (k, res)
     assert res["max_cfd_err"] <= 1e-9 and res["max_cfdmax_err"] == 0.0 and res["max_hsu_err"] <= 1e-9 and res["max_jost_err"] <= 1e-9, res
     if max_ot == 40:
