@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the self-verification and the list-delivering discover after the timed loop")
     ap.add_argument("--no-skewed", action="store_true", help="skip the second workload (repeat-structured genome, guides sampled from it)")
     ap.add_argument("--no-c2", action="store_true", help="skip the chr22-scale leg (configs[1]: 1000 guides, resident step + CLI wall time)")
+    ap.add_argument("--pipelined", action="store_true", help="also time distinct guide batches with two calls in flight (ffh_pipe) against sequential calls")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure the compare kernel's HBM traffic")
     ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"), help="where the PMC passes write their CSVs")
     return ap.parse_args()
@@ -322,6 +323,34 @@ def verify_step(torch, ctx, db, guides_np, step_result, args):
     note = ("summaries of the timed aggregates-only step == summaries of a list-delivering ffh_discover (bytes); hit lists and positions of %d "
             "sampled guides == brute-force torch scan of all targets + ordered cut-off" % len(sample))
     return True, med, note
+
+
+def pipelined_leg(torch, capi, synth, ctx, dev, args, n_batches=6, lanes=2):
+    """Distinct guide batches against the resident database, one after the other (what GPUTraverser.scala's grouped loop and the reference's
+    traverser do) and with `lanes` of them in flight (ffh_pipe_*: sharing contexts on the same database, one host thread each).  Both hand
+    the guides over as host buffers (a pipe copies them at submit), both deliver the per-guide aggregates; the results must be the same
+    bytes.  Reported BESIDE the synchronous step, never as `value`."""
+    G = args.guides
+    batches = [synth.make_guides(G, seed=synth.GUIDE_SEED + 1001 + 17 * k, device=dev).cpu().numpy().view(np.uint64) for k in range(n_batches)]
+    run = lambda g: ctx.discover(g, args.max_mismatch, args.max_offtargets, summaries_only=True)
+    for g in batches[:2]:
+        run(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seq = [run(g) for g in batches]
+    t_seq = (time.perf_counter() - t0) * 1e3 / n_batches
+    with ctx.pipe(lanes) as pipe:
+        for _ in range(2):   # (every lane's buffers, graphs and images warm)
+            for t in [pipe.submit(g, args.max_mismatch, args.max_offtargets, summaries_only=True) for g in batches[:2 * lanes]]:
+                pipe.wait(t)
+        t0 = time.perf_counter()
+        got = [pipe.wait(t) for t in [pipe.submit(g, args.max_mismatch, args.max_offtargets, summaries_only=True) for g in batches]]
+        t_pipe = (time.perf_counter() - t0) * 1e3 / n_batches
+    same = all(a.summaries.tobytes() == b.summaries.tobytes() for a, b in zip(seq, got))
+    if not same:
+        raise SystemExit("bench: a pipelined batch differs from the sequential call")
+    return {"what": "%d distinct batches of %d guides (host buffers), aggregates to the host: sequential ffh_discover calls against %d calls in flight (ffh_pipe)" % (n_batches, G, lanes),
+            "lanes": lanes, "batches": n_batches, "sequential_ms_per_batch": t_seq, "pipelined_ms_per_batch": t_pipe, "gain": 1.0 - t_pipe / t_seq, "identical": same}
 
 
 def skewed_workload(torch, capi, synth, ctx_uniform, dev, local, args):
@@ -613,7 +642,14 @@ def main():
         verify_db = None
         torch.cuda.empty_cache()
 
-    skewed, real_genome, c2 = None, None, None
+    skewed, real_genome, c2, pipelined = None, None, None, None
+    if rank == 0 and world == 1 and args.pipelined:
+        try:
+            pipelined = pipelined_leg(torch, capi, synth, ctx, dev, args)
+        except SystemExit:
+            raise
+        except Exception as e:  # a reported extra, never a reason to lose the measurement
+            pipelined = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_c2:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -692,6 +728,8 @@ def main():
             "step_delivers": "per-guide aggregates only (guides resident in HBM); hit lists: see discover_product_ms",
             # the same step with the guide set handed over as a (pageable) host buffer: PCIe-inclusive, never `value`
             "ms_per_step_host_guides": host_ms,
+            # distinct guide batches, two calls in flight against the resident database (ffh_pipe): beside the synchronous step, never `value`
+            "pipelined": pipelined, "pipelined_ms_per_step": pipelined.get("pipelined_ms_per_batch") if pipelined else None,
             "verified": verified, "verification": verify_note,
             # the complete discover product: scan + cut-off + aggregates + the retained hits (target long incl. count, mismatches) and
             # their positions on the host -- what ResultsAggregator hands to the writer (CRISPRHit: sequence, count, coordinates)

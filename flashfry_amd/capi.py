@@ -32,7 +32,8 @@ SYMBOLS = [
     "ffh_result_positions", "ffh_result_free", "ffh_get_timings",
     "ffh_comm_unique_id", "ffh_comm_create_rank", "ffh_comm_create_local", "ffh_comm_destroy", "ffh_comm_last_error", "ffh_comm_world",
     "ffh_comm_first_shard", "ffh_comm_local_shards", "ffh_comm_transport", "ffh_discover_sharded", "ffh_comm_exchange", "ffh_comm_shard_lists",
-    "ffh_comm_device_summaries", "ffh_comm_timings", "ffh_comm_set_exchange", "ffh_comm_get_exchange", "ffh_host_alloc", "ffh_host_free",
+    "ffh_comm_device_summaries", "ffh_comm_timings", "ffh_comm_set_exchange", "ffh_comm_get_exchange", "ffh_ctx_share_db", "ffh_pipe_create", "ffh_pipe_submit", "ffh_pipe_wait",
+    "ffh_pipe_last_error", "ffh_pipe_lanes", "ffh_pipe_destroy", "ffh_host_alloc", "ffh_host_free",
 ]
 
 
@@ -195,6 +196,14 @@ def load_library(build=True):
     L.ffh_comm_device_summaries.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.ffh_comm_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ffh_comm_set_exchange.argtypes = [C.c_void_p, C.c_int]
+    L.ffh_ctx_share_db.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.ffh_pipe_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.ffh_pipe_submit.argtypes = [C.c_void_p, u64p, C.c_uint32, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_uint64)]
+    L.ffh_pipe_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.ffh_pipe_last_error.restype = C.c_char_p
+    L.ffh_pipe_last_error.argtypes = [C.c_void_p]
+    L.ffh_pipe_lanes.argtypes = [C.c_void_p]
+    L.ffh_pipe_destroy.argtypes = [C.c_void_p]
     L.ffh_comm_get_exchange.argtypes = [C.c_void_p]
     if hasattr(L, "ffh_host_alloc"):   # (absent from A/B builds of earlier revisions: FFH_LIBRARY)
         L.ffh_host_alloc.restype = C.c_void_p
@@ -388,6 +397,19 @@ class Context:
         if rc != 0:
             raise FlashFryHipError(rc, self.L.ffh_last_error(self.h).decode())
 
+    def share(self):
+        """ffh_ctx_share_db: a second context on the same device that scans THIS context's resident database through aliases (nothing is
+        copied); the two may be driven from two host threads at once.  Close it before this one."""
+        out = C.c_void_p()
+        self._check(self.L.ffh_ctx_share_db(self.h, C.byref(out)))
+        c = Context.__new__(Context)
+        c.L, c.h, c.enzyme_index, c._owner = self.L, out.value, self.enzyme_index, self
+        return c
+
+    def pipe(self, lanes=2):
+        """ffh_pipe_create: `lanes` discover calls in flight against this context's database (do not use the context directly meanwhile)"""
+        return Pipe(self, lanes)
+
     # ---- database ------------------------------------------------------------------------------------
     def load_blocks(self, longs, bin_offsets):
         longs = np.ascontiguousarray(longs, dtype=np.int64)
@@ -559,6 +581,55 @@ class Context:
         t = Timings()
         self._check(self.L.ffh_get_timings(self.h, C.byref(t)))
         return t
+
+
+class Pipe:
+    """ffh_pipe_*: guide batches submitted to a FIFO, `lanes` of them in flight at once against one resident database"""
+
+    def __init__(self, ctx, lanes=2):
+        self.L, self.ctx = ctx.L, ctx
+        out = C.c_void_p()
+        ctx._check(self.L.ffh_pipe_create(ctx.h, int(lanes), C.byref(out)))
+        self.h = out.value
+        self._kind = {}
+
+    @property
+    def lanes(self):
+        return self.L.ffh_pipe_lanes(self.h)
+
+    def submit(self, guides, max_mismatch=4, max_offtargets=2000, summaries_only=False, jost=False, positions=True, hit_scores=True):
+        g = np.ascontiguousarray(guides).view(np.uint64)
+        t = C.c_uint64()
+        rc = self.L.ffh_pipe_submit(self.h, g.ctypes.data_as(u64p), len(g), max_mismatch, max_offtargets, self.ctx._finalize_flags(summaries_only, jost, positions, hit_scores), C.byref(t))
+        if rc:
+            raise FlashFryHipError(rc, "ffh_pipe_submit failed")
+        self._kind[t.value] = (not summaries_only, positions, hit_scores)
+        return t.value
+
+    def wait(self, ticket):
+        out = C.c_void_p()
+        rc = self.L.ffh_pipe_wait(self.h, ticket, C.byref(out))
+        lists, positions, hit_scores = self._kind.pop(ticket, (True, True, True))
+        if rc:
+            raise FlashFryHipError(rc, self.L.ffh_pipe_last_error(self.h).decode())
+        return Result(self.L, out.value, lists=lists, positions=positions, hit_scores=hit_scores)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ffh_pipe_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 TRANSPORTS = {0: "copy", 1: "rccl-all", 2: "rccl-rank"}

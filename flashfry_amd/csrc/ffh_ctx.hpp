@@ -27,27 +27,29 @@ template <typename T>
 struct DevBuf {  // device allocation that grows on demand and frees itself (on the device that is current: the entry points set it)
     T *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;   // an alias of another context's allocation (ffh_ctx_share_db): never freed here, replaced by an allocation of its own when it has to grow
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), borrowed(o.borrowed) { o.p = nullptr; o.cap = 0; o.borrowed = false; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        if (this != &o) { release(); p = o.p; cap = o.cap; borrowed = o.borrowed; o.p = nullptr; o.cap = 0; o.borrowed = false; }
         return *this;
     }
     ~DevBuf() { release(); }
     hipError_t reserve(size_t n) {  // contents are NOT preserved
         if (n <= cap) return hipSuccess;
         if (t_capturing) return hipErrorStreamCaptureUnsupported;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        if (p && !borrowed) (void)hipFree(p);
+        p = nullptr; cap = 0; borrowed = false;
         size_t want = n + n / 8 + 64;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if (e != hipSuccess) return e;
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
+    void alias(const DevBuf &o) { release(); p = o.p; cap = o.cap; borrowed = o.p != nullptr; }
 };
 
 struct Image {  // one bucketed scan image of the database
@@ -61,6 +63,10 @@ struct Image {  // one bucketed scan image of the database
     int rest = 0;             // bases in the rest key (the ones the bucket id does not hold)
     DevBuf<uint32_t> live;    // [2^live_bits] which bucket-id prefixes of live_bits = min(2 width, 12) bits hold a target (k_bucket_live)
     uint32_t live_bits = 0;
+    void alias(const Image &o) {   // the same image through another context (ffh_ctx_share_db): nothing is copied, nothing is owned
+        width = o.width; direct = o.direct; rest = o.rest; live_bits = o.live_bits;
+        bstart.alias(o.bstart); gstart.alias(o.gstart); gwords.alias(o.gwords); tidx.alias(o.tidx); live.alias(o.live);
+    }
 };
 
 struct Plan { int a, r1, s, r2; };  // prefix width/radius, suffix width/radius (r2 < 0: no suffix pass)
@@ -201,6 +207,8 @@ struct ffh_ctx {
     std::string err;
 
     // database
+    ffh_ctx *db_owner = nullptr;   // ffh_ctx_share_db: this context scans db_owner's resident database (targets, positions, the two scan images are aliases)
+    std::atomic<int> db_sharers{0};   // ... and so many contexts scan this one's: it must not load, rebuild or drop what they alias
     uint64_t T = 0, P = 0;
     bool db_sorted = false;   // targets are in sequence order (every database the reference writes is)
     DevBuf<uint64_t> targets, positions, pos_off;

@@ -346,6 +346,28 @@ int ffh_comm_device_summaries(ffh_comm *comm, int local_shard, const void **devi
 /* host wall time of the last ffh_discover_sharded: the scans (slowest local shard), the exchange incl. the copy-out */
 int ffh_comm_timings(const ffh_comm *comm, double *scan_ms, double *exchange_ms);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Several discover calls in flight against ONE resident database (round 6).
+ * The reference's traverser serves one guide set at a time (reference/traverser/LinearTraverser.scala:59-130); a host that cuts a guide file
+ * into batches pays every batch's host round trips with the device idle in between.  ffh_ctx_share_db makes a second context ON THE SAME
+ * DEVICE that scans `owner`'s database through aliases of its device memory (targets, positions, the two scan images: nothing is copied);
+ * everything a scan writes is the new context's own, on its own stream, so the two contexts may be driven from two host threads at once and
+ * every call returns what it would return alone.  While a sharing context exists the owner refuses to load or rebuild its database
+ * (FFH_E_STATE); destroy the sharing contexts before the owner.
+ * ffh_pipe_*: the convenience on top -- `lanes` contexts (the owner + lanes - 1 sharing ones), one host thread each, a FIFO of submitted
+ * guide batches.  ffh_pipe_submit copies the guides and returns a ticket at once; ffh_pipe_wait(ticket) blocks until that batch is done
+ * and hands over its result (ffh_discover's, flags as there; free it with ffh_result_free).  The owner context must not be used directly
+ * while the pipe exists.  ffh_pipe_destroy runs what is still queued, frees uncollected results and the sharing contexts.
+ * ------------------------------------------------------------------------------------------------------- */
+int ffh_ctx_share_db(ffh_ctx *owner, ffh_ctx **out);
+typedef struct ffh_pipe ffh_pipe;
+int ffh_pipe_create(ffh_ctx *owner, int lanes /* 1 .. 8 */, ffh_pipe **out);
+int ffh_pipe_submit(ffh_pipe *pipe, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, uint64_t *ticket);
+int ffh_pipe_wait(ffh_pipe *pipe, uint64_t ticket, ffh_result **out);
+const char *ffh_pipe_last_error(const ffh_pipe *pipe);
+int ffh_pipe_lanes(const ffh_pipe *pipe);
+void ffh_pipe_destroy(ffh_pipe *pipe);
+
 /* The `score` path (modules/ScoreResults.scala:90-154): hit lists that already exist (re-read from a discover table)
  * are scored on the device with the same epilogue.  guide_offsets has n_guides+1 entries into hit_targets; the
  * lists are taken as they are (no cut-off, overflow = 0).  No database needs to be loaded.  The result carries
