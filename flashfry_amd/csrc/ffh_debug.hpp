@@ -34,6 +34,9 @@ struct Switches {
                                      // <= 2 or >= 6 mismatches -- always deal with a fixed stride, launch_compare_pair)
     bool pipeline = false;           // FFH_PIPELINE=1: a list-delivering ffh_discover scans its guide set in two parts, the first part's lists crossing the
                                      // link under the second part's scan.  OFF: measured slower on this stack (profiles/r05/ab_log.txt 7); kept for tests / A-B
+    bool list_zero_copy = false;     // FFH_LIST_ZERO_COPY=1: a list-delivering finalize stores the per-hit arrays and the positions straight into the result's page-locked
+                                     // block from the kernels that produce them (as the summaries always are) instead of copying them afterwards.  OFF until measured
+                                     // (round 6: built while the GPU pool was closed; results must be the same bytes: tests/test_gpu_configs.py)
     bool load_pipeline = false;      // FFH_LOAD_PIPELINE=1: ffh_db_open moves even a small body through the threaded page-locked pipeline (A/B)
     bool slab_totals_sorted = false; // FFH_SLAB_TOTALS=sort: a bounded scan adds up a slab's positions per guide from the records ordered by guide (round 4) instead of k_slab_totals
     bool slab_filter = true;         // FFH_SLAB_FILTER=0: a bounded scan keeps every record of the slab in which a guide reaches the limit (round 4)
@@ -66,6 +69,7 @@ struct Switches {
         s.slab_filter = num("FFH_SLAB_FILTER", 1) != 0;
         s.slab_totals_sorted = is("FFH_SLAB_TOTALS", "sort");
         s.load_pipeline = num("FFH_LOAD_PIPELINE", 0) == 1;
+        s.list_zero_copy = num("FFH_LIST_ZERO_COPY", 0) == 1;
         s.nb_force[0] = (int)num("FFH_NB_PREFIX", 0); s.nb_force[1] = (int)num("FFH_NB_SUFFIX", 0);
         { const long v = num("FFH_RAW_HIT_LIMIT", 0); if (v > 0) s.raw_hit_limit = (uint64_t)v; }
         return s;

@@ -664,7 +664,9 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
                              uint8_t *__restrict__ out_mm, uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_tidx,
                              double *__restrict__ out_cfd, double *__restrict__ out_hsu, double *__restrict__ out_jost /* may be null */,
                              const uint32_t *__restrict__ pre, const uint64_t *__restrict__ pos_base, uint64_t *__restrict__ out_posoff /* all three
-                             nullable: first position slot of every retained hit = the guide's base + the kept positions before the hit (k_cutoff) */) {
+                             nullable: first position slot of every retained hit = the guide's base + the kept positions before the hit (k_cutoff) */,
+                             uint64_t *__restrict__ h_target = nullptr, uint8_t *__restrict__ h_mm = nullptr, double *__restrict__ h_cfd = nullptr /* nullable
+                             (FFH_LIST_ZERO_COPY): the result's own page-locked arrays -- what the host reads is stored there as well, under the kernel */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_hits) return;
     const uint64_t key = hits[i];
@@ -685,6 +687,9 @@ __global__ void k_score_hits(const uint64_t *__restrict__ hits, uint64_t n_hits,
     out_hsu[o] = hsu;
     if (out_jost) out_jost[o] = (geo.c0 == 3 && mm != 0) ? jost_pair(guides[g], t, geo, tab) : __builtin_nan("");
     if (out_posoff) out_posoff[o] = pos_base[g] + pre[i];
+    if (h_target) h_target[o] = t;
+    if (h_mm) h_mm[o] = (uint8_t)mm;
+    if (h_cfd) h_cfd[o] = cfd;
 }
 
 // the same for caller-supplied hit lists (the `score` path: hit lists re-read from a discover table)

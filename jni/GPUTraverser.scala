@@ -53,6 +53,12 @@ object GPUTraverser extends Traverser with LazyLogging {
   @native private def discoverSharded(comm: Long, guides: Array[Long], maxMismatch: Int, maxOffTargets: Int): Int // ffh_discover_sharded
   @native private def shardLists(comm: Long, shard: Int): Long                          // ffh_comm_shard_lists: ffh_result*, 0 on error
   @native private def commLastError(comm: Long): String
+  // the batches of a large guide set in flight against the one resident database (ffh_pipe_*: sharing contexts, one host thread each)
+  @native private def pipeCreate(ctx: Long, lanes: Int): Long                           // ffh_pipe*, 0 on error
+  @native private def pipeSubmit(pipe: Long, guides: Array[Long], maxMismatch: Int, maxOffTargets: Int): Long // ticket, 0 on error
+  @native private def pipeWait(pipe: Long, ticket: Long): Long                          // ffh_result*, 0 on error
+  @native private def pipeLastError(pipe: Long): String
+  @native private def pipeDestroy(pipe: Long): Unit
 
   /** guides per native call, sized so that no returned Array[Long] can reach the 2^31 elements a JVM array holds: a guide keeps
     * fewer than maxOffTargets + 32767 positions (the hit that crosses the limit is kept whole, BlockReader.scala:147-153 caps a
@@ -165,7 +171,28 @@ object GPUTraverser extends Traverser with LazyLogging {
         // maximumOffTargets: the same for every guide of a run (OffTargetDiscovery.scala:100-102); needs CRISPRSiteOT.overflowValue
         val maxOffTargets = aggregator.wrappedGuides.head.otSite.overflowValue
 
-        guides.grouped(guidesPerCall(maxOffTargets)).foreach { batch =>
+        val batches = guides.grouped(guidesPerCall(maxOffTargets)).toArray
+        // One device, several batches: two calls in flight (-Dflashfry.gpu.lanes, default 2).  The reference's traverser serves one
+        // aggregator at a time (LinearTraverser.scala:59-130); here batch k + 1 is scanned while batch k's lists cross the link and are
+        // replayed into the aggregator.  Results are collected -- and replayed -- in submission order, so updateOT sees the sequence it
+        // would see from sequential calls.
+        val lanes = math.max(1, Integer.getInteger("flashfry.gpu.lanes", 2).intValue)
+        if (devs.length == 1 && batches.length > 1 && lanes > 1) {
+          val pipe = pipeCreate(ctxs(0), math.min(lanes, 8))
+          if (pipe == 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))
+          try {
+            val tickets = batches.map { batch =>
+              val t = pipeSubmit(pipe, batch.map(_.guide), maxMismatch, maxOffTargets)
+              if (t == 0) throw new IllegalStateException("GPUTraverser: a guide batch could not be submitted")
+              t
+            }
+            batches.indices.foreach { k =>
+              val res = pipeWait(pipe, tickets(k))
+              if (res == 0) throw new IllegalStateException("GPUTraverser: " + pipeLastError(pipe))
+              try replay(res, ctxs(0), batches(k), aggregator) finally resultFree(res)
+            }
+          } finally pipeDestroy(pipe)
+        } else batches.foreach { batch =>
           if (devs.length == 1) {
             val res = discover(ctxs(0), batch.map(_.guide), maxMismatch, maxOffTargets)
             if (res == 0) throw new IllegalStateException("GPUTraverser: " + lastError(ctxs(0)))

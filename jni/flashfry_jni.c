@@ -55,6 +55,37 @@ JNIEXPORT jlong JNICALL FN(discover)(JNIEnv *e, jobject self, jlong ctx, jlongAr
     return rc ? 0 : (jlong)(intptr_t)r;
 }
 
+/* ffh_pipe_*: the batches of a large guide set in flight against the one resident database (round 6) */
+#define PIPE(h) ((ffh_pipe *)(intptr_t)(h))
+JNIEXPORT jlong JNICALL FN(pipeCreate)(JNIEnv *e, jobject self, jlong ctx, jint lanes) {
+    (void)e; (void)self;
+    ffh_pipe *p = 0;
+    return ffh_pipe_create(CTX(ctx), (int)lanes, &p) ? 0 : (jlong)(intptr_t)p;
+}
+JNIEXPORT jlong JNICALL FN(pipeSubmit)(JNIEnv *e, jobject self, jlong pipe, jlongArray guides, jint max_mismatch, jint max_offtargets) {   /* the ticket, 0 on error */
+    (void)self;
+    const jsize n = (*e)->GetArrayLength(e, guides);
+    jlong *g = (*e)->GetLongArrayElements(e, guides, 0);
+    if (!g) return 0;
+    uint64_t ticket = 0;
+    const int rc = ffh_pipe_submit(PIPE(pipe), (const uint64_t *)g, (uint32_t)n, (int)max_mismatch, (int)max_offtargets, FFH_FINALIZE_NO_HIT_SCORES, &ticket);   /* (the guides are copied) */
+    (*e)->ReleaseLongArrayElements(e, guides, g, JNI_ABORT);
+    return rc ? 0 : (jlong)ticket;
+}
+JNIEXPORT jlong JNICALL FN(pipeWait)(JNIEnv *e, jobject self, jlong pipe, jlong ticket) {   /* the ffh_result handle or 0 */
+    (void)e; (void)self;
+    ffh_result *r = 0;
+    return ffh_pipe_wait(PIPE(pipe), (uint64_t)ticket, &r) ? 0 : (jlong)(intptr_t)r;
+}
+JNIEXPORT jstring JNICALL FN(pipeLastError)(JNIEnv *e, jobject self, jlong pipe) {
+    (void)self;
+    return (*e)->NewStringUTF(e, ffh_pipe_last_error(PIPE(pipe)));
+}
+JNIEXPORT void JNICALL FN(pipeDestroy)(JNIEnv *e, jobject self, jlong pipe) {
+    (void)e; (void)self;
+    ffh_pipe_destroy(PIPE(pipe));
+}
+
 static jlongArray to_jlongs(JNIEnv *e, const uint64_t *p, uint64_t n) {
     if (n > 0x7FFFFFF0ull) return 0;   /* a Java array holds < 2^31 elements: the caller splits the guide set before that */
     jlongArray a = (*e)->NewLongArray(e, (jsize)n);

@@ -21,7 +21,10 @@ def test_jni_sources_cover_the_natives_and_only_call_the_c_abi():
     assert sorted(natives) == sorted(["create", "destroy", "dbOpen", "discover", "resultOffsets", "resultTargets", "resultPosOffsets",
                                       "resultPositions", "resultFree", "lastError",
                                       # several GPUs: one context per device, the exchange inside the library (VERDICT r3 missing 2)
-                                      "dbOpenHeader", "dbBins", "dbBinBytes", "createLocalComm", "commDestroy", "discoverSharded", "shardLists", "commLastError"])
+                                      "dbOpenHeader", "dbBins", "dbBinBytes", "createLocalComm", "commDestroy", "discoverSharded", "shardLists", "commLastError",
+                                      # the batches of a large guide set in flight against one resident database (round 6: ffh_pipe_*)
+                                      "pipeCreate", "pipeSubmit", "pipeWait", "pipeLastError", "pipeDestroy"])
+    assert "flashfry.gpu.lanes" in scala and "pipeSubmit(pipe" in scala and "pipeWait(pipe, tickets(k))" in scala
     assert "flashfry.gpu.devices" in scala and "discoverSharded(comm" in scala and "shardLists(comm, i)" in scala
     for n in natives:  # every native method has its JNI function
         assert re.search(r"FN\(%s\)\(JNIEnv" % n, c), n
