@@ -36,7 +36,7 @@ struct Switches {
                                      // link under the second part's scan.  OFF: measured slower on this stack (profiles/r05/ab_log.txt 7); kept for tests / A-B
     bool list_zero_copy = false;     // FFH_LIST_ZERO_COPY=1: a list-delivering finalize stores the per-hit arrays and the positions straight into the result's page-locked
                                      // block from the kernels that produce them (as the summaries always are) instead of copying them afterwards.  OFF until measured
-                                     // (round 6: built while the GPU pool was closed; results must be the same bytes: tests/test_gpu_configs.py)
+                                     // (round 6: built while the GPU pool was closed; results must be the same bytes: tests/test_zz_r6_zero_copy.py)
     bool load_pipeline = false;      // FFH_LOAD_PIPELINE=1: ffh_db_open moves even a small body through the threaded page-locked pipeline (A/B)
     bool slab_totals_sorted = false; // FFH_SLAB_TOTALS=sort: a bounded scan adds up a slab's positions per guide from the records ordered by guide (round 4) instead of k_slab_totals
     bool slab_filter = true;         // FFH_SLAB_FILTER=0: a bounded scan keeps every record of the slab in which a guide reaches the limit (round 4)

@@ -80,41 +80,6 @@ def test_shards_on_one_device_through_the_copy_transport(capi, case, world, max_
         assert (spans >= 2).sum() > 0 and 0 < int(full.summaries["overflow"].sum()) < G
 
 
-@pytest.mark.parametrize("world,max_ot,n_guides", [(2, 40, 300), (3, 15, 299), (5, 2000, 300), (8, 25, 300), (8, 25, 5)])
-def test_exchange_by_guide_slices_equals_the_all_gather_form(capi, case, world, max_ot, n_guides):
-    """round 6: ffh_comm_set_exchange(1) -- all-to-all of the records by guide slice, every rank folds its slice, the
-    priors travel back, the folded slices are all-gathered -- over the copy transport: reduced aggregates byte-identical to the
-    all-gather form's, and every shard's hit list (cut off with the prior the exchange left on its device) the same.  Guide counts that
-    the world size does not divide, fewer guides than shards, cut-offs that cross shard boundaries (the second round)."""
-    odb, targets, positions, guides, sizes = case
-    guides = guides[:n_guides]
-    ctxs = []
-    try:
-        for lo, hi, plo, phi in shard_slices(targets, sizes, world):
-            c = capi.Context(3)
-            c.load_soa(targets[lo:hi], positions[plo:phi])
-            ctxs.append(c)
-        with capi.Comm.local(ctxs) as comm:
-            ref = comm.discover(guides, 4, max_ot, jost=True).copy()
-            ref_lists = [comm.shard_lists(i, jost=True) for i in range(world)]
-            comm.set_exchange("slice")
-            got = comm.discover(guides, 4, max_ot, jost=True).copy()
-            got_lists = [comm.shard_lists(i, jost=True) for i in range(world)]
-            again = comm.discover(guides, 4, max_ot, jost=True)
-            assert again.tobytes() == got.tobytes()
-            comm.set_exchange("gather")
-            back = comm.discover(guides, 4, max_ot, jost=True)
-            assert back.tobytes() == ref.tobytes()
-    finally:
-        for c in ctxs:
-            c.close()
-    assert got.tobytes() == ref.tobytes()
-    for a, b in zip(ref_lists, got_lists):
-        assert np.array_equal(a.guide_offsets, b.guide_offsets) and np.array_equal(a.hit_targets, b.hit_targets) and a.summaries.tobytes() == b.summaries.tobytes()
-    if max_ot < 2000 and n_guides > 100:
-        assert 0 < int(ref["overflow"].sum()) < n_guides
-
-
 def test_one_rank_rccl_communicator(capi, case):
     """ncclCommInitRank with world 1: every collective of the exchange runs through librccl on the context's stream"""
     odb, targets, positions, guides, sizes = case
