@@ -72,3 +72,14 @@ def test_bulge_results_of_shards_merge_in_rank_order():
         a, b = int(m.guide_offsets[g]), int(m.guide_offsets[g + 1])
         got = list(zip(m.hit_targets[a:b].tolist(), m.hit_mismatches[a:b].tolist(), m.hit_bulge_type[a:b].tolist(), m.hit_bulge_position[a:b].tolist()))
         assert got == per_guide[g]
+
+
+def test_exchange_kernels_emulated_on_the_cpu(tmp_path):
+    """round 6: the kernels of the shards' exchange, compiled by g++ from the source the GPU build compiles and run thread after thread
+    (tests/exchange_emul_main.cpp): the exchange by guide slices -- pack, all-to-all, fold per slice, priors and flag back, assemble,
+    all-gather of the folded slices -- leaves on every shard the prior, the flag word and the reduced records of the all-gather form;
+    world 2 / 3 / 5 / 8, guide counts the world size does not divide, fewer guides than shards, failing shards, both rounds."""
+    exe = str(tmp_path / "exchange_emul")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "exchange_emul_main.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "leaves what the all-gather form leaves" in r.stdout, r.stdout[-2000:]
