@@ -169,8 +169,9 @@ struct ScanStats {
 class GpuTraverser {
 public:
     // devices: GPU ids; the bins are sharded contiguously over them (one host thread + one context per GPU)
+    // header: what readHeaderInfo(binaryFile) returned to a caller that has read it already (nullptr: read here)
     static ScanStats scan(const std::string &binaryFile, std::vector<CRISPRSiteOT> &guides, int maxMismatch, int maximumOffTargets,
-                          const std::vector<int> &devices, bool wantPositions);
+                          const std::vector<int> &devices, bool wantPositions, const struct HeaderInfo *header = nullptr);
 };
 
 // header of an on-disk database (enzyme + contig table): BinaryHeader.readHeader, reference/binary/BinaryHeader.scala:115-160

@@ -278,7 +278,7 @@ HeaderInfo readHeaderInfo(const std::string &databasePath) {
 
 // ---- GpuTraverser: the replacement of SeekTraverser / LinearTraverser.scan ------------------------------------------------
 ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSiteOT> &guides, int maxMismatch, int maximumOffTargets,
-                             const std::vector<int> &devices, bool wantPositions) {
+                             const std::vector<int> &devices, bool wantPositions, const HeaderInfo *header) {
     using clk = std::chrono::steady_clock;
     ScanStats st;
     const size_t ng = guides.size(), nd = std::max<size_t>(devices.size(), 1);
@@ -286,7 +286,9 @@ ScanStats GpuTraverser::scan(const std::string &binaryFile, std::vector<CRISPRSi
     std::vector<uint64_t> longs(ng);
     for (size_t i = 0; i < ng; ++i) longs[i] = guides[i].longEncoding;
     // contiguous bin ranges balanced by payload bytes
-    const HeaderInfo hdr = readHeaderInfo(binaryFile);
+    // (the CLI has read the header already: a second read costs a context -- streams, events, device memory -- created and destroyed for it)
+    const HeaderInfo own = header ? HeaderInfo() : readHeaderInfo(binaryFile);
+    const HeaderInfo &hdr = header ? *header : own;
     const size_t nbins = hdr.binBytes.size();
     std::vector<uint32_t> cut(nd + 1, 0);
     {
