@@ -80,10 +80,12 @@ __global__ void k_slice_pack(const GuideSummary *__restrict__ summ /* [G + 1], r
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= world * (sl + 1u)) return;
     const uint32_t j = t / (sl + 1u), k = t % (sl + 1u), g = j * sl + k;
-    GuideSummary v{};
-    if (k == sl) v = summ[G];
-    else if (g < G) v = summ[g];
-    send[t] = v;
+    // (moved as eleven 64-bit words: a GuideSummary held in a local was 96 bytes of scratch per lane)
+    static_assert(sizeof(GuideSummary) == 11 * sizeof(uint64_t), "the record is moved as eleven 64-bit words");
+    const uint64_t *src = k == sl ? (const uint64_t *)(summ + G) : g < G ? (const uint64_t *)(summ + g) : nullptr;   // (past G: the padding of the last slices)
+    uint64_t *dst = (uint64_t *)(send + t);
+#pragma unroll
+    for (int w = 0; w < 11; ++w) dst[w] = src ? src[w] : 0ull;
 }
 // fold of one slice: `all` = [world][sl + 1] (per source shard: the slice's records, then the shard's status record); n_slice guides of it
 // exist.  prior_all [world][sl + 1]: row r = the prior of shard r for the slice's guides (first round only; word sl of every row is filled
