@@ -32,6 +32,11 @@ def test_jni_sources_cover_the_natives_and_only_call_the_c_abi():
     for sym in set(re.findall(r"\b(ffh_\w+)\s*\(", c)):
         assert sym in declared, sym
     assert "extends Traverser" in scala and "aggregator.updateOT" in scala and "overflowValue" in scala
+    # the shim's C is type-checked against the library's header (a box without a JDK: the eight JNI functions it calls are declared from
+    # the public JNI specification in tests/jni_typecheck/jni.h -- declarations only, nothing is linked or run against them)
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "jni_typecheck"),
+                        os.path.join(JNI, "flashfry_jni.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     assert os.path.exists(os.path.join(JNI, "Makefile"))
     r = subprocess.run(["make", "-C", JNI], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "JAVA_HOME"})
     assert r.returncode == 0 and "JAVA_HOME is not set" in r.stdout
