@@ -44,6 +44,12 @@ constexpr int FFH_WAVES_PER_SIMD = 4;   // launch bound (four blocks of four wav
 constexpr int FFH_GPL = 6;              // groups per job of a large bucket, about
 constexpr int FFH_PIPE_TRIPS = 2;       // 16-byte pieces of a group's words requested one group ahead (more cost registers)
 constexpr int FFH_MAX_ENTRY_WORK = 2048;   // group tests per work entry of a heavy bucket, at most
+constexpr int FFH_ROW_SETUP_Q = 0;         // one-bucket pieces: quarters of a step a row's set-up is priced at when the parts per candidate are chosen.  0 = round 5's
+                                           // price (rows x steps).  tools/lds_conflict_model.py: a row's set-up costs ~1.25 steps (60 against 48 instructions), and with
+                                           // it priced the suffix image stops cutting a bucket into 12-13 parts of 3 groups -- two rows, and the parts p and p + 8 of
+                                           // one candidate on the same LDS banks (a group there is an EVEN number of 16-byte pieces) -- in favour of 6 parts of 7 groups
+                                           // in one row: predicted -2 % vector instructions, -11 % LDS cycles of the strip reads on that image.  A/B: FFH_ROW_SETUP_Q=5
+                                           // (tools/build_variant.sh); unmeasured, hence 0
 constexpr int FFH_TRIP_STATS = 0;          // 1 (tools/build_variant.sh only): the kernel counts its rows, steps, parks, pushes and flushes per image
                                            // (cursor[16..27], printed by scan_impl) -- the trip counts of profiles/r05/compare_attribution.md
 constexpr int kCmpThreads = 256;           // four waves, each with its own LDS strip: no block-level synchronisation in the kernel
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(kCmpThreads, FFH_WAVES_PER_SIMD) void k_compare(con
                 if (Pc > 1u) perc |= 1u;     // (an odd number of groups per part keeps the parts out of each other's LDS banks: below)
                 Pc = perc ? ceil_div(ngr0, perc) : 1u;
                 const uint32_t rows_c = (ng0 * Pc + 63u) >> 6;
-                uint32_t best = ((rows_c * perc) << 16) | (rows_c << 8) | Pc;    // fewest row-steps, then fewest rows, then fewest parts
+                uint32_t best = ((4u * rows_c * perc + (uint32_t)FFH_ROW_SETUP_Q * rows_c) << 16) | (rows_c << 8) | Pc;    // fewest row-steps (in quarters, + the rows' set-up), then fewest rows, then fewest parts
                 best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
                 best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
                 best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x141, 0xf, 0xf, false));   // row_half_mirror

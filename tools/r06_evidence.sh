@@ -9,6 +9,7 @@
 #   shard     one rank's step of a 1 / 2 / 4 / 8-way run through the (one-rank) communicator
 #   lists     the list-delivering discover: copying form against FFH_LIST_ZERO_COPY=1
 #   sweep     the randomised parity sweep, both checker modes, on the final code
+#   setupq    A/B of FFH_ROW_SETUP_Q (the row set-up priced when the suffix image's parts per candidate are chosen: tools/lds_conflict_model.py)
 #   gather    FETCH_SIZE and the TCC request counters on a random 8-byte gather of known footprint (66 or 132 B per hit?)
 #   c2 skewed timeline other grid r03   as in tools/r05_evidence.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -31,6 +32,8 @@ skewed) timeout 600 bash tools/skewed_timeline.sh > $O/skewed_timeline.txt 2>&1;
 timeline) timeout 300 bash tools/timeline.sh > $O/timeline_step.txt 2>&1; timeout 300 bash tools/timeline.sh --targets 4.5e6 --guides 1000 > $O/timeline_c2.txt 2>&1; tail -4 $O/timeline_step.txt ;;
 other)  timeout 900 bash tools/pmc_other_kernels.sh > $O/pmc_other_kernels.txt 2>&1; tail -40 $O/pmc_other_kernels.txt ;;
 sweep)  timeout $(( ${STRESS_SECS:-600} + 300 )) bash tools/stress_sweep.sh ${STRESS_SECS:-600} 5 gpurun_out/r06_evidence/stress ;;
+setupq) bash tools/build_variant.sh WORK setup0 > /dev/null 2>&1; bash tools/build_variant.sh WORK setup5 FFH_ROW_SETUP_Q=5 > /dev/null 2>&1
+        for v in setup0 setup5 setup0 setup5; do echo "$v $(FFH_LIBRARY=$R/flashfry_amd/lib/ab/$v.so timeout 300 python bench.py --no-traffic --cpu-seconds 0 --no-verify --no-skewed --no-c2 --steps 40 --warmup 5 2>/dev/null | tail -1 | python -c 'import sys, json; d = json.loads(sys.stdin.read()); print(d["ms_per_step"], d["breakdown_ms"])')"; done | tee $O/ab_row_setup.txt ;;
 gather) timeout 1200 bash tools/pmc_gather_calibration.sh > $O/gather_calibration.log 2>&1; tail -30 $O/gather_calibration.log ;;
 grid)   timeout 1500 python tools/timing_grid.py > $O/timing_grid.md 2> $O/timing_grid.err; tail -12 $O/timing_grid.md ;;
 r03)    timeout 900 python tools/ingest_scale.py > $O/ingest_scale.txt 2>&1; tail -5 $O/ingest_scale.txt; timeout 900 python tools/cli_wall.py --mbases 3100 --big-guides 100000 > $O/cli_wall.txt 2>&1; tail -12 $O/cli_wall.txt ;;
