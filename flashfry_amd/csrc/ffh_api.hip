@@ -39,7 +39,8 @@
 #include "ffh_load.inc"         // scan images, ffh_db_load_soa / _blocks / ffh_db_open
 #include "ffh_scan.inc"         // candidate lists, bounded scan, hit ordering, ffh_scan*
 #include "ffh_finalize.inc"     // ffh_finalize, ffh_discover, ffh_score_lists, result accessors
-#include "ffh_pipe.inc"         // ffh_ctx_share_db, ffh_pipe_*: several discover calls in flight against one resident database
+#include "ffh_share.inc"        // ffh_ctx_share_db: a context that scans another context's resident database through aliases
+#include "ffh_pipe.inc"         // ffh_pipe_*: several discover calls in flight against one resident database
 #include "ffh_index_api.inc"    // ffh_indexer_*
 #include "ffh_bulge_api.inc"    // ffh_discover_bulge
 #include "ffh_exchange.inc"     // ffh_finalize_shard, ffh_exchange_*
