@@ -170,3 +170,13 @@ def test_pipe_logic_under_thread_sanitizer(tmp_path):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=thread", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "pipe_emul_main.cpp")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "every ticket its own result" in r.stdout and "ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-3000:]
+
+
+def test_devbuf_ownership_rules(tmp_path):
+    """round 6: DevBuf<T> (csrc/ffh_devbuf.hpp) against counting stand-ins of hipMalloc / hipFree, under AddressSanitizer: an owner frees its
+    allocation exactly once, an alias (ffh_ctx_share_db) never does, an alias that has to grow gets memory of its own, moves and swaps carry
+    the flag"""
+    exe = str(tmp_path / "devbuf_emul")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address", "-o", exe, os.path.join(ROOT, "tests", "devbuf_emul_main.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "owners free once, aliases never" in r.stdout, (r.stdout + r.stderr)[-3000:]
