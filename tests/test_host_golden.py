@@ -21,7 +21,11 @@ def host_golden(tmp_path_factory):
     _build.build_hip_library()
     exe = str(tmp_path_factory.mktemp("host_golden") / "host_golden")
     host = os.path.join(ROOT, "flashfry_amd", "host")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "host_golden_main.cpp"),
+    # (round 6: the host layer under AddressSanitizer + UBSan for these runs -- it is what a drop-in CLI user's tables go through; leaks are
+    # not looked for: the HIP runtime the library links keeps what it allocates at load time)
+    os.environ.setdefault("ASAN_OPTIONS", "detect_leaks=0")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-Wall", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "host_golden_main.cpp"),
                            os.path.join(host, "ffhost_core.cpp"), os.path.join(host, "ffhost_table.cpp"), os.path.join(host, "ffhost_index.cpp"),
                            "-L" + _build.LIB_DIR, "-lflashfry_hip", "-Wl,-rpath," + _build.LIB_DIR, "-lz", "-lpthread"])
     return exe
