@@ -1,0 +1,79 @@
+/* tests/mock_hip/mock_hip.c -- an LD_PRELOAD stand-in of the 35 HIP entry points libflashfry_hip.so imports, for HOST-LOGIC tests on a box
+ * without a GPU (round 6; test infrastructure).  "Device" memory is calloc'd host memory, copies are memcpy, kernels DO NOT RUN (a launch is
+ * counted and returns), streams / events / graphs are tokens.  What the library's host code does with contexts, shared databases, pipes,
+ * streams and allocations can then be exercised end to end -- create, load an empty database, share, scan (every count reads zero), finalize,
+ * destroy -- and counted: mock_hip_counts() tells how many streams were created and DESTROYED (the library must never destroy one,
+ * csrc/ffh_streams.hpp), how many device allocations are live, how many frees hit something that was not allocated.
+ * It proves nothing about kernels or about the real runtime. */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int hipError_t;
+typedef struct { unsigned x, y, z; } dim3_t;
+enum { N_LIVE = 1 << 16 };
+static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+static void *live[N_LIVE];
+static long long c_stream_create, c_stream_destroy, c_malloc, c_free, c_bad_free, c_launch, c_host_malloc, c_host_free, c_event_create, c_event_destroy;
+static __thread hipError_t last_error;
+
+static void track(void *p) { pthread_mutex_lock(&mu); for (int i = 0; i < N_LIVE; i++) if (!live[i]) { live[i] = p; break; } pthread_mutex_unlock(&mu); }
+static int untrack(void *p) { int ok = 0; pthread_mutex_lock(&mu); for (int i = 0; i < N_LIVE; i++) if (live[i] == p) { live[i] = 0; ok = 1; break; } pthread_mutex_unlock(&mu); return ok; }
+static long long n_live(void) { long long n = 0; pthread_mutex_lock(&mu); for (int i = 0; i < N_LIVE; i++) n += live[i] != 0; pthread_mutex_unlock(&mu); return n; }
+
+void mock_hip_counts(long long *out /* [10]: streams created, destroyed, device mallocs, frees, bad frees, live allocations (device + host), launches, host mallocs, events created, events destroyed */) {
+    out[0] = c_stream_create; out[1] = c_stream_destroy; out[2] = c_malloc; out[3] = c_free; out[4] = c_bad_free; out[5] = n_live(); out[6] = c_launch; out[7] = c_host_malloc;
+    out[8] = c_event_create; out[9] = c_event_destroy;
+}
+
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+hipError_t hipSetDevice(int d) { return d == 0 ? 0 : 101; }
+hipError_t hipDeviceSynchronize(void) { return 0; }
+const char *hipGetErrorString(hipError_t e) { (void)e; return "mock HIP error"; }
+hipError_t hipGetLastError(void) { hipError_t e = last_error; last_error = 0; return e; }
+
+hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); if (!*p) return 2; track(*p); __sync_fetch_and_add(&c_malloc, 1); return 0; }
+hipError_t hipFree(void *p) { if (!p) return 0; if (!untrack(p)) { __sync_fetch_and_add(&c_bad_free, 1); return 1; } free(p); __sync_fetch_and_add(&c_free, 1); return 0; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags) { (void)flags; *p = calloc(1, n ? n : 1); if (!*p) return 2; track(*p); __sync_fetch_and_add(&c_host_malloc, 1); return 0; }
+hipError_t hipHostFree(void *p) { if (!p) return 0; if (!untrack(p)) { __sync_fetch_and_add(&c_bad_free, 1); return 1; } free(p); __sync_fetch_and_add(&c_host_free, 1); return 0; }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned flags) { (void)flags; *d = h; return 0; }
+hipError_t hipMemcpy(void *dst, const void *src, size_t n, int kind) { (void)kind; if (n) memmove(dst, src, n); return 0; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, int kind, void *st) { (void)kind; (void)st; if (n) memmove(dst, src, n); return 0; }
+hipError_t hipMemsetAsync(void *dst, int v, size_t n, void *st) { (void)st; if (n) memset(dst, v, n); return 0; }
+
+hipError_t hipStreamCreateWithFlags(void **s, unsigned flags) { (void)flags; *s = malloc(8); __sync_fetch_and_add(&c_stream_create, 1); return 0; }
+hipError_t hipStreamDestroy(void *s) { free(s); __sync_fetch_and_add(&c_stream_destroy, 1); return 0; }
+hipError_t hipStreamSynchronize(void *s) { (void)s; return 0; }
+hipError_t hipStreamWaitEvent(void *s, void *e, unsigned flags) { (void)s; (void)e; (void)flags; return 0; }
+hipError_t hipEventCreate(void **e) { *e = malloc(8); __sync_fetch_and_add(&c_event_create, 1); return 0; }
+hipError_t hipEventCreateWithFlags(void **e, unsigned flags) { (void)flags; return hipEventCreate(e); }
+hipError_t hipEventDestroy(void *e) { free(e); __sync_fetch_and_add(&c_event_destroy, 1); return 0; }
+hipError_t hipEventRecord(void *e, void *s) { (void)e; (void)s; return 0; }
+hipError_t hipEventSynchronize(void *e) { (void)e; return 0; }
+hipError_t hipEventElapsedTime(float *ms, void *a, void *b) { (void)a; (void)b; *ms = 0.01f; return 0; }
+
+/* no capture, no graphs: the library runs its launches plainly when a capture cannot be begun */
+hipError_t hipStreamBeginCapture(void *s, int mode) { (void)s; (void)mode; return 801; }
+hipError_t hipStreamEndCapture(void *s, void **g) { (void)s; *g = 0; return 801; }
+hipError_t hipGraphInstantiate(void **exec, void *g, void *a, void *b, size_t c) { (void)g; (void)a; (void)b; (void)c; *exec = 0; return 801; }
+hipError_t hipGraphLaunch(void *exec, void *s) { (void)exec; (void)s; return 801; }
+hipError_t hipGraphDestroy(void *g) { (void)g; return 0; }
+hipError_t hipGraphExecDestroy(void *e) { (void)e; return 0; }
+
+/* kernels are registered and "launched", never run */
+void **__hipRegisterFatBinary(const void *data) { static void *handle; (void)data; return &handle; }
+void __hipRegisterFunction(void **modules, const void *host_fn, char *dev_fn, const char *dev_name, unsigned tl, void *tid, void *bid, void *bdim, void *gdim, int *ws) {
+    (void)modules; (void)host_fn; (void)dev_fn; (void)dev_name; (void)tl; (void)tid; (void)bid; (void)bdim; (void)gdim; (void)ws;
+}
+void __hipUnregisterFatBinary(void **modules) { (void)modules; }
+static __thread struct { dim3_t grid, block; size_t shmem; void *stream; } cfg;
+hipError_t __hipPushCallConfiguration(dim3_t grid, dim3_t block, size_t shmem, void *stream) { cfg.grid = grid; cfg.block = block; cfg.shmem = shmem; cfg.stream = stream; return 0; }
+hipError_t __hipPopCallConfiguration(dim3_t *grid, dim3_t *block, size_t *shmem, void **stream) { *grid = cfg.grid; *block = cfg.block; *shmem = cfg.shmem; *stream = cfg.stream; return 0; }
+hipError_t hipLaunchKernel(const void *fn, dim3_t grid, dim3_t block, void **args, size_t shmem, void *stream) {
+    (void)fn; (void)grid; (void)block; (void)args; (void)shmem; (void)stream;
+    __sync_fetch_and_add(&c_launch, 1);
+    return 0;
+}
