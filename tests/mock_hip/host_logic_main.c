@@ -5,10 +5,12 @@
  *     shared, both scan (ffh_discover returns; with kernels that do not run every guide has zero hits), the owner loads again afterwards;
  *   * ffh_pipe_*: three lanes, sixty batches, out-of-order collection, teardown with batches queued;
  *   * ffh_discover_sharded over the copy transport with 2 and 5 shards, both forms of the exchange (all-gather / by guide slices);
+ *   * ffh_db_write + ffh_db_open through the three loaders (device inflate, host-thread inflate, the threaded page-locked pipeline);
  *   * at the end: no device or page-locked allocation left, no free of anything that was not allocated.
  * Run by tests/test_library_cpu.py with FFH_NO_SPIN=1 (the polled wait would wait for a kernel that never runs). */
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/flashfry_hip.h"
@@ -86,9 +88,37 @@ int main(void) {
         ffh_comm_destroy(comm);
         for (int i = 0; i < world; ++i) ffh_destroy(sh[i]);
     }
+    /* ---- the database file path: ffh_db_write (host only: real BGZF + header), then ffh_db_open through every loader -- device inflate (the
+     * members' bytes copied as they are), host-thread inflate (zlib + CRC-32 on the loader threads), the threaded page-locked pipeline with its
+     * pooled streams.  The decode kernels do not run, so the database that comes up is empty; every host thread, buffer and stream is real. ---- */
+    {
+        enum { T = 60000 };
+        static uint64_t t[T], p[T];
+        uint64_t x = 12345;
+        for (int i = 0; i < T; ++i) { x += 1 + (x * 2654435761u) % 17000000ull; t[i] = (((x & 0xFFFFFFFFFFull) << 6) | 0x2A) | (1ull << 48); p[i] = (23ull << 52) | (1ull << 32) | (uint64_t)i; }
+        const char *contigs[] = {"c1", "c2"};
+        const char *path = getenv("FFH_MOCK_DB") ? getenv("FFH_MOCK_DB") : "/tmp/ffh_mock_db";
+        EXPECT(ffh_db_write(path, 3, 7, contigs, 2, t, T, p, T) == FFH_OK, "ffh_db_write");
+        const char *modes[][2] = {{"FFH_INFLATE", "device"}, {"FFH_INFLATE", "host"}, {"FFH_LOAD_PIPELINE", "1"}};
+        for (int m = 0; m < 3; ++m) {
+            setenv(modes[m][0], modes[m][1], 1);
+            ffh_ctx *ctx = ffh_create(0, 0);
+            EXPECT(ctx && ffh_db_open(ctx, path, 0, 0) == FFH_OK, "ffh_db_open");
+            EXPECT(ctx && ffh_db_open(ctx, path, 100, 9000) == FFH_OK, "ffh_db_open of a bin range");
+            ffh_db_info info;
+            EXPECT(ctx && ffh_db_info_get(ctx, &info) == FFH_OK && info.enzyme_index == 3 && info.n_bins == 16384, "the header's enzyme and bins");
+            EXPECT(ctx && ffh_db_contig(ctx, 2) && !strcmp(ffh_db_contig(ctx, 2), "c2"), "the contig table");
+            ffh_destroy(ctx);
+            unsetenv(modes[m][0]);
+        }
+        EXPECT(ffh_db_open(NULL, path, 0, 0) != FFH_OK, "null context");
+        ffh_ctx *ctx = ffh_create(0, 0);
+        EXPECT(ffh_db_open(ctx, "/nonexistent/db", 0, 0) == FFH_E_IO, "a missing file is an I/O error");
+        ffh_destroy(ctx);
+    }
     mock_hip_counts(c);
     EXPECT(c[1] == 0, "no stream destroyed, ever");
-    EXPECT(c[0] <= 10, "streams: the pool's handful (two per context alive at once at most)");
+    EXPECT(c[0] <= 40, "streams: the pool's handful (two per context alive at once + the loader's lanes)");
     EXPECT(c[5] == 0, "no device or page-locked allocation left behind");
     EXPECT(c[4] == 0, "nothing freed that was not allocated (no alias freed)");
     EXPECT(c[8] == c[9], "every event destroyed");

@@ -186,7 +186,7 @@ def test_host_logic_over_the_mock_runtime(tmp_path):
     """round 6: the library's host logic end to end on a box without a GPU, over tests/mock_hip (an LD_PRELOAD stand-in of the 35 HIP entry
     points the library imports: device memory is host memory, kernels are counted and never run).  Contexts created and destroyed -- two
     streams created, NONE destroyed (csrc/ffh_streams.hpp) --, ffh_ctx_share_db (aliases never freed, the owner frozen while shared),
-    ffh_pipe_* (three lanes, sixty batches), ffh_discover_sharded over the copy transport in both forms of the exchange; at the end no
+    ffh_pipe_* (three lanes, sixty batches), ffh_discover_sharded over the copy transport in both forms of the exchange, ffh_db_write + ffh_db_open through the three loaders; at the end no
     allocation left and nothing freed that was not allocated.  tools/r06_host_asan_mock.sh runs the same with the host side under ASan."""
     from flashfry_amd import _build
     mock = os.path.join(ROOT, "tests", "mock_hip")
@@ -194,7 +194,7 @@ def test_host_logic_over_the_mock_runtime(tmp_path):
     subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(mock, "mock_hip.c"), "-lpthread"])
     subprocess.check_call(["gcc", "-O1", "-g", "-Wall", "-o", exe, os.path.join(mock, "host_logic_main.c"), "-L" + _build.LIB_DIR, "-lflashfry_hip", "-L" + str(tmp_path), "-lmock_hip",
                            "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath," + str(tmp_path)])
-    env = dict(os.environ, FFH_NO_SPIN="1", LD_PRELOAD=so)
+    env = dict(os.environ, FFH_NO_SPIN="1", LD_PRELOAD=so, FFH_MOCK_DB=str(tmp_path / "db"))
     env.pop("FFH_STREAM_DESTROY", None)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "as specified" in r.stdout and "destroyed 0," in r.stdout, (r.stdout + r.stderr)[-3000:]

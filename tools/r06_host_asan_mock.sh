@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the library's HOST side under AddressSanitizer on a box WITHOUT a GPU -- over tests/mock_hip/libmock_hip.so (device memory = host
 # memory, kernels counted and never run): tests/mock_hip/host_logic_main.c = contexts and the stream pool, ffh_ctx_share_db, ffh_pipe_*, the
-# sharded discover over the copy transport in both forms of the exchange.  (VERDICT r5 item 1a asked for the host side under ASan in the
+# sharded discover over the copy transport in both forms of the exchange, ffh_db_write + ffh_db_open through the three loaders (the inflate workers).  (VERDICT r5 item 1a asked for the host side under ASan in the
 # in-process sweep; with the GPU pool closed this is the part of it a CPU can do: every host path of round 6's additions, no kernel.)
 # usage: tools/r06_host_asan_mock.sh [out file]
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
