@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: the library's HOST side under AddressSanitizer on a box WITHOUT a GPU -- over tests/mock_hip/libmock_hip.so (device memory = host
+# round 6: the library's HOST side under AddressSanitizer and under ThreadSanitizer on a box WITHOUT a GPU -- over tests/mock_hip/libmock_hip.so (device memory = host
 # memory, kernels counted and never run): tests/mock_hip/host_logic_main.c = contexts and the stream pool, ffh_ctx_share_db, ffh_pipe_*, the
 # sharded discover over the copy transport in both forms of the exchange, ffh_db_write + ffh_db_open through the three loaders (the inflate workers).  (VERDICT r5 item 1a asked for the host side under ASan in the
 # in-process sweep; with the GPU pool closed this is the part of it a CPU can do: every host path of round 6's additions, no kernel.)
@@ -15,10 +15,19 @@ T=$(mktemp -d)
 gcc -O1 -g -Wall -o $T/plain tests/mock_hip/host_logic_main.c -Lflashfry_amd/lib -lflashfry_hip -Ltests/mock_hip -lmock_hip -Wl,-rpath,$R/flashfry_amd/lib -Wl,-rpath,$R/tests/mock_hip || exit 1
 gcc -O1 -g -Wall -o $T/asan tests/mock_hip/host_logic_main.c -Lflashfry_amd/lib/asan -lflashfry_hip -Ltests/mock_hip -lmock_hip -L$RTD -l:libclang_rt.asan-x86_64.so \
     -Wl,-rpath,$R/flashfry_amd/lib/asan -Wl,-rpath,$R/tests/mock_hip -Wl,-rpath,$RTD || exit 1
+# ... and under ThreadSanitizer (the pipe's lanes, the shards' scan threads of ffh_discover_sharded, the loader's and the writer's workers)
+TSD=$(dirname $(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1))
+mkdir -p flashfry_amd/lib/tsan
+(cd flashfry_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=thread -fno-gpu-sanitize -fno-omit-frame-pointer \
+   -I/opt/rocm/include -o ../lib/tsan/libflashfry_hip.so ffh_api.hip ffh_dbfile.cpp ffh_dbwrite.cpp -lz -lpthread -ldl) || exit 1
+/opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=thread -shared-libsan -o $T/tsan tests/mock_hip/host_logic_main.c -Lflashfry_amd/lib/tsan -lflashfry_hip -Ltests/mock_hip -lmock_hip \
+    -Wl,-rpath,$R/flashfry_amd/lib/tsan -Wl,-rpath,$R/tests/mock_hip -Wl,-rpath,$TSD || exit 1
+TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" FFH_NO_SPIN=1 LD_PRELOAD=$TSD/libclang_rt.tsan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 900 $T/tsan > $T/tsan.log 2>&1
 {
   echo "# tools/r06_host_asan_mock.sh: tests/mock_hip/host_logic_main.c over the mock runtime (no GPU)"
   echo "plain build:                 $(FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -3 | tr '\n' ' ')"
   echo "host side under ASan:        $(ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 FFH_NO_SPIN=1 LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 600 $T/asan 2>&1 | tail -3 | tr '\n' ' ')"
+  echo "host side under TSan:        $(tail -1 $T/tsan.log); ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $T/tsan.log)"
   echo "FFH_STREAM_DESTROY=1 (A side): $(FFH_STREAM_DESTROY=1 FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -4 | tr '\n' ' ')"
 } | tee $OUT
 rm -rf $T
