@@ -196,7 +196,8 @@ def test_host_logic_over_the_mock_runtime(tmp_path):
                            "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath," + str(tmp_path)])
     env = dict(os.environ, FFH_NO_SPIN="1", LD_PRELOAD=so, FFH_MOCK_DB=str(tmp_path / "db"))
     env.pop("FFH_STREAM_DESTROY", None)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "as specified" in r.stdout and "destroyed 0," in r.stdout, (r.stdout + r.stderr)[-3000:]
+    for spin in ("1", "0"):   # hipStreamSynchronize, then the library's default: the polled wait (the mock performs k_publish, the kernel behind it)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, FFH_NO_SPIN=spin))
+        assert r.returncode == 0 and "as specified" in r.stdout and "destroyed 0," in r.stdout, (spin, (r.stdout + r.stderr)[-3000:])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, FFH_STREAM_DESTROY="1"))   # the A side: rounds 1-5 destroyed their streams
     assert r.returncode == 1 and "none destroyed" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -22,11 +22,11 @@ mkdir -p flashfry_amd/lib/tsan
    -I/opt/rocm/include -o ../lib/tsan/libflashfry_hip.so ffh_api.hip ffh_dbfile.cpp ffh_dbwrite.cpp -lz -lpthread -ldl) || exit 1
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=thread -shared-libsan -o $T/tsan tests/mock_hip/host_logic_main.c -Lflashfry_amd/lib/tsan -lflashfry_hip -Ltests/mock_hip -lmock_hip \
     -Wl,-rpath,$R/flashfry_amd/lib/tsan -Wl,-rpath,$R/tests/mock_hip -Wl,-rpath,$TSD || exit 1
-TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" FFH_NO_SPIN=1 LD_PRELOAD=$TSD/libclang_rt.tsan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 900 $T/tsan > $T/tsan.log 2>&1
+TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" LD_PRELOAD=$TSD/libclang_rt.tsan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 900 $T/tsan > $T/tsan.log 2>&1
 {
   echo "# tools/r06_host_asan_mock.sh: tests/mock_hip/host_logic_main.c over the mock runtime (no GPU)"
-  echo "plain build:                 $(FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -3 | tr '\n' ' ')"
-  echo "host side under ASan:        $(ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 FFH_NO_SPIN=1 LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 600 $T/asan 2>&1 | tail -3 | tr '\n' ' ')"
+  echo "plain build:                 $(LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -3 | tr '\n' ' ')"
+  echo "host side under ASan:        $(ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 600 $T/asan 2>&1 | tail -3 | tr '\n' ' ')"
   echo "host side under TSan:        $(tail -1 $T/tsan.log); ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $T/tsan.log)"
   echo "FFH_STREAM_DESTROY=1 (A side): $(FFH_STREAM_DESTROY=1 FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -4 | tr '\n' ' ')"
 } | tee $OUT
