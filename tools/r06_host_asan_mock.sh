@@ -23,11 +23,29 @@ mkdir -p flashfry_amd/lib/tsan
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=thread -shared-libsan -o $T/tsan tests/mock_hip/host_logic_main.c -Lflashfry_amd/lib/tsan -lflashfry_hip -Ltests/mock_hip -lmock_hip \
     -Wl,-rpath,$R/flashfry_amd/lib/tsan -Wl,-rpath,$R/tests/mock_hip -Wl,-rpath,$TSD || exit 1
 TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" LD_PRELOAD=$TSD/libclang_rt.tsan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 900 $T/tsan > $T/tsan.log 2>&1
+# ... and the drop-in CLI's three subcommands, host layer + library host side under ASan, over the mock runtime (no site is found, no hit: the kernels
+# do not run; every line of option handling, FASTA reading, header / BGZF writing and reading, table writing and re-reading does)
+/opt/rocm/lib/llvm/bin/clang++ -O1 -g -fsanitize=address -shared-libasan -std=c++17 -ffp-contract=off -o $T/cli flashfry_amd/host/ffhost_core.cpp flashfry_amd/host/ffhost_table.cpp \
+    flashfry_amd/host/ffhost_index.cpp flashfry_amd/host/ffhost_cli.cpp -Lflashfry_amd/lib/asan -lflashfry_hip -Wl,-rpath,$R/flashfry_amd/lib/asan -Wl,-rpath,$RTD -lz -lpthread || exit 1
+python3 - $T <<'PY'
+import sys, numpy as np
+rng = np.random.default_rng(3)
+seq = "".join(rng.choice(list("ACGT"), size=300000))
+open(sys.argv[1] + "/genome.fa", "w").write(">chrA some description\n" + "\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + "\n>chrB\n" + seq[:5000] + "\n")
+open(sys.argv[1] + "/guides.fa", "w").write(">g1\nGAGTCCGAGCAGAAGAAGAAGGG\n>g2\n" + seq[1000:1023] + "\n")
+PY
+cli() { ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 120 $T/cli "$@" > $T/cli.log 2>&1; echo "rc $? $(grep -c AddressSanitizer $T/cli.log) ASan reports; $(tail -1 $T/cli.log)"; }
+CLI_INDEX=$(cli index --reference $T/genome.fa --database $T/db --enzyme spcas9ngg --tmpLocation $T)
+CLI_DISCOVER=$(cli discover --fasta $T/guides.fa --database $T/db --output $T/out.txt --positionOutput)
+CLI_SCORE=$(cli score --input $T/out.txt --output $T/scored.txt --scoringMetrics doench2016cfd,hsu2013,minot,dangerous --database $T/db)
 {
   echo "# tools/r06_host_asan_mock.sh: tests/mock_hip/host_logic_main.c over the mock runtime (no GPU)"
   echo "plain build:                 $(LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -3 | tr '\n' ' ')"
   echo "host side under ASan:        $(ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so timeout 600 $T/asan 2>&1 | tail -3 | tr '\n' ' ')"
   echo "host side under TSan:        $(tail -1 $T/tsan.log); ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $T/tsan.log)"
+  echo "CLI under ASan, index:       $CLI_INDEX"
+  echo "CLI under ASan, discover:    $CLI_DISCOVER"
+  echo "CLI under ASan, score:       $CLI_SCORE"
   echo "FFH_STREAM_DESTROY=1 (A side): $(FFH_STREAM_DESTROY=1 FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -4 | tr '\n' ' ')"
 } | tee $OUT
 rm -rf $T
