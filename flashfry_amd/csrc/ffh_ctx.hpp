@@ -7,16 +7,19 @@ namespace ffh {
 void set_global_error(const std::string &m) { g_create_error = m; }
 }  // namespace ffh
 
+// (on failure the stream is waited for before the function returns: an asynchronous copy issued a line earlier into one of the function's locals
+// must not land in a dead stack frame -- profiles/r06/uaf_analysis.md, appendix.  Inside a stream capture the wait is refused by the runtime
+// and costs nothing.)
 #define FFH_HIP(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) {                                                                         \
             ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+            if (ctx->st) { (void)hipStreamSynchronize(ctx->st); (void)hipGetLastError(); }              \
             return FFH_E_HIP;                                                                           \
         }                                                                                               \
     } while (0)
 
-#include "ffh_devbuf.hpp"   // DevBuf<T>: the device allocation every buffer of a context is (owned, or an alias of another context's)
 namespace {
 
 struct Image {  // one bucketed scan image of the database
