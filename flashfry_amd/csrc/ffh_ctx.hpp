@@ -20,6 +20,7 @@ void set_global_error(const std::string &m) { g_create_error = m; }
         }                                                                                               \
     } while (0)
 
+#include "ffh_devbuf.hpp"   // DevBuf<T>: the device allocation every buffer of a context is (owned, or an alias of another context's)
 namespace {
 
 struct Image {  // one bucketed scan image of the database
