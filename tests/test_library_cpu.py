@@ -201,3 +201,29 @@ def test_host_logic_over_the_mock_runtime(tmp_path):
         assert r.returncode == 0 and "as specified" in r.stdout and "destroyed 0," in r.stdout, (spin, (r.stdout + r.stderr)[-3000:])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, FFH_STREAM_DESTROY="1"))   # the A side: rounds 1-5 destroyed their streams
     assert r.returncode == 1 and "none destroyed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_fault_injection_over_the_mock_runtime(tmp_path):
+    """round 6: one scenario through the library's host logic (context, discover with lists and aggregates, shared database, pipe, two-shard
+    communicator in both exchange forms, database file) with the n-th HIP call failing, n walked over the whole scenario (every second
+    call here; tools/r06_host_asan_mock.sh walks every call with the host side under ASan): whatever fails, the library returns an error
+    code, and after everything that exists has been destroyed no allocation is left and nothing was freed twice.  Found on its first run:
+    finalize_lists returned from a failed FFH_HIP with the result it had just created still alive -- and with it the context's pool of
+    page-locked blocks (csrc/ffh_finalize.inc: Guard)."""
+    from flashfry_amd import _build
+    mock = os.path.join(ROOT, "tests", "mock_hip")
+    so, exe = str(tmp_path / "libmock_hip.so"), str(tmp_path / "fault")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(mock, "mock_hip.c"), "-lpthread", "-ldl"])
+    subprocess.check_call(["gcc", "-O1", "-g", "-Wall", "-o", exe, os.path.join(mock, "fault_main.c"), "-L" + _build.LIB_DIR, "-lflashfry_hip", "-L" + str(tmp_path), "-lmock_hip",
+                           "-Wl,-rpath," + _build.LIB_DIR, "-Wl,-rpath," + str(tmp_path)])
+    env = dict(os.environ, LD_PRELOAD=so, FFH_MOCK_DB=str(tmp_path / "db"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env, MOCK_HIP_FAIL_AT="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    n_calls = int(r.stdout.split()[1])
+    assert n_calls > 500 and " errors 0 " in r.stdout, r.stdout
+    failed_somewhere = 0
+    for n in range(1, n_calls + 8, 2):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env, MOCK_HIP_FAIL_AT=str(n)))
+        assert r.returncode == 0 and " live 0 bad_frees 0 " in r.stdout, (n, (r.stdout + r.stderr)[-2000:])
+        failed_somewhere += " errors 0 " not in r.stdout
+    assert failed_somewhere > n_calls // 4   # (the faults really reach the library: most injection points make a call fail)

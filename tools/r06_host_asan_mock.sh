@@ -38,6 +38,17 @@ cli() { ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:
 CLI_INDEX=$(cli index --reference $T/genome.fa --database $T/db --enzyme spcas9ngg --tmpLocation $T)
 CLI_DISCOVER=$(cli discover --fasta $T/guides.fa --database $T/db --output $T/out.txt --positionOutput)
 CLI_SCORE=$(cli score --input $T/out.txt --output $T/scored.txt --scoringMetrics doench2016cfd,hsu2013,minot,dangerous --database $T/db)
+# ... and fault injection: tests/mock_hip/fault_main.c with the n-th HIP call failing, n over the whole scenario, host side under ASan
+gcc -O1 -g -Wall -o $T/fault tests/mock_hip/fault_main.c -Lflashfry_amd/lib/asan -lflashfry_hip -Ltests/mock_hip -lmock_hip -L$RTD -l:libclang_rt.asan-x86_64.so \
+    -Wl,-rpath,$R/flashfry_amd/lib/asan -Wl,-rpath,$R/tests/mock_hip -Wl,-rpath,$RTD || exit 1
+FENV="ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0:verify_asan_link_order=0 FFH_MOCK_DB=$T/fdb LD_PRELOAD=$RTD/libclang_rt.asan-x86_64.so:$R/tests/mock_hip/libmock_hip.so"
+NCALLS=$(env $FENV MOCK_HIP_FAIL_AT=0 $T/fault | awk '{print $2}')
+FBAD=0; FERR=0
+for n in $(seq 1 $((NCALLS + 8))); do
+  o=$(env $FENV MOCK_HIP_FAIL_AT=$n timeout 60 $T/fault 2>&1); rc=$?
+  if [ $rc != 0 ] || echo "$o" | grep -q AddressSanitizer; then FBAD=$((FBAD + 1)); echo "fault n=$n rc=$rc: $(echo "$o" | tail -2 | tr '\n' ' ')" >> $T/fault_bad.txt; fi
+  echo "$o" | grep -q " errors 0 " || FERR=$((FERR + 1))
+done
 {
   echo "# tools/r06_host_asan_mock.sh: tests/mock_hip/host_logic_main.c over the mock runtime (no GPU)"
   echo "plain build:                 $(LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -3 | tr '\n' ' ')"
@@ -46,6 +57,8 @@ CLI_SCORE=$(cli score --input $T/out.txt --output $T/scored.txt --scoringMetrics
   echo "CLI under ASan, index:       $CLI_INDEX"
   echo "CLI under ASan, discover:    $CLI_DISCOVER"
   echo "CLI under ASan, score:       $CLI_SCORE"
+  echo "fault injection under ASan:  $NCALLS HIP calls in the scenario, each made to fail in turn: $FERR runs in which a library call then returned an error, $FBAD runs that left an allocation, freed twice, crashed or tripped ASan"
+  [ -f $T/fault_bad.txt ] && head -20 $T/fault_bad.txt
   echo "FFH_STREAM_DESTROY=1 (A side): $(FFH_STREAM_DESTROY=1 FFH_NO_SPIN=1 LD_PRELOAD=$R/tests/mock_hip/libmock_hip.so timeout 300 $T/plain 2>&1 | tail -4 | tr '\n' ' ')"
 } | tee $OUT
 rm -rf $T
