@@ -65,6 +65,51 @@ int main(void) {
         const char *path = getenv("FFH_MOCK_DB") ? getenv("FFH_MOCK_DB") : "/tmp/ffh_mock_fault_db";
         if (ffh_db_write(path, 3, 7, contigs, 1, t, T, p, T) == FFH_OK && ctx) { STEP(ffh_db_open(ctx, path, 0, 0)); }
     }
+    /* ---- the rest of the ABI's entry points that allocate or copy: score, bulge search, shard totals, the two-step shard epilogue, the indexer ---- */
+    if (ctx) {
+        ffh_result *r = NULL;
+        uint64_t offs[4] = {0, 2, 2, 5}, tg[5];
+        for (int i = 0; i < 5; ++i) tg[i] = guides[i] ^ (3ull << (6 + 2 * i));
+        STEP(ffh_score_lists(ctx, guides, 3, offs, tg, &r)); ffh_result_free(r); r = NULL;
+        STEP(ffh_db_load_soa(ctx, NULL, 0, NULL, 0, 0));
+        ffh_ctx *cpf1 = ffh_create(0, 1);   /* (the bulge search is Cas12a's) */
+        if (cpf1) {
+            ffh_bulge_result *br = NULL;
+            STEP(ffh_db_load_soa(cpf1, NULL, 0, NULL, 0, 0));
+            STEP(ffh_discover_bulge(cpf1, guides, 16, 3, 1, 0, &br)); ffh_bulge_result_free(br); br = NULL;
+            STEP(ffh_discover_bulge(cpf1, guides, 16, 2, 1, FFH_BULGE_PAM_TTTV | FFH_BULGE_BRUTE_FORCE, &br)); ffh_bulge_result_free(br);
+            ffh_destroy(cpf1);
+        } else ++errors;
+        STEP(ffh_scan_bounded(ctx, guides, 24, 4, 40));
+        uint32_t totals[24];
+        STEP(ffh_shard_totals(ctx, totals, 40));
+        void *dsum = ffh_host_alloc(24 * sizeof(struct ffh_guide_summary)), *dtot = ffh_host_alloc(24 * 4);   /* (the mock's device memory is host memory) */
+        if (dsum && dtot) {
+            STEP(ffh_finalize_shard(ctx, 40, 0, dsum, (uint32_t *)dtot));
+            STEP(ffh_exchange_prior(ctx, (const uint32_t *)dtot, 24, 0, 40, (uint32_t *)dtot));
+            STEP(ffh_finalize_shard_fixup(ctx, 40, 0, (const uint32_t *)dtot, (const uint32_t *)dtot, dsum));
+            STEP(ffh_summaries_to_device(ctx, dsum));
+        }
+        ffh_host_free(dsum); ffh_host_free(dtot);
+        int64_t blocks[3] = {1, 1, 1};     /* three empty linear blocks (BlockManager.scala:431) */
+        uint64_t boffs[4] = {0, 1, 2, 3};
+        STEP(ffh_db_load_blocks(ctx, blocks, boffs, 3));
+    }
+    {
+        ffh_indexer *ix = ffh_indexer_create(0, 3);
+        if (ix) {
+            static char seq[20000];
+            for (int i = 0; i < 20000; ++i) seq[i] = "ACGT"[(i * 7 + i / 3) & 3];
+            STEP(ffh_indexer_add_contig(ix, "chrA", seq, sizeof seq));
+            STEP(ffh_indexer_add_contig(ix, "chrB", seq, 5000));
+            const char *path = getenv("FFH_MOCK_DB") ? getenv("FFH_MOCK_DB") : "/tmp/ffh_mock_fault_db";
+            char ipath[600];
+            snprintf(ipath, sizeof ipath, "%s.indexed", path);
+            ffh_index_stats ist;
+            STEP(ffh_indexer_finish(ix, ipath, 7, &ist));
+            ffh_indexer_destroy(ix);
+        } else ++errors;
+    }
     ffh_destroy(ctx);
     long long c[10];
     mock_hip_counts(c);
