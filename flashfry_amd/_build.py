@@ -10,7 +10,7 @@ LIB = os.path.join(LIB_DIR, "libflashfry_hip.so")
 
 HIP_SOURCES = ["ffh_api.hip"]
 CXX_SOURCES = ["ffh_dbfile.cpp", "ffh_dbwrite.cpp"]
-DEPS = ["ffh_api.hip", "ffh_ctx.hpp", "ffh_devbuf.hpp", "ffh_plan.inc", "ffh_context.inc", "ffh_load.inc", "ffh_scan.inc", "ffh_finalize.inc", "ffh_pipe.inc", "ffh_share.inc", "ffh_index_api.inc", "ffh_bulge_api.inc", "ffh_exchange.inc", "ffh_debug.hpp", "ffh_streams.hpp", "ffh_kernels.hpp", "ffh_compare.hpp", "ffh_prims.hpp", "ffh_dbfile.cpp", "ffh_dbfile.hpp", "ffh_dbwrite.cpp", "ffh_ingest.hpp", "ffh_index.hpp", "ffh_inflate.hpp", "ffh_bulge.hpp", "ffh_comm.hpp", "ffh_exchange_kernels.hpp", "cfd_table.inc", "jost_table.inc",
+DEPS = ["ffh_api.hip", "ffh_ctx.hpp", "ffh_devbuf.hpp", "ffh_abi_guard.hpp", "ffh_plan.inc", "ffh_context.inc", "ffh_load.inc", "ffh_scan.inc", "ffh_finalize.inc", "ffh_pipe.inc", "ffh_share.inc", "ffh_index_api.inc", "ffh_bulge_api.inc", "ffh_exchange.inc", "ffh_debug.hpp", "ffh_streams.hpp", "ffh_kernels.hpp", "ffh_compare.hpp", "ffh_prims.hpp", "ffh_dbfile.cpp", "ffh_dbfile.hpp", "ffh_dbwrite.cpp", "ffh_ingest.hpp", "ffh_index.hpp", "ffh_inflate.hpp", "ffh_bulge.hpp", "ffh_comm.hpp", "ffh_exchange_kernels.hpp", "cfd_table.inc", "jost_table.inc",
         os.path.join("..", "..", "include", "flashfry_hip.h")]
 
 

@@ -207,6 +207,7 @@ int ffh_comm_unique_id(void *id128) {
 static ffh_comm *comm_new(ffh_ctx *const *ctxs, int n) {
     ffh_comm *cm = new (std::nothrow) ffh_comm();
     if (!cm) { g_create_error = "out of memory"; return nullptr; }
+    try {
     cm->ctx.assign(ctxs, ctxs + n);
     { const char *e = std::getenv("FFH_EXCHANGE"); if (e && std::strcmp(e, "slice") == 0) cm->exchange = FFH_EXCHANGE_SLICE; }
     for (int i = 0; i < n; ++i) {
@@ -218,6 +219,7 @@ static ffh_comm *comm_new(ffh_ctx *const *ctxs, int n) {
             return nullptr;
         }
     }
+    } catch (...) { ffh_comm_destroy(cm); ffh_note_exception(&g_create_error, "out of host memory creating a communicator"); return nullptr; }
     return cm;
 }
 
@@ -234,11 +236,12 @@ void ffh_comm_destroy(ffh_comm *cm) {
     delete cm;
 }
 
-int ffh_comm_create_local(ffh_ctx *const *ctxs, int n, ffh_comm **out) {
+int ffh_comm_create_local(ffh_ctx *const *ctxs, int n, ffh_comm **out) try {
     if (!ctxs || n < 1 || !out) return FFH_E_ARG;
     for (int i = 0; i < n; ++i) if (!ctxs[i]) return FFH_E_ARG;
     ffh_comm *cm = comm_new(ctxs, n);
     if (!cm) return FFH_E_NOMEM;
+    try {
     cm->world = n; cm->first = 0;
     bool distinct = n > 1;
     for (int i = 0; i < n; ++i)
@@ -254,16 +257,18 @@ int ffh_comm_create_local(ffh_ctx *const *ctxs, int n, ffh_comm **out) {
         if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitAll: ") + R->GetErrorString(r); cm->nccl.clear(); ffh_comm_destroy(cm); return FFH_E_HIP; }
         cm->mode = FFH_COMM_ALL;
     } else cm->mode = FFH_COMM_COPY;
+    } catch (...) { ffh_comm_destroy(cm); throw; }
     *out = cm;
     return FFH_OK;
-}
+} FFH_CATCH(&g_create_error)
 
-int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, ffh_comm **out) {
+int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, ffh_comm **out) try {
     if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !id128) return FFH_E_ARG;
     RcclApi *R = rccl_api();
     if (!R->lib) { g_create_error = R->err; return FFH_E_STATE; }
     ffh_comm *cm = comm_new(&ctx, 1);
     if (!cm) return FFH_E_NOMEM;
+    try {
     cm->world = world; cm->first = rank; cm->mode = FFH_COMM_RANK;
     ncclUniqueId id;
     std::memcpy(&id, id128, 128);
@@ -271,9 +276,10 @@ int ffh_comm_create_rank(ffh_ctx *ctx, int rank, int world, const void *id128, f
     (void)hipSetDevice(ctx->device);
     const ncclResult_t r = R->CommInitRank(&cm->nccl[0], world, id, rank);
     if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitRank: ") + R->GetErrorString(r); cm->nccl.clear(); ffh_comm_destroy(cm); return FFH_E_HIP; }
+    } catch (...) { ffh_comm_destroy(cm); throw; }
     *out = cm;
     return FFH_OK;
-}
+} FFH_CATCH(&g_create_error)
 
 void *ffh_host_alloc(size_t bytes) {
     void *p = nullptr;
@@ -462,14 +468,14 @@ static int discover_sharded_split(ffh_comm *cm, const uint64_t *guides, uint32_t
     if (!rc) cm->err.clear();   // (the "more than 2^32 raw hits" text of the attempt that was split is not this call's outcome)
     return rc;
 }
-int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
+int ffh_discover_sharded(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) try {
     if (!cm || (n_guides && !guides) || max_mismatch < 0 || max_offtargets < 0) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
     bool split = false;
     const int rc = discover_sharded_split(cm, guides, n_guides, max_mismatch, max_offtargets, flags, summaries_out, split);
     cm->was_split = !rc && split;
     if (cm->was_split) cm->exchanged = false;
     return rc;
-}
+} FFH_CATCH(cm ? &cm->err : nullptr)
 static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t n_guides, int max_mismatch, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
     const size_t L = cm->ctx.size();
     cm->exchanged = false;
@@ -497,7 +503,7 @@ static int discover_sharded_once(ffh_comm *cm, const uint64_t *guides, uint32_t 
 }
 
 // the exchange alone, for callers that scanned the shards themselves (ffh_scan / ffh_scan_bounded on every local context)
-int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) {
+int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsigned flags, ffh_guide_summary *summaries_out) try {
     if (!cm || max_offtargets < 0) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
     cm->exchanged = false; cm->was_split = false;
     const auto t1 = std::chrono::steady_clock::now();
@@ -506,16 +512,16 @@ int ffh_comm_exchange(ffh_comm *cm, uint32_t n_guides, int max_offtargets, unsig
     cm->n_guides = n_guides; cm->max_ot = max_offtargets; cm->exchanged = true;
     cm->exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     return FFH_OK;
-}
+} FFH_CATCH(cm ? &cm->err : nullptr)
 
-int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_result **out) {
+int ffh_comm_shard_lists(ffh_comm *cm, int local_shard, unsigned flags, ffh_result **out) try {
     if (!cm || !out || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) { if (cm) cm->err = "bad argument"; return FFH_E_ARG; }
     if (!cm->exchanged) { cm->err = cm->was_split ? kSplitMessage : "ffh_discover_sharded has not run"; return FFH_E_STATE; }
     ffh_ctx *ctx = cm->ctx[(size_t)local_shard];
     const int rc = ffh_finalize(ctx, cm->buf[(size_t)local_shard]->prior.p, cm->max_ot, (flags & ~FFH_FINALIZE_SUMMARIES_ONLY) | FFH_FINALIZE_PRIOR_ON_DEVICE, out);
     if (rc) { std::lock_guard<std::mutex> g(cm->err_m); cm->err = ctx->err; }
     return rc;
-}
+} FFH_CATCH(cm ? &cm->err : nullptr)
 
 int ffh_comm_device_summaries(ffh_comm *cm, int local_shard, const void **device_summaries) {
     if (!cm || !device_summaries || local_shard < 0 || (size_t)local_shard >= cm->ctx.size()) return FFH_E_ARG;

@@ -20,6 +20,7 @@ void set_global_error(const std::string &m) { g_create_error = m; }
         }                                                                                               \
     } while (0)
 
+#include "ffh_abi_guard.hpp"   // FFH_CATCH: no C++ exception crosses the C ABI
 #include "ffh_devbuf.hpp"   // DevBuf<T>: the device allocation every buffer of a context is (owned, or an alias of another context's)
 namespace {
 
@@ -103,7 +104,8 @@ struct PinnedPool {
         }
         std::lock_guard<std::mutex> g(m);
         if (free_blocks.size() >= 6) { check_poison(free_blocks.front()); (void)hipHostFree(free_blocks.front().first); free_blocks.erase(free_blocks.begin()); }
-        free_blocks.emplace_back(p, cap);
+        // (called from ~ffh_result: must not throw -- a block that cannot be listed is freed instead of pooled)
+        try { free_blocks.emplace_back(p, cap); } catch (...) { (void)hipHostFree(p); }
     }
     void check_poison(const std::pair<void *, size_t> &b) const {
         if (pool_debug() && !all_bytes(b.first, b.second, kPoison)) {

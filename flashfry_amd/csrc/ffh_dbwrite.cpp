@@ -44,18 +44,22 @@ unsigned worker_count(size_t units) {
 template <typename F>
 void parallel_units(size_t n, size_t grain, F fn) {  // fn(begin, end) over dynamic chunks of `grain` units
     std::atomic<size_t> next(0);
+    std::atomic<int> threw(0);   // (an exception inside a worker -- std::bad_alloc of a unit's scratch -- ends the process if it leaves the thread: it is carried to the caller)
     auto work = [&]() {
-        for (;;) {
-            const size_t a = next.fetch_add(grain);
-            if (a >= n) break;
-            fn(a, std::min(n, a + grain));
-        }
+        try {
+            for (;;) {
+                const size_t a = next.fetch_add(grain);
+                if (a >= n || threw) break;
+                fn(a, std::min(n, a + grain));
+            }
+        } catch (...) { threw = 1; }
     };
     const unsigned nt = worker_count((n + grain - 1) / grain);
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    try { for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work); } catch (...) { threw = 1; }   // (the threads that did start are joined below)
     work();
     for (auto &t : pool) t.join();
+    if (threw) throw std::bad_alloc();
 }
 
 std::string bin_name(int width, uint32_t idx) {  // utils/BaseCombinationGenerator.scala:33-69
@@ -72,7 +76,7 @@ int fail(const std::string &m, int code) {
 }  // namespace
 
 extern "C" int ffh_db_write(const char *db_path, int enzyme_index, int bin_width, const char *const *contigs, uint32_t n_contigs, const uint64_t *targets,
-                            uint64_t n_targets, const uint64_t *positions, uint64_t n_positions) {
+                            uint64_t n_targets, const uint64_t *positions, uint64_t n_positions) try {
     if (!db_path || (n_targets && !targets) || (n_positions && !positions) || (n_contigs && !contigs)) return fail("null argument", FFH_E_ARG);
     if (enzyme_index < 1 || enzyme_index > 6) return fail("Unable to find the correct parameter pack for enzyme: " + std::to_string(enzyme_index), FFH_E_ARG);
     if (bin_width < 1 || bin_width > 12) return fail("binSize must be within 1..12", FFH_E_ARG);
@@ -204,4 +208,6 @@ extern "C" int ffh_db_write(const char *db_path, int enzyme_index, int bin_width
     for (uint32_t c = 0; c < n_contigs; ++c) std::fprintf(h, "%s=%u\n", contigs[c], c + 1);
     if (std::fclose(h) != 0) return fail("short write", FFH_E_IO);
     return FFH_OK;
+} catch (...) {   // (no C++ exception crosses the C ABI: csrc/ffh_abi_guard.hpp; an open FILE is left to the process)
+    try { return fail("out of host memory writing the database", FFH_E_NOMEM); } catch (...) { return FFH_E_NOMEM; }
 }

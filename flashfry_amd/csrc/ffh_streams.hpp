@@ -44,7 +44,7 @@ struct StreamPool {
         (void)hipStreamSynchronize(s);
         if (destroy) { (void)hipStreamDestroy(s); return; }
         std::lock_guard<std::mutex> g(m);
-        idle[device].push_back(s);
+        try { idle[device].push_back(s); } catch (...) {}   // (called from ffh_destroy: must not throw; a stream that cannot be listed stays alive unlisted -- never destroyed)
     }
 };
 inline StreamPool &stream_pool() {

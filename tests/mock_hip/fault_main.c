@@ -13,11 +13,14 @@
 void mock_hip_counts(long long *out);
 long long mock_hip_calls(void);
 void mock_hip_dump(void);
+__attribute__((weak)) void mock_new_arm(long long n);        /* tests/mock_hip/mock_new.cpp, when it is preloaded too */
+__attribute__((weak)) long long mock_new_count(void);
 
 int main(void) {
     uint64_t guides[48];
     for (int i = 0; i < 48; ++i) guides[i] = (1ull << 48) | ((uint64_t)(i * 2654435761u) << 6) | 0x2A;
     int errors = 0, steps = 0;
+    if (mock_new_arm) mock_new_arm(getenv("MOCK_NEW_FAIL_AT") ? atoll(getenv("MOCK_NEW_FAIL_AT")) : 0);   /* the n-th operator new from here on throws */
 #define STEP(call) do { ++steps; const int rc_ = (call); if (rc_ != FFH_OK) { ++errors; if (getenv("MOCK_HIP_TRACE")) fprintf(stderr, "step %d failed (%d): %s\n", steps, rc_, #call); } } while (0)
     ffh_ctx *ctx = ffh_create(0, 3), *other = NULL, *sh[2] = {NULL, NULL};
     if (ctx) {
@@ -113,7 +116,7 @@ int main(void) {
     ffh_destroy(ctx);
     long long c[10];
     mock_hip_counts(c);
-    printf("calls %lld steps %d errors %d live %lld bad_frees %lld events %lld/%lld\n", mock_hip_calls(), steps, errors, c[5], c[4], c[8], c[9]);
+    printf("calls %lld steps %d errors %d live %lld bad_frees %lld events %lld/%lld news %lld\n", mock_hip_calls(), steps, errors, c[5], c[4], c[8], c[9], mock_new_count ? mock_new_count() : 0);
     if (c[5]) mock_hip_dump();
     return (c[5] == 0 && c[4] == 0 && c[8] == c[9]) ? 0 : 1;
 }

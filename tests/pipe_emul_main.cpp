@@ -41,6 +41,7 @@ static int ffh_discover(ffh_ctx *ctx, const uint64_t *g, uint32_t n, int mm, int
     return FFH_OK;
 }
 
+#include "../flashfry_amd/csrc/ffh_abi_guard.hpp"
 #include "../flashfry_amd/csrc/ffh_pipe.inc"
 
 int main() {

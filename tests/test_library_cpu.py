@@ -227,3 +227,17 @@ def test_fault_injection_over_the_mock_runtime(tmp_path):
         assert r.returncode == 0 and " live 0 bad_frees 0 " in r.stdout, (n, (r.stdout + r.stderr)[-2000:])
         failed_somewhere += " errors 0 " not in r.stdout
     assert failed_somewhere > n_calls // 4   # (the faults really reach the library: most injection points make a call fail)
+    # ... and with the n-th `operator new` of the scenario throwing std::bad_alloc (tests/mock_hip/mock_new.cpp): no C++ exception crosses the C ABI
+    # (csrc/ffh_abi_guard.hpp: FFH_CATCH) -- the process must not end in std::terminate, and again nothing may be left behind.  First run: 40 of
+    # 201 injection points ended the process (PinnedPool::put inside ~ffh_result, StreamPool::release inside ffh_destroy, the writer's worker
+    # threads, ffh_discover_bulge, half-built contexts / pipes / communicators).
+    new_so = str(tmp_path / "libmock_new.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-o", new_so, os.path.join(mock, "mock_new.cpp")])
+    env2 = dict(env, LD_PRELOAD=new_so + ":" + so)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env2, MOCK_NEW_FAIL_AT="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    n_news = int(r.stdout.split()[-1])
+    assert n_news > 100, r.stdout
+    for n in range(1, n_news + 8):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env2, MOCK_NEW_FAIL_AT=str(n)))
+        assert r.returncode == 0 and " live 0 bad_frees 0 " in r.stdout, (n, (r.stdout + r.stderr)[-2500:])
