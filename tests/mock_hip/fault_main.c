@@ -66,7 +66,16 @@ int main(void) {
         for (int i = 0; i < T; ++i) { x += 1 + (x * 2654435761u) % 300000000ull; t[i] = (((x & 0xFFFFFFFFFFull) << 6) | 0x2A) | (1ull << 48); p[i] = (23ull << 52) | (1ull << 32) | (uint64_t)i; }
         const char *contigs[] = {"c1"};
         const char *path = getenv("FFH_MOCK_DB") ? getenv("FFH_MOCK_DB") : "/tmp/ffh_mock_fault_db";
-        if (ffh_db_write(path, 3, 7, contigs, 1, t, T, p, T) == FFH_OK && ctx) { STEP(ffh_db_open(ctx, path, 0, 0)); }
+        if (ffh_db_write(path, 3, 7, contigs, 1, t, T, p, T) == FFH_OK && ctx) {
+            STEP(ffh_db_open(ctx, path, 0, 0));
+            const char *modes[][2] = {{"FFH_INFLATE", "host"}, {"FFH_LOAD_PIPELINE", "1"}};   /* the loaders with host threads of their own (read when a context is created) */
+            for (int m = 0; m < 2; ++m) {
+                setenv(modes[m][0], modes[m][1], 1);
+                ffh_ctx *c2 = ffh_create(0, 0);
+                if (c2) { STEP(ffh_db_open(c2, path, 0, 0)); ffh_destroy(c2); } else ++errors;
+                unsetenv(modes[m][0]);
+            }
+        }
     }
     /* ---- the rest of the ABI's entry points that allocate or copy: score, bulge search, shard totals, the two-step shard epilogue, the indexer ---- */
     if (ctx) {
