@@ -241,3 +241,15 @@ def test_fault_injection_over_the_mock_runtime(tmp_path):
     for n in range(1, n_news + 8):
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(env2, MOCK_NEW_FAIL_AT=str(n)))
         assert r.returncode == 0 and " live 0 bad_frees 0 " in r.stdout, (n, (r.stdout + r.stderr)[-2500:])
+
+
+def test_python_bindings_over_the_mock_runtime(tmp_path):
+    """round 6: flashfry_amd.capi's new bindings (Context.share, Pipe, Comm.set_exchange, ffh_get_bounding) called end to end over the mock
+    runtime -- argument types, result construction, error mapping -- on an empty database (tests/mock_hip/python_bindings_main.py)"""
+    mock = os.path.join(ROOT, "tests", "mock_hip")
+    so = str(tmp_path / "libmock_hip.so")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(mock, "mock_hip.c"), "-lpthread", "-ldl"])
+    env = dict(os.environ, LD_PRELOAD=so)
+    env.pop("FFH_LIBRARY", None)
+    r = subprocess.run([sys.executable, os.path.join(mock, "python_bindings_main.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "python bindings over the mock runtime: ok" in r.stdout and "ERROR" not in r.stdout, (r.stdout + r.stderr)[-3000:]
