@@ -58,7 +58,7 @@ class DbInfo(C.Structure):
 class LoadStats(C.Structure):
     _fields_ = [("open_ms", C.c_double), ("inflate_ms", C.c_double), ("decode_ms", C.c_double), ("prepare_ms", C.c_double),
                 ("compressed_bytes", C.c_uint64), ("raw_bytes", C.c_uint64), ("threads", C.c_uint32), ("reserved", C.c_uint32),
-                ("device_inflate_ms", C.c_double)]
+                ("device_inflate_ms", C.c_double), ("alloc_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -155,6 +155,9 @@ typedef struct ffh_load_stats {
     uint32_t threads;          /* host threads that staged (or inflated) */
     uint32_t reserved;
     double device_inflate_ms;  /* part of inflate_ms spent in the device inflate + CRC kernels (0 with FFH_INFLATE=host) */
+    double alloc_ms;           /* host wall time the calling thread spent inside hipMalloc / hipFree during the load (round 6): part of the
+                                  stages above, wherever a buffer had to grow -- GB-sized allocations right after another context's have been
+                                  freed are where a load can lose a second without a kernel running */
 } ffh_load_stats;
 int ffh_db_load_stats(const ffh_ctx *ctx, ffh_load_stats *out);
 /* contig names of the database header (1-based ids as in BitPosition.scala:38-49); NULL past the end */
